@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Run once in the build container (needs /root/reference; never on the GPU box):
+    python tests/golden/make_golden.py [--skip-slow]
+
+What it does
+  * copies the reference's own test/example DATA files (alignments only) into
+    tests/golden/data/ and writes the toy / trimmed alignments derived from them;
+  * plmDCA: calls the reference's compiled C++ (oracle/_ref/libpydca_ref.so, built by
+    `make -C oracle ref` from the sources under /root/reference) for the de-duplicated
+    sequences, weights, initial x and (x, fx, g) triples of PlmDCA::gradient, plus a few
+    full `plmdcaBackend` runs (1 thread => deterministic);
+  * mfDCA: imports the reference's Python package from /root/reference.  numba and
+    Biopython are not installed in the image, so two probe stubs are put on sys.path in
+    a temp dir: `numba.jit` = identity decorator, `prange` = range, and a minimal
+    `Bio.AlignIO.read` / `Bio.Align.MultipleSeqAlignment`.  The stubbed import is
+    validated against the values published in examples/pydca_demo.ipynb cell 10
+    (KAT_MF below) before anything is written.
+No reference source text is stored: fixtures are inputs and numeric outputs only.
+"""
+import argparse
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+DATA = os.path.join(HERE, "data")
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import plm as oplm  # noqa: E402
+
+# examples/pydca_demo.ipynb, cell 10 (mfDCA) and cell 5 (plmDCA) outputs -- published values
+KAT_MF = [((44, 56), 4.290005464965937), ((16, 28), 4.210860173400806),
+          ((17, 27), 4.207758141824402), ((45, 55), 4.190480172499375),
+          ((43, 57), 4.039065434604404)]
+KAT_PLM = [((45, 55), 2.571105010148373), ((44, 56), 2.5499034354788233),
+           ((16, 28), 2.530926710394089), ((17, 27), 2.502918758504699),
+           ((43, 57), 2.4373260100372316)]
+
+
+def read_records(path):
+    recs, name, cur = [], None, []
+    with open(path) as fh:
+        for line in fh:
+            line = line.rstrip("\n")
+            if line.startswith(">"):
+                if name is not None:
+                    recs.append((name, "".join(cur)))
+                name, cur = line[1:], []
+            elif line.strip():
+                cur.append(line.strip())
+    if name is not None:
+        recs.append((name, "".join(cur)))
+    return recs
+
+
+def write_fasta(path, recs):
+    with open(path, "w") as fh:
+        for name, seq in recs:
+            fh.write(">%s\n%s\n" % (name, seq))
+
+
+def make_toy(path, alphabet, n, L, seed):
+    """Small random alignment with clusters (so reweighting matters), a few exact
+    duplicates (so dedup matters) and lower-case letters (so toupper matters)."""
+    rng = np.random.default_rng(seed)
+    q = len(alphabet)
+    prof = rng.dirichlet(0.5 * np.ones(q), size=L)
+    founders = np.stack([[rng.choice(q, p=prof[i]) for i in range(L)] for _ in range(max(2, n // 6))])
+    rows = []
+    for k in range(n):
+        r = founders[rng.integers(len(founders))].copy()
+        m = rng.random(L) < 0.25
+        r[m] = [rng.choice(q, p=prof[i]) for i in np.nonzero(m)[0]]
+        rows.append(r)
+    for k in range(3):
+        rows[n - 1 - k] = rows[k].copy()
+    recs = []
+    for k, r in enumerate(rows):
+        s = "".join(alphabet[v] for v in r)
+        if k % 7 == 3:
+            s = s.lower()
+        recs.append(("t%03d" % k, s))
+    write_fasta(path, recs)
+
+
+def install_stubs(tmp):
+    with open(os.path.join(tmp, "numba.py"), "w") as fh:
+        fh.write("def jit(*a, **k):\n"
+                 "    if len(a) == 1 and callable(a[0]) and not k:\n        return a[0]\n"
+                 "    return lambda f: f\nprange = range\n")
+    os.makedirs(os.path.join(tmp, "Bio"))
+    open(os.path.join(tmp, "Bio", "__init__.py"), "w").close()
+    with open(os.path.join(tmp, "Bio", "Align.py"), "w") as fh:
+        fh.write("class MultipleSeqAlignment(list):\n    pass\n")
+    with open(os.path.join(tmp, "Bio", "AlignIO.py"), "w") as fh:
+        fh.write(
+            "from .Align import MultipleSeqAlignment\n"
+            "class _Rec:\n"
+            "    def __init__(self, i, s):\n        self.id = i; self.seq = s\n"
+            "def read(fn, fmt):\n"
+            "    recs, name, cur = MultipleSeqAlignment(), None, []\n"
+            "    for line in open(fn):\n"
+            "        line = line.strip()\n"
+            "        if line.startswith('>'):\n"
+            "            if name is not None: recs.append(_Rec(name, ''.join(cur)))\n"
+            "            name, cur = line[1:], []\n"
+            "        elif line: cur.append(line)\n"
+            "    if name is not None: recs.append(_Rec(name, ''.join(cur)))\n"
+            "    return recs\n")
+    sys.path[:0] = [tmp, REF]
+
+
+def perturbed(x0, L, q):
+    x = x0.copy()
+    k = np.arange(x.size - L * q, dtype=np.float64)
+    x[L * q:] = (0.05 * np.sin(0.37 * k)).astype(x.dtype)
+    return x
+
+
+def plm_golden(tag, path, bio, L, q, seqid, lh, lJ, full_run=None, subsample=None):
+    ref = oplm.Reference(path, bio, L, q, seqid, lh, lJ, threads=1)
+    out = dict(L=L, q=q, seqid=np.float32(seqid), lambda_h=np.float32(lh), lambda_J=np.float32(lJ),
+               X=ref.seqs(), w=ref.weights(), raw_count=len(read_records(path)))
+    x0 = ref.init_x()
+    f0, g0 = ref.gradient(x0)
+    xp = perturbed(x0, L, q)
+    f1, g1 = ref.gradient(xp)
+    out.update(fx0=np.float32(f0), fx1=np.float32(f1))
+    if subsample:
+        idx = np.arange(0, x0.size, subsample)
+        out.update(idx=idx, h0=x0[:L * q], g0_sub=g0[idx], g1_sub=g1[idx],
+                   g0_norm=np.linalg.norm(g0.astype(np.float64)), g1_norm=np.linalg.norm(g1.astype(np.float64)))
+    else:
+        out.update(x0=x0, g0=g0, g1=g1)
+    if full_run:
+        for name, (mit, thr) in full_run.items():
+            out["run_%s" % name] = ref.backend(path, bio, seqid, lh, lJ, mit, threads=thr)
+            out["run_%s_max_iterations" % name] = mit
+    ref.close()
+    np.savez_compressed(os.path.join(HERE, "plm_%s.npz" % tag), **out)
+    print("plm_%s: N'=%d  fx0=%.6f fx1=%.6f" % (tag, out["X"].shape[0], f0, f1))
+
+
+def mf_golden(tag, path, bio, pseudocount, seqid, stages):
+    from pydca.meanfield_dca import meanfield_dca
+    inst = meanfield_dca.MeanFieldDCA(path, bio, pseudocount=pseudocount, seqid=seqid)
+    out = dict(X=np.array(inst.alignment, dtype=np.int32), w=np.array(inst.sequences_weight),
+               pseudocount=pseudocount, seqid=seqid, q=inst.num_site_states)
+    if stages:
+        fi = inst.get_single_site_freqs()
+        out["fi"] = fi.copy()
+        out["reg_fi"] = inst.get_reg_single_site_freqs()
+        out["fij"] = inst.get_pair_site_freqs()
+        reg_fij = inst.get_reg_pair_site_freqs()
+        out["reg_fij"] = reg_fij
+        corr = inst.construct_corr_mat(out["reg_fi"], reg_fij)
+        out["corr_mat"] = corr
+        out["couplings"] = inst.compute_couplings(corr)
+    fn = inst.compute_sorted_FN()
+    apc = inst.compute_sorted_FN_APC()
+    out["fn_pairs"] = np.array([p for p, _ in fn], dtype=np.int32)
+    out["fn_scores"] = np.array([s for _, s in fn])
+    out["apc_pairs"] = np.array([p for p, _ in apc], dtype=np.int32)
+    out["apc_scores"] = np.array([s for _, s in apc])
+    np.savez_compressed(os.path.join(HERE, "mf_%s.npz" % tag), **out)
+    print("mf_%s: N'=%d  top=%s" % (tag, out["X"].shape[0], apc[:2]))
+    return apc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-slow", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(DATA, exist_ok=True)
+    oplm.build(ref=True)
+
+    # ---- data files ---------------------------------------------------------
+    rf = os.path.join(DATA, "MSA_RF00167.fa")
+    pf = os.path.join(DATA, "PF02826.faa")
+    shutil.copyfile(os.path.join(REF, "examples", "MSA_RF00167.fa"), rf)
+    shutil.copyfile(os.path.join(REF, "examples", "ref_RF00167.fa"), os.path.join(DATA, "ref_RF00167.fa"))
+    shutil.copyfile(os.path.join(REF, "tests", "tests_input", "PF02826.faa"), pf)
+    for p in (rf, pf, os.path.join(DATA, "ref_RF00167.fa")):
+        os.chmod(p, 0o644)
+    recs = read_records(rf)
+    refrec = [s for n, s in recs if "REFERENCE" in n][0]
+    keep = [k for k, ch in enumerate(refrec) if ch not in "-.~"]
+    rf71 = os.path.join(DATA, "MSA_RF00167_trimmed71.fa")
+    write_fasta(rf71, [(n, "".join(s[k] for k in keep)) for n, s in recs])
+    assert len(keep) == 71
+    toy_rna = os.path.join(DATA, "toy_rna.fa")
+    toy_prot = os.path.join(DATA, "toy_protein.fa")
+    make_toy(toy_rna, "ACGU-", 48, 10, 7)
+    make_toy(toy_prot, "ACDEFGHIKLMNPQRSTVWY-", 40, 8, 11)
+
+    # ---- plmDCA via the compiled reference -------------------------------------
+    plm_golden("toy_rna", toy_rna, 2, 10, 5, 0.8, 1.8, 1.8, full_run={"a": (100, 1)})
+    plm_golden("toy_protein", toy_prot, 1, 8, 21, 0.8, 1.0, 5.0, full_run={"a": (30, 1)})
+    plm_golden("rf71", rf71, 2, 71, 5, 0.8, 1.0, 20.0, full_run={"a": (500, 1), "b": (500, 8)})
+    plm_golden("rf00167", rf, 2, 102, 5, 0.8, 20.2, 20.2, subsample=97)
+    if not args.skip_slow:
+        plm_golden("pf02826", pf, 1, 195, 21, 0.8, 1.0, 50.0, subsample=9973)
+
+    # ---- mfDCA via the stubbed import of the reference ---------------------------
+    tmp = tempfile.mkdtemp(prefix="pydca_stubs_")
+    try:
+        install_stubs(tmp)
+        apc = mf_golden("rf71", rf71, "rna", 0.5, 0.8, stages=False)
+        for (pair, val), (rp, rv) in zip(KAT_MF, apc):
+            assert tuple(rp) == pair and abs(rv - val) <= 1e-12 * abs(val), (pair, val, rp, rv)
+        print("stubbed import reproduces the notebook mfDCA KAT")
+        mf_golden("toy_rna", toy_rna, "rna", 0.5, 0.8, stages=True)
+        mf_golden("toy_protein", toy_prot, "protein", 0.5, 0.8, stages=True)
+        mf_golden("toy_rna_theta02_seqid1", toy_rna, "rna", 0.2, 1.0, stages=True)
+        mf_golden("rf00167", rf, "rna", 0.5, 0.8, stages=False)
+        if not args.skip_slow:
+            mf_golden("pf02826", pf, "protein", 0.5, 0.8, stages=False)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    np.savez(os.path.join(HERE, "kat_notebook.npz"),
+             mf_pairs=np.array([p for p, _ in KAT_MF]), mf_scores=np.array([s for _, s in KAT_MF]),
+             plm_pairs=np.array([p for p, _ in KAT_PLM]), plm_scores=np.array([s for _, s in KAT_PLM]))
+
+
+if __name__ == "__main__":
+    main()
