@@ -1,0 +1,164 @@
+/* dca_hip.h -- C ABI of the MI355X-native DCA compute core (libdca_hip.so).
+ *
+ * Plain C: opaque handle, raw pointers and sizes, int status codes.  No torch / C++
+ * types cross this boundary and nothing throws across it.  Host buffers are
+ * caller-owned, C-contiguous.  A context owns one HIP device and one HIP stream;
+ * calls on one context are serialised by the caller, different contexts are
+ * independent (no globals except the thread-local error string).
+ *
+ * Each entry names the reference interface it replaces (paths relative to the
+ * reference repository root).
+ */
+#ifndef DCA_HIP_H
+#define DCA_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status codes */
+#define DCA_OK 0
+#define DCA_ERR_ARG (-1)        /* invalid argument / call order */
+#define DCA_ERR_IO (-2)         /* cannot open MSA file (reference: throws, plmdca_numerics.cpp:743-746) */
+#define DCA_ERR_RESIDUE (-3)    /* character outside the reference's table or short line (reference: std::out_of_range, :752) */
+#define DCA_ERR_NOMEM (-4)
+#define DCA_ERR_HIP (-5)        /* HIP runtime error; text in dca_last_error() */
+#define DCA_ERR_NO_DEVICE (-6)  /* no usable gfx950 device: the product never falls back to a CPU path */
+#define DCA_ERR_NOT_SPD (-7)    /* correlation matrix not positive definite (reference: numpy LinAlgError, meanfield_dca.py:542-548) */
+#define DCA_ERR_STATE (-8)      /* required earlier stage has not been run */
+
+#define DCA_BIOMOLECULE_PROTEIN 1 /* q = 21, plmdca.py:57 */
+#define DCA_BIOMOLECULE_RNA 2     /* q = 5 */
+
+#define DCA_F32 32
+#define DCA_F64 64
+
+/* carry_mode of dca_plm_configure */
+#define DCA_CARRY_EXACT 0   /* mathematically exact pseudolikelihood gradient (opt-in) */
+#define DCA_CARRY_CHUNKED 1 /* reference semantics (plmdca_numerics.cpp:492-530 carry-over), chunk-parallel scan with warm-up */
+#define DCA_CARRY_SERIAL 2  /* reference semantics, one strictly serial chain per site (slow; checking mode) */
+
+typedef struct dca_ctx dca_ctx;
+
+const char* dca_last_error(void);
+int dca_device_count(void);
+const char* dca_version(void);
+
+/* ------------------------------------------------------------------ drop-in FFI
+ * Same symbols, signatures and meaning as the reference's ctypes boundary
+ * (pydca/plmdca/plmdcaBackend.cpp:151-156 and :204; bound in pydca/plmdca/plmdca.py:79-89).
+ * Returns a malloc()'d block of L*q + L(L-1)/2*q*q floats, or NULL on any error
+ * (reason in dca_last_error()); release it with freeFieldsAndCouplings (free()).
+ * num_threads is accepted and ignored (the work runs on the GPU). */
+float* plmdcaBackend(unsigned short biomolecule, unsigned short num_site_states, const char* msa_file,
+                     unsigned int seqs_len, float seqid, float lambda_h, float lambda_J,
+                     unsigned int max_iteration, unsigned int num_threads, bool verbose);
+void freeFieldsAndCouplings(void* h_and_J);
+
+/* ------------------------------------------------------------------ MSA input
+ * dca_read_msa: PlmDCA::readSequencesFromFile (plmdca_numerics.cpp:685-767): one
+ * sequence per non-empty, non-'>' line, first L characters, 0-based codes with
+ * gap = q-1, exact duplicates dropped keeping the first occurrence.
+ * Returns the number of unique rows (>=0) or a DCA_ERR_*; raw_count (optional)
+ * receives the number of sequence lines read. */
+int dca_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count);
+int dca_count_msa_lines(const char* path);
+
+/* ------------------------------------------------------------------ context */
+int dca_create(dca_ctx** out, int device, int precision /* DCA_F32 | DCA_F64 */);
+void dca_destroy(dca_ctx* ctx);
+/* X: N x L, 0-based codes < q, gap = q-1 (the C++ coding; the Python mfDCA layer
+ * converts from the reference's 1-based coding).  Copies to the device. */
+int dca_set_msa(dca_ctx* ctx, const uint8_t* X, int N, int L, int q);
+
+/* Sequence weights: PlmDCA::computeSeqsWeight (plmdca_numerics.cpp:611-671) when
+ * compare_precision == DCA_F32 ((float)ident/(float)L > (float)seqid) and
+ * msa_numerics.compute_sequences_weight (meanfield_dca/msa_numerics.py:13-50) when
+ * DCA_F64.  Integer-exact. */
+int dca_compute_weights(dca_ctx* ctx, double seqid, int compare_precision);
+int dca_set_weights(dca_ctx* ctx, const double* w);           /* externally computed weights */
+int dca_get_weights(dca_ctx* ctx, double* w_out);             /* N values: 1/count */
+int dca_get_weight_counts(dca_ctx* ctx, uint32_t* counts_out);/* N values (after dca_compute_weights) */
+int dca_get_meff(dca_ctx* ctx, double* meff_out);
+
+/* ------------------------------------------------------------------ plmDCA
+ * dca_plm_configure fixes lambda_h / lambda_J (PlmDCA ctor, plmdca_numerics.cpp:17-48),
+ * the carry mode and the scan geometry (chunk sequences per independent scan, warm-up
+ * steps; 0 = defaults 128 / 40).  halo = number of leading sequences of this context's
+ * MSA that only warm up the scan and do not contribute to fx/g (used by sequence
+ * sharding; 0 otherwise).  add_regulariser = 0 on every shard except one. */
+int dca_plm_configure(dca_ctx* ctx, double lambda_h, double lambda_J, int carry_mode,
+                      int chunk, int warmup, int halo, int add_regulariser);
+size_t dca_plm_num_params(int L, int q);
+/* x <- initial fields/couplings: PlmDCA::initFieldsAndCouplings (plmdca_numerics.cpp:207-249) */
+int dca_plm_init_x(dca_ctx* ctx);
+int dca_plm_set_x(dca_ctx* ctx, const void* x, int dtype);
+int dca_plm_get_x(dca_ctx* ctx, void* x_out, int dtype);
+/* fx, g at the context's current x: PlmDCA::gradient (plmdca_numerics.cpp:436-607) */
+int dca_plm_gradient(dca_ctx* ctx, double* fx_out);
+int dca_plm_get_g(dca_ctx* ctx, void* g_out, int dtype);
+
+/* Optional reduction hook for sequence sharding: called after the local data term is
+ * on the device, before the optimiser sees it.  g_dev/fx_dev are DEVICE pointers
+ * (count elements of dtype / one double); the hook must sum them over all shards in
+ * place and return 0.  The stream is idle when the hook runs. */
+typedef int (*dca_reduce_hook)(void* user, void* g_dev, size_t count, int dtype, void* fx_dev);
+int dca_plm_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user);
+
+typedef struct {
+    int status;        /* libLBFGS code as the reference would report it (lbfgs.h:76-149): 0, -997, -998, -1001 ... */
+    int iterations;    /* completed iterations since dca_plm_lbfgs_begin */
+    int evaluations;   /* objective/gradient evaluations since dca_plm_lbfgs_begin */
+    int finished;      /* 1 once a terminal status was reached */
+    double fx, xnorm, gnorm, step;
+    double seconds;    /* wall time spent inside dca_plm_lbfgs_iterate so far */
+} dca_plm_stats;
+
+/* L-BFGS with More-Thuente line search and the backend's parameters
+ * (plmdcaBackend.cpp:68-75: m=5, epsilon=1e-3, max_linesearch=5, ftol=1e-4; the rest
+ * libLBFGS defaults, lbfgs.cpp:116-121).  begin() evaluates at the current x;
+ * iterate() runs up to `iterations` more iterations (resumable); max_iterations is the
+ * reference's cap (-997 when exceeded; 0 = unlimited). */
+int dca_plm_lbfgs_begin(dca_ctx* ctx, int max_iterations, int verbose);
+int dca_plm_lbfgs_iterate(dca_ctx* ctx, int iterations, dca_plm_stats* stats_out);
+
+/* Frobenius-norm scores of the current x: PlmDCA.get_couplings_no_gap_state +
+ * compute_sorted_FN / compute_sorted_FN_APC (plmdca.py:246-268, :437-524), in pair
+ * order (0,1),(0,2)...; sorting is left to the host. */
+int dca_plm_scores(dca_ctx* ctx, int apc, double* scores_out);
+
+/* ------------------------------------------------------------------ mfDCA
+ * Stage functions mirror pydca/meanfield_dca/msa_numerics.py; all float64. */
+int dca_mf_single_site_freqs(dca_ctx* ctx, double* fi_out /* L*q, gap last (:53-89) */);
+int dca_mf_pair_site_freqs(dca_ctx* ctx, double* fij_out /* pairs*(q-1)^2 (:182-229) */);
+/* regularise (:92-125, :231-267) + build the L(q-1) x L(q-1) correlation matrix (:270-318) */
+int dca_mf_corr_mat(dca_ctx* ctx, double pseudocount, double* corr_out /* may be NULL */);
+/* couplings = -inv(C) (:321-342) by blocked Cholesky on f64 MFMA */
+int dca_mf_couplings(dca_ctx* ctx, double* couplings_out /* may be NULL */);
+/* FN / FN_APC of the couplings (meanfield_dca.py:902-988), pair order */
+int dca_mf_scores(dca_ctx* ctx, int apc, double* scores_out);
+/* whole chain on the device: counts -> C -> -inv -> scores */
+int dca_mf_run(dca_ctx* ctx, double pseudocount, int apc, double* scores_out, double* couplings_out /* may be NULL */);
+/* stage API on caller-provided arrays: construct_corr_mat (:270-318) from regularised
+ * frequencies (reg_fi: L*q, reg_fij: pairs*(q-1)^2) -> corr_out: (L(q-1))^2 */
+int dca_mf_corr_from_freqs(dca_ctx* ctx, const double* reg_fi, const double* reg_fij, int L, int q, double* corr_out);
+/* test hook / stage API: inverse of a host SPD matrix through the same device path */
+int dca_spd_inverse(dca_ctx* ctx, const double* A, int n, double* Ainv_out);
+
+/* ------------------------------------------------------------------ timing
+ * When profiling is on, selected kernels are bracketed with HIP events on the
+ * context's stream.  dca_get_kernel_time returns accumulated ms and launch count
+ * for a kernel tag ("weights", "plm_logits", "plm_softmax", "plm_scatter", "plm_expand",
+ * "plm_fold", "lbfgs_vec", "mf_counts", "mf_inverse", "scores"). */
+int dca_set_profiling(dca_ctx* ctx, int on);
+int dca_get_kernel_time(dca_ctx* ctx, const char* tag, double* ms_out, int* launches_out);
+int dca_reset_kernel_times(dca_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCA_HIP_H */

@@ -1,0 +1,309 @@
+"""ctypes binding of libdca_hip.so (include/dca_hip.h).
+
+The product has no CPU fallback: if the shared library is missing or no gfx950 device
+is visible, every compute entry point raises -- it never routes to another
+implementation.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdca_hip.so")
+
+DCA_OK = 0
+DCA_ERR_NOT_SPD = -7
+DCA_F32, DCA_F64 = 32, 64
+CARRY_EXACT, CARRY_CHUNKED, CARRY_SERIAL = 0, 1, 2
+PROTEIN, RNA = 1, 2
+
+
+class DcaBackendError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libdca_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class PlmStats(C.Structure):
+    _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("evaluations", C.c_int), ("finished", C.c_int),
+                ("fx", C.c_double), ("xnorm", C.c_double), ("gnorm", C.c_double), ("step", C.c_double),
+                ("seconds", C.c_double)]
+
+
+REDUCE_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+
+def build(verbose=False):
+    """Compile libdca_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j", str(min(8, os.cpu_count() or 1))]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DcaBackendError(-100, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(pydca_amd has no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+    sig = {
+        "dca_last_error": (C.c_char_p, []),
+        "dca_version": (C.c_char_p, []),
+        "dca_device_count": (i, []),
+        "dca_read_msa": (i, [C.c_char_p, i, i, vp, i, C.POINTER(i)]),
+        "dca_count_msa_lines": (i, [C.c_char_p]),
+        "dca_create": (i, [C.POINTER(vp), i, i]),
+        "dca_destroy": (None, [vp]),
+        "dca_set_msa": (i, [vp, vp, i, i, i]),
+        "dca_compute_weights": (i, [vp, d, i]),
+        "dca_set_weights": (i, [vp, vp]),
+        "dca_get_weights": (i, [vp, vp]),
+        "dca_get_weight_counts": (i, [vp, vp]),
+        "dca_get_meff": (i, [vp, C.POINTER(d)]),
+        "dca_plm_configure": (i, [vp, d, d, i, i, i, i, i]),
+        "dca_plm_num_params": (sz, [i, i]),
+        "dca_plm_init_x": (i, [vp]),
+        "dca_plm_set_x": (i, [vp, vp, i]),
+        "dca_plm_get_x": (i, [vp, vp, i]),
+        "dca_plm_gradient": (i, [vp, C.POINTER(d)]),
+        "dca_plm_get_g": (i, [vp, vp, i]),
+        "dca_plm_set_reduce_hook": (i, [vp, REDUCE_HOOK, vp]),
+        "dca_plm_lbfgs_begin": (i, [vp, i, i]),
+        "dca_plm_lbfgs_iterate": (i, [vp, i, C.POINTER(PlmStats)]),
+        "dca_plm_scores": (i, [vp, i, vp]),
+        "dca_mf_single_site_freqs": (i, [vp, vp]),
+        "dca_mf_pair_site_freqs": (i, [vp, vp]),
+        "dca_mf_corr_mat": (i, [vp, d, vp]),
+        "dca_mf_couplings": (i, [vp, vp]),
+        "dca_mf_scores": (i, [vp, i, vp]),
+        "dca_mf_run": (i, [vp, d, i, vp, vp]),
+        "dca_mf_corr_from_freqs": (i, [vp, vp, vp, i, i, vp]),
+        "dca_spd_inverse": (i, [vp, vp, i, vp]),
+        "dca_set_profiling": (i, [vp, i]),
+        "dca_get_kernel_time": (i, [vp, C.c_char_p, C.POINTER(d), C.POINTER(i)]),
+        "dca_reset_kernel_times": (i, [vp]),
+        "plmdcaBackend": (C.c_void_p, [C.c_ushort, C.c_ushort, C.c_char_p, C.c_uint, C.c_float, C.c_float, C.c_float,
+                                       C.c_uint, C.c_uint, C.c_bool]),
+        "freeFieldsAndCouplings": (None, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_read_msa", "dca_count_msa_lines", "dca_create",
+           "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
+           "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_num_params", "dca_plm_init_x",
+           "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook",
+           "dca_plm_lbfgs_begin", "dca_plm_lbfgs_iterate", "dca_plm_scores", "dca_mf_single_site_freqs",
+           "dca_mf_pair_site_freqs", "dca_mf_corr_mat", "dca_mf_couplings", "dca_mf_scores", "dca_mf_run",
+           "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_set_profiling", "dca_get_kernel_time",
+           "dca_reset_kernel_times", "plmdcaBackend", "freeFieldsAndCouplings"]
+
+
+def check(rc):
+    if rc != DCA_OK:
+        raise DcaBackendError(rc, lib().dca_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def read_msa(path, biomolecule, L):
+    """Reference C++ reader semantics (plmdca_numerics.cpp:685-767) -> (uint8[N',L], raw_count)."""
+    l = lib()
+    cap = l.dca_count_msa_lines(os.fsencode(path))
+    if cap < 0:
+        check(cap)
+    out = np.zeros((max(cap, 1), L), dtype=np.uint8)
+    raw = C.c_int(0)
+    n = l.dca_read_msa(os.fsencode(path), int(biomolecule), int(L), _ptr(out), cap, C.byref(raw))
+    if n < 0:
+        check(n)
+    return np.ascontiguousarray(out[:n]), raw.value
+
+
+class Context:
+    """One GPU, one stream, one alignment (include/dca_hip.h `dca_ctx`)."""
+
+    def __init__(self, device=0, precision=DCA_F32):
+        self._l = lib()
+        self._h = C.c_void_p()
+        check(self._l.dca_create(C.byref(self._h), int(device), int(precision)))
+        self.precision = precision
+        self.N = self.L = self.q = 0
+        self._hook = None
+
+    def close(self):
+        if self._h:
+            self._l.dca_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- alignment / weights
+    def set_msa(self, X, q):
+        X = np.ascontiguousarray(X, dtype=np.uint8)
+        self.N, self.L, self.q = X.shape[0], X.shape[1], int(q)
+        check(self._l.dca_set_msa(self._h, _ptr(X), self.N, self.L, self.q))
+
+    def compute_weights(self, seqid, compare_precision=DCA_F32):
+        check(self._l.dca_compute_weights(self._h, float(seqid), int(compare_precision)))
+        return self.weights()
+
+    def set_weights(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        assert w.shape == (self.N,)
+        check(self._l.dca_set_weights(self._h, _ptr(w)))
+
+    def weights(self):
+        w = np.zeros(self.N, dtype=np.float64)
+        check(self._l.dca_get_weights(self._h, _ptr(w)))
+        return w
+
+    def weight_counts(self):
+        c = np.zeros(self.N, dtype=np.uint32)
+        check(self._l.dca_get_weight_counts(self._h, _ptr(c)))
+        return c
+
+    def meff(self):
+        v = C.c_double(0)
+        check(self._l.dca_get_meff(self._h, C.byref(v)))
+        return v.value
+
+    # ---- plmDCA
+    def num_params(self):
+        return int(self._l.dca_plm_num_params(self.L, self.q))
+
+    def plm_configure(self, lambda_h, lambda_J, carry_mode=CARRY_CHUNKED, chunk=0, warmup=0, halo=0, add_regulariser=1):
+        check(self._l.dca_plm_configure(self._h, float(lambda_h), float(lambda_J), int(carry_mode), int(chunk),
+                                        int(warmup), int(halo), int(add_regulariser)))
+
+    def plm_init_x(self):
+        check(self._l.dca_plm_init_x(self._h))
+
+    def plm_set_x(self, x):
+        x = np.ascontiguousarray(x)
+        dt = DCA_F32 if x.dtype == np.float32 else DCA_F64
+        if dt == DCA_F64:
+            x = np.ascontiguousarray(x, dtype=np.float64)
+        check(self._l.dca_plm_set_x(self._h, _ptr(x), dt))
+
+    def plm_get_x(self, dtype=np.float32):
+        x = np.zeros(self.num_params(), dtype=dtype)
+        check(self._l.dca_plm_get_x(self._h, _ptr(x), DCA_F32 if x.dtype == np.float32 else DCA_F64))
+        return x
+
+    def plm_get_g(self, dtype=np.float32):
+        g = np.zeros(self.num_params(), dtype=dtype)
+        check(self._l.dca_plm_get_g(self._h, _ptr(g), DCA_F32 if g.dtype == np.float32 else DCA_F64))
+        return g
+
+    def plm_gradient(self):
+        fx = C.c_double(0)
+        check(self._l.dca_plm_gradient(self._h, C.byref(fx)))
+        return fx.value
+
+    def plm_set_reduce_hook(self, pyfunc):
+        """pyfunc(g_dev_ptr:int, count:int, dtype:int, fx_dev_ptr:int) -> 0 on success."""
+        def tramp(user, g_dev, count, dtype, fx_dev):
+            try:
+                return int(pyfunc(g_dev, count, dtype, fx_dev) or 0)
+            except Exception:   # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._hook = REDUCE_HOOK(tramp) if pyfunc is not None else C.cast(None, REDUCE_HOOK)
+        check(self._l.dca_plm_set_reduce_hook(self._h, self._hook, None))
+
+    def plm_lbfgs_begin(self, max_iterations, verbose=False):
+        check(self._l.dca_plm_lbfgs_begin(self._h, int(max_iterations), int(bool(verbose))))
+
+    def plm_lbfgs_iterate(self, iterations):
+        st = PlmStats()
+        check(self._l.dca_plm_lbfgs_iterate(self._h, int(iterations), C.byref(st)))
+        return st
+
+    def plm_scores(self, apc=True):
+        out = np.zeros(self.L * (self.L - 1) // 2, dtype=np.float64)
+        check(self._l.dca_plm_scores(self._h, int(bool(apc)), _ptr(out)))
+        return out
+
+    # ---- mfDCA
+    def mf_single_site_freqs(self):
+        out = np.zeros((self.L, self.q), dtype=np.float64)
+        check(self._l.dca_mf_single_site_freqs(self._h, _ptr(out)))
+        return out
+
+    def mf_pair_site_freqs(self):
+        qm = self.q - 1
+        out = np.zeros((self.L * (self.L - 1) // 2, qm, qm), dtype=np.float64)
+        check(self._l.dca_mf_pair_site_freqs(self._h, _ptr(out)))
+        return out
+
+    def mf_corr_mat(self, pseudocount, want=True):
+        n = self.L * (self.q - 1)
+        out = np.zeros((n, n), dtype=np.float64) if want else None
+        check(self._l.dca_mf_corr_mat(self._h, float(pseudocount), _ptr(out) if want else None))
+        return out
+
+    def mf_couplings(self, want=True):
+        n = self.L * (self.q - 1)
+        out = np.zeros((n, n), dtype=np.float64) if want else None
+        check(self._l.dca_mf_couplings(self._h, _ptr(out) if want else None))
+        return out
+
+    def mf_scores(self, apc=True):
+        out = np.zeros(self.L * (self.L - 1) // 2, dtype=np.float64)
+        check(self._l.dca_mf_scores(self._h, int(bool(apc)), _ptr(out)))
+        return out
+
+    def mf_run(self, pseudocount, apc=True, want_couplings=False):
+        n = self.L * (self.q - 1)
+        scores = np.zeros(self.L * (self.L - 1) // 2, dtype=np.float64)
+        J = np.zeros((n, n), dtype=np.float64) if want_couplings else None
+        check(self._l.dca_mf_run(self._h, float(pseudocount), int(bool(apc)), _ptr(scores),
+                                 _ptr(J) if want_couplings else None))
+        return (scores, J) if want_couplings else scores
+
+    def mf_corr_from_freqs(self, reg_fi, reg_fij, L, q):
+        reg_fi = np.ascontiguousarray(reg_fi, dtype=np.float64)
+        reg_fij = np.ascontiguousarray(reg_fij, dtype=np.float64)
+        n = L * (q - 1)
+        out = np.zeros((n, n), dtype=np.float64)
+        check(self._l.dca_mf_corr_from_freqs(self._h, _ptr(reg_fi), _ptr(reg_fij), int(L), int(q), _ptr(out)))
+        return out
+
+    def spd_inverse(self, A):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        out = np.zeros_like(A)
+        check(self._l.dca_spd_inverse(self._h, _ptr(A), A.shape[0], _ptr(out)))
+        return out
+
+    # ---- timing
+    def set_profiling(self, on=True):
+        check(self._l.dca_set_profiling(self._h, int(bool(on))))
+
+    def reset_kernel_times(self):
+        check(self._l.dca_reset_kernel_times(self._h))
+
+    def kernel_time(self, tag):
+        ms, n = C.c_double(0), C.c_int(0)
+        check(self._l.dca_get_kernel_time(self._h, tag.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

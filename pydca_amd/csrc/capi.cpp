@@ -1,0 +1,327 @@
+// extern "C" surface of libdca_hip.so (see include/dca_hip.h).
+#include <cstdlib>
+
+#include "dca_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void dca_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+void dca_flush_clocks(dca_ctx* ctx)
+{
+    for (auto& kv : ctx->clocks) {
+        for (auto& pr : kv.second.pending) {
+            float ms = 0.f;
+            hipEventSynchronize(pr.second);
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) kv.second.ms += ms;
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+#define CHECK_CTX(ctx)                                             \
+    do {                                                           \
+        if (!(ctx)) { dca_set_error("null context"); return DCA_ERR_ARG; } \
+        hipError_t _e = hipSetDevice((ctx)->device);               \
+        if (_e != hipSuccess) { dca_set_error("hipSetDevice: %s", hipGetErrorString(_e)); return DCA_ERR_HIP; } \
+    } while (0)
+
+extern "C" {
+
+const char* dca_last_error(void) { return g_err; }
+const char* dca_version(void) { return "pydca_amd libdca_hip 0.1 (gfx950)"; }
+
+int dca_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t dca_plm_num_params(int L, int q)
+{
+    return (size_t)L * q + (size_t)L * (L - 1) / 2 * (size_t)q * q;
+}
+
+int dca_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count)
+{
+    return dca_read_msa_impl(path, biomolecule, L, out, capacity, raw_count);
+}
+
+int dca_count_msa_lines(const char* path)
+{
+    FILE* fp = fopen(path, "r");
+    if (!fp) { dca_set_error("Unable to open file %s", path); return DCA_ERR_IO; }
+    int n = 0, c, first = 1, is_seq = 0, nonempty = 0;
+    while ((c = fgetc(fp)) != EOF) {
+        if (c == '\n') { if (nonempty && is_seq) ++n; first = 1; nonempty = 0; is_seq = 0; continue; }
+        if (c == '\r') continue;
+        if (first) { is_seq = (c != '>'); first = 0; }
+        nonempty = 1;
+    }
+    if (nonempty && is_seq) ++n;
+    fclose(fp);
+    return n;
+}
+
+int dca_create(dca_ctx** out, int device, int precision)
+{
+    if (!out || (precision != DCA_F32 && precision != DCA_F64)) { dca_set_error("dca_create: bad arguments"); return DCA_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        dca_set_error("no HIP device visible: libdca_hip has no CPU fallback");
+        return DCA_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { dca_set_error("device %d out of range (%d visible)", device, ndev); return DCA_ERR_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        dca_set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return DCA_ERR_NO_DEVICE;
+    }
+    dca_ctx* ctx = new dca_ctx();
+    ctx->device = device;
+    ctx->precision = precision;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dScal), 16 * sizeof(double)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->hScal), 16 * sizeof(double), hipHostMallocDefault));
+    *out = ctx;
+    return DCA_OK;
+}
+
+static void free_msa(dca_ctx* ctx)
+{
+    delete ctx->plm; ctx->plm = nullptr;
+    if (ctx->mf) { dca_free_mf_engine(ctx->mf); ctx->mf = nullptr; }
+    hipFree(ctx->dX); ctx->dX = nullptr;
+    hipFree(ctx->dCounts); ctx->dCounts = nullptr;
+    hipFree(ctx->dWd); ctx->dWd = nullptr;
+    ctx->have_weights = ctx->have_counts = false;
+}
+
+void dca_destroy(dca_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    dca_flush_clocks(ctx);
+    free_msa(ctx);
+    hipFree(ctx->dScal);
+    hipHostFree(ctx->hScal);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int dca_set_msa(dca_ctx* ctx, const uint8_t* X, int N, int L, int q)
+{
+    CHECK_CTX(ctx);
+    if (!X || N <= 0 || L <= 1 || q < 2 || q > 32) { dca_set_error("dca_set_msa: bad arguments"); return DCA_ERR_ARG; }
+    for (size_t k = 0; k < (size_t)N * L; ++k)
+        if (X[k] >= q) { dca_set_error("dca_set_msa: code %d >= q at element %zu", (int)X[k], k); return DCA_ERR_ARG; }
+    free_msa(ctx);
+    ctx->N = N; ctx->L = L; ctx->q = q;
+    ctx->Ls = (int)round_up((size_t)L, 128);
+    ctx->hX.assign(X, X + (size_t)N * L);
+    std::vector<uint8_t> padded((size_t)N * ctx->Ls, 0);
+    for (int n = 0; n < N; ++n) memcpy(padded.data() + (size_t)n * ctx->Ls, X + (size_t)n * L, (size_t)L);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dX), padded.size()));
+    HIP_TRY(hipMemcpy(ctx->dX, padded.data(), padded.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dCounts), (size_t)N * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dWd), (size_t)N * sizeof(double)));
+    return DCA_OK;
+}
+
+int dca_compute_weights(dca_ctx* ctx, double seqid, int compare_precision)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->dX) { dca_set_error("dca_set_msa first"); return DCA_ERR_STATE; }
+    if (compare_precision != DCA_F32 && compare_precision != DCA_F64) return DCA_ERR_ARG;
+    return dca_weights_compute(ctx, seqid, compare_precision);
+}
+
+int dca_set_weights(dca_ctx* ctx, const double* w)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->dX || !w) { dca_set_error("dca_set_msa first"); return DCA_ERR_STATE; }
+    HIP_TRY(hipMemcpy(ctx->dWd, w, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice));
+    double s = 0;
+    for (int n = 0; n < ctx->N; ++n) s += w[n];
+    ctx->meff = s;
+    ctx->have_weights = true;
+    ctx->have_counts = false;
+    return DCA_OK;
+}
+
+int dca_get_weights(dca_ctx* ctx, double* w_out)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_weights) { dca_set_error("weights not available"); return DCA_ERR_STATE; }
+    HIP_TRY(hipMemcpy(w_out, ctx->dWd, (size_t)ctx->N * sizeof(double), hipMemcpyDeviceToHost));
+    return DCA_OK;
+}
+
+int dca_get_weight_counts(dca_ctx* ctx, uint32_t* counts_out)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_counts) { dca_set_error("counts not available"); return DCA_ERR_STATE; }
+    HIP_TRY(hipMemcpy(counts_out, ctx->dCounts, (size_t)ctx->N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return DCA_OK;
+}
+
+int dca_get_meff(dca_ctx* ctx, double* meff_out)
+{
+    if (!ctx || !ctx->have_weights) { dca_set_error("weights not available"); return DCA_ERR_STATE; }
+    *meff_out = ctx->meff;
+    return DCA_OK;
+}
+
+// ------------------------------------------------------------------ plmDCA
+static int need_plm(dca_ctx* ctx)
+{
+    if (!ctx->dX) { dca_set_error("dca_set_msa first"); return DCA_ERR_STATE; }
+    if (!ctx->plm) ctx->plm = dca_make_plm_engine(ctx);
+    return DCA_OK;
+}
+
+int dca_plm_configure(dca_ctx* ctx, double lambda_h, double lambda_J, int carry_mode, int chunk, int warmup, int halo, int add_regulariser)
+{
+    CHECK_CTX(ctx);
+    DCA_TRY(need_plm(ctx));
+    if (carry_mode < 0 || carry_mode > 2) return DCA_ERR_ARG;
+    return ctx->plm->configure(lambda_h, lambda_J, carry_mode, chunk, warmup, halo, add_regulariser);
+}
+int dca_plm_init_x(dca_ctx* ctx) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->init_x(); }
+int dca_plm_set_x(dca_ctx* ctx, const void* x, int dtype) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->set_x(x, dtype); }
+int dca_plm_get_x(dca_ctx* ctx, void* x, int dtype) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->get_x(x, dtype); }
+int dca_plm_get_g(dca_ctx* ctx, void* g, int dtype) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->get_g(g, dtype); }
+int dca_plm_gradient(dca_ctx* ctx, double* fx_out) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->gradient(fx_out); }
+int dca_plm_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user)
+{
+    CHECK_CTX(ctx);
+    DCA_TRY(need_plm(ctx));
+    ctx->plm->hook = hook;
+    ctx->plm->hook_user = user;
+    return DCA_OK;
+}
+int dca_plm_lbfgs_begin(dca_ctx* ctx, int max_iterations, int verbose) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->lbfgs_begin(max_iterations, verbose); }
+int dca_plm_lbfgs_iterate(dca_ctx* ctx, int iterations, dca_plm_stats* st) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->lbfgs_iterate(iterations, st); }
+int dca_plm_scores(dca_ctx* ctx, int apc, double* out) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->scores(apc, out); }
+
+// ------------------------------------------------------------------ mfDCA
+static int need_mf(dca_ctx* ctx)
+{
+    if (!ctx->dX) { dca_set_error("dca_set_msa first"); return DCA_ERR_STATE; }
+    if (!ctx->have_weights) { dca_set_error("weights must be computed or set first"); return DCA_ERR_STATE; }
+    if (!ctx->mf) ctx->mf = dca_make_mf_engine(ctx);
+    return ctx->mf ? DCA_OK : DCA_ERR_NOMEM;
+}
+int dca_mf_single_site_freqs(dca_ctx* ctx, double* fi_out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_site_freqs(ctx->mf, fi_out); }
+int dca_mf_pair_site_freqs(dca_ctx* ctx, double* fij_out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_pair_freqs(ctx->mf, fij_out); }
+int dca_mf_corr_mat(dca_ctx* ctx, double pseudocount, double* corr_out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_corr(ctx->mf, pseudocount, corr_out); }
+int dca_mf_couplings(dca_ctx* ctx, double* out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_couplings(ctx->mf, out); }
+int dca_mf_scores(dca_ctx* ctx, int apc, double* out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_scores(ctx->mf, apc, out); }
+int dca_mf_run(dca_ctx* ctx, double pseudocount, int apc, double* scores_out, double* couplings_out)
+{
+    CHECK_CTX(ctx);
+    DCA_TRY(need_mf(ctx));
+    DCA_TRY(dca_mf_engine_corr(ctx->mf, pseudocount, nullptr));
+    DCA_TRY(dca_mf_engine_couplings(ctx->mf, couplings_out));
+    return dca_mf_engine_scores(ctx->mf, apc, scores_out);
+}
+
+int dca_spd_inverse(dca_ctx* ctx, const double* A, int n, double* Ainv_out)
+{
+    CHECK_CTX(ctx);
+    if (!A || !Ainv_out || n <= 0) return DCA_ERR_ARG;
+    const int np = (int)round_up((size_t)n, 64);
+    std::vector<double> padded((size_t)np * np, 0.0);
+    for (int r = 0; r < n; ++r) memcpy(padded.data() + (size_t)r * np, A + (size_t)r * n, (size_t)n * sizeof(double));
+    for (int r = n; r < np; ++r) padded[(size_t)r * np + r] = 1.0;
+    double *dA = nullptr, *dWork = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dA), padded.size() * sizeof(double)));
+    if (hipMalloc(reinterpret_cast<void**>(&dWork), 2 * padded.size() * sizeof(double)) != hipSuccess) { hipFree(dA); dca_set_error("out of device memory"); return DCA_ERR_NOMEM; }
+    int info = 0;
+    int rc = DCA_OK;
+    if (hipMemcpy(dA, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = DCA_ERR_HIP;
+    if (rc == DCA_OK) rc = dca_spd_inverse_device(ctx, dA, np, dWork, &info);
+    if (rc == DCA_OK && info != 0) { dca_set_error("matrix is not positive definite (pivot %d)", info); rc = DCA_ERR_NOT_SPD; }
+    if (rc == DCA_OK) {
+        if (hipMemcpy(padded.data(), dA, padded.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = DCA_ERR_HIP;
+        else for (int r = 0; r < n; ++r) memcpy(Ainv_out + (size_t)r * n, padded.data() + (size_t)r * np, (size_t)n * sizeof(double));
+    }
+    hipFree(dA); hipFree(dWork);
+    return rc;
+}
+
+// ------------------------------------------------------------------ timing
+int dca_set_profiling(dca_ctx* ctx, int on) { if (!ctx) return DCA_ERR_ARG; ctx->profiling = on != 0; return DCA_OK; }
+int dca_reset_kernel_times(dca_ctx* ctx)
+{
+    CHECK_CTX(ctx);
+    hipStreamSynchronize(ctx->stream);
+    dca_flush_clocks(ctx);
+    ctx->clocks.clear();
+    return DCA_OK;
+}
+int dca_get_kernel_time(dca_ctx* ctx, const char* tag, double* ms_out, int* launches_out)
+{
+    CHECK_CTX(ctx);
+    hipStreamSynchronize(ctx->stream);
+    dca_flush_clocks(ctx);
+    auto it = ctx->clocks.find(tag ? tag : "");
+    if (ms_out) *ms_out = it == ctx->clocks.end() ? 0.0 : it->second.ms;
+    if (launches_out) *launches_out = it == ctx->clocks.end() ? 0 : it->second.launches;
+    return DCA_OK;
+}
+
+// ------------------------------------------------------------------ drop-in FFI
+// plmdcaBackend.cpp:151-201: read + dedup, weights, initial x, L-BFGS; returns the
+// parameter vector.  malloc/free are paired here (the reference mixes malloc/delete[]).
+float* plmdcaBackend(unsigned short biomolecule, unsigned short num_site_states, const char* msa_file,
+                     unsigned int seqs_len, float seqid, float lambda_h, float lambda_J,
+                     unsigned int max_iteration, unsigned int num_threads, bool verbose)
+{
+    (void)num_threads;
+    const int L = (int)seqs_len, q = (int)num_site_states;
+    int cap = dca_count_msa_lines(msa_file);
+    if (cap <= 0) { if (cap == 0) dca_set_error("no sequences in %s", msa_file); return nullptr; }
+    std::vector<uint8_t> X((size_t)cap * L);
+    int raw = 0;
+    const int N = dca_read_msa_impl(msa_file, biomolecule, L, X.data(), cap, &raw);
+    if (N <= 0) return nullptr;
+    dca_ctx* ctx = nullptr;
+    float* result = nullptr;
+    dca_plm_stats st;
+    memset(&st, 0, sizeof(st));
+    const size_t P = dca_plm_num_params(L, q);
+    if (dca_create(&ctx, 0, DCA_F32) != DCA_OK) return nullptr;
+    if (dca_set_msa(ctx, X.data(), N, L, q) == DCA_OK &&
+        dca_compute_weights(ctx, (double)seqid, DCA_F32) == DCA_OK &&
+        dca_plm_configure(ctx, (double)lambda_h, (double)lambda_J, DCA_CARRY_CHUNKED, 0, 0, 0, 1) == DCA_OK &&
+        dca_plm_init_x(ctx) == DCA_OK &&
+        dca_plm_lbfgs_begin(ctx, (int)max_iteration, verbose ? 1 : 0) == DCA_OK &&
+        dca_plm_lbfgs_iterate(ctx, max_iteration ? (int)max_iteration : 1 << 30, &st) == DCA_OK) {
+        result = static_cast<float*>(malloc(P * sizeof(float)));
+        if (!result) dca_set_error("out of host memory");
+        else if (dca_plm_get_x(ctx, result, DCA_F32) != DCA_OK) { free(result); result = nullptr; }
+    }
+    if (verbose && result) {
+        if (st.status == -1001) fprintf(stderr, "L-BFGS optimization completed\n");
+        else { fprintf(stderr, "L-BFGS optimization terminated with status code = %d\n", st.status); fprintf(stderr, "fx = %f\n", st.fx); }
+    }
+    dca_destroy(ctx);
+    return result;
+}
+
+void freeFieldsAndCouplings(void* h_and_J) { free(h_and_J); }
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+// Inverse of a symmetric positive definite float64 matrix on MI355X, used for
+// couplings = -inv(C)  (reference: compute_couplings, pydca/meanfield_dca/msa_numerics.py:321-342,
+// which goes through LAPACK getrf/getri; C is SPD for pseudocount > 0, so the Cholesky route
+// inv(A) = L^-T L^-1 is used: ~n^3 flop instead of 2 n^3).
+//
+// Everything that is a GEMM runs on the f64 matrix cores (v_mfma_f64_16x16x4_f64):
+//   recursive block step on A = [[A11, .], [A21, A22]]  (sizes multiples of 64)
+//     (X11)        <- cholinv(A11)                 X = L^-1, stored lower + mirrored upper
+//     L21          <- A21 * X11^T                  (TRSM as a GEMM with the inverse)
+//     A22          <- A22 - L21 * L21^T            (SYRK, lower tiles only)
+//     (X22)        <- cholinv(A22)
+//     T^T          <- X11^T * L21^T
+//     X21          <- -X22 * T                     (written to (2,1) and mirrored to (1,2))
+//   finally inv(A) = X^T X as one triangular-aware GEMM.
+// All products are of the form C[i][j] = sum_k A[i][k] * B[j][k] ("NT", both operands
+// K-contiguous), which is why X is kept mirrored: X^T rows are then plain rows.
+// The 64x64 diagonal leaves (Cholesky + triangular inverse) run in one workgroup in LDS.
+#include "dca_internal.h"
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+enum { MASK_NONE = 0, MASK_LOWER = 1 /* k <= row */, MASK_UPPER = 2 /* k >= row */ };
+
+constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int LDS_STRIDE = BK + 1;   // doubles; odd stride spreads the 16 fragment rows over banks
+
+struct GemmArgs {
+    const double* A; int lda; int maskA;
+    const double* B; int ldb; int maskB;
+    double* C; int ldc;
+    double* Cm; int ldcm;          // optional mirror: Cm[j][i] = C[i][j]
+    int M, N, K;
+    double alpha, beta;
+    int lowerOnly;                 // square output: only tiles with tj <= ti; strict mirror rule on the diagonal
+};
+
+__global__ __launch_bounds__(256)
+void gemm_nt_f64_kernel(GemmArgs g)
+{
+    __shared__ double As[2][BM * LDS_STRIDE];
+    __shared__ double Bs[2][BN * LDS_STRIDE];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (g.lowerOnly && tj > ti) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // K range implied by the triangular operands
+    int kLo = 0, kHi = g.K;
+    if (g.maskA == MASK_LOWER) kHi = min(kHi, (ti + 1) * BM);
+    if (g.maskA == MASK_UPPER) kLo = max(kLo, ti * BM);
+    if (g.maskB == MASK_LOWER) kHi = min(kHi, (tj + 1) * BN);
+    if (g.maskB == MASK_UPPER) kLo = max(kLo, tj * BN);
+    kLo = kLo / BK * BK;
+
+    double4_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    // staging role: thread -> (row r, 4 consecutive k)
+    const int sr = tid >> 2, sk = (tid & 3) * 4;
+    const double* Arow = g.A + (size_t)(ti * BM + sr) * g.lda;
+    const double* Brow = g.B + (size_t)(tj * BN + sr) * g.ldb;
+    const int aRowLocal = ti * BM + sr, bRowLocal = tj * BN + sr;
+
+    double ra[4], rb[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + sk + u;
+            double va = Arow[k], vb = Brow[k];
+            if (g.maskA == MASK_LOWER && k > aRowLocal) va = 0.0;
+            if (g.maskA == MASK_UPPER && k < aRowLocal) va = 0.0;
+            if (g.maskB == MASK_LOWER && k > bRowLocal) vb = 0.0;
+            if (g.maskB == MASK_UPPER && k < bRowLocal) vb = 0.0;
+            ra[u] = va; rb[u] = vb;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            As[buf][sr * LDS_STRIDE + sk + u] = ra[u];
+            Bs[buf][sr * LDS_STRIDE + sk + u] = rb[u];
+        }
+    };
+
+    const int nk = (kHi - kLo + BK - 1) / BK;
+    if (nk > 0) {
+        load_tile(kLo);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) load_tile(kLo + (t + 1) * BK);
+        const double* as = As[buf];
+        const double* bs = Bs[buf];
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int kcol = kk * 4 + (lane >> 4);
+            const double a0 = as[(wm * 32 + (lane & 15)) * LDS_STRIDE + kcol];
+            const double a1 = as[(wm * 32 + 16 + (lane & 15)) * LDS_STRIDE + kcol];
+            const double b0 = bs[(wn * 32 + (lane & 15)) * LDS_STRIDE + kcol];
+            const double b1 = bs[(wn * 32 + 16 + (lane & 15)) * LDS_STRIDE + kcol];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (t + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue.  f64 16x16x4 accumulator layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * BM + wm * 32 + m * 16 + (lane >> 4) + 4 * r;
+                const int j = tj * BN + wn * 32 + n * 16 + (lane & 15);
+                if (g.lowerOnly && j > i) continue;
+                double v = g.alpha * acc[m][n][r];
+                double* cp = g.C + (size_t)i * g.ldc + j;
+                if (g.beta != 0.0) v += g.beta * (*cp);
+                *cp = v;
+                if (g.Cm && !(g.lowerOnly && i == j)) g.Cm[(size_t)j * g.ldcm + i] = v;
+            }
+}
+
+// 64x64 leaf: A (lower triangle valid) -> X = inv(chol(A)), written lower + mirrored upper.
+// One LDS array: L lives in the lower triangle (diagonal included), X[i][j] (i >= j) is kept
+// in the free upper part at [j][i+1] (the row stride has one spare column).
+__global__ __launch_bounds__(256)
+void cholinv_leaf_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info)
+{
+    constexpr int n = 64, S = 65;
+    __shared__ double Ls[n * S];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e % n;
+        if (j <= i) Ls[i * S + j] = M[(size_t)i * ld + j];
+    }
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) {
+            const double d = Ls[k * S + k];
+            if (!(d > 0.0)) atomicCAS(info, 0, pivotBase + k + 1);
+            Ls[k * S + k] = sqrt(d);
+        }
+        __syncthreads();
+        const double dk = Ls[k * S + k];
+        if (tid > k && tid < n) Ls[tid * S + k] /= dk;
+        __syncthreads();
+        const int m = n - k - 1;
+        for (int e = tid; e < m * m; e += 256) {
+            const int i = k + 1 + e / m, j = k + 1 + e % m;
+            if (j <= i) Ls[i * S + j] -= Ls[i * S + k] * Ls[j * S + k];
+        }
+        __syncthreads();
+    }
+    // X = L^-1 by forward substitution, one column per thread (thread j owns row j's upper part)
+    if (tid < n) {
+        const int j = tid;
+        Ls[j * S + j + 1] = 1.0 / Ls[j * S + j];
+        for (int i = j + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int k = j; k < i; ++k) s += Ls[i * S + k] * Ls[j * S + k + 1];
+            Ls[j * S + i + 1] = -s / Ls[i * S + i];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e % n;
+        M[(size_t)i * ld + j] = (j <= i) ? Ls[j * S + i + 1] : Ls[i * S + j + 1];
+    }
+}
+
+struct Arena {
+    double* base; size_t cap, top = 0;
+    double* alloc(size_t n) { if (top + n > cap) return nullptr; double* p = base + top; top += n; return p; }
+};
+
+int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
+{
+    dim3 grid(g.N / BN, g.M / BM);
+    hipLaunchKernelGGL(gemm_nt_f64_kernel, grid, dim3(256), 0, ctx->stream, g);
+    return DCA_OK;
+}
+
+int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws, int* dInfo)
+{
+    if (n == 64) {
+        hipLaunchKernelGGL(cholinv_leaf_kernel, dim3(1), dim3(256), 0, ctx->stream, M, ld, pivotBase, dInfo);
+        return DCA_OK;
+    }
+    const int n1 = (n / 64 / 2) * 64, n2 = n - n1;
+    double* M11 = M;
+    double* M12 = M + n1;
+    double* M21 = M + (size_t)n1 * ld;
+    double* M22 = M + (size_t)n1 * ld + n1;
+    DCA_TRY(cholinv_rec(ctx, M11, ld, n1, pivotBase, ws, dInfo));
+    const size_t mark = ws.top;
+    double* L21 = ws.alloc((size_t)n2 * n1);
+    double* Tt = ws.alloc((size_t)n1 * n2);
+    if (!L21 || !Tt) { dca_set_error("cholinv workspace exhausted"); return DCA_ERR_NOMEM; }
+    // L21 = A21 * X11^T : C[i][j] = sum_k A21[i][k] * X11[j][k],  X11 lower (k <= j)
+    DCA_TRY(launch_gemm(ctx, GemmArgs{M21, ld, MASK_NONE, M11, ld, MASK_LOWER, L21, n1, nullptr, 0, n2, n1, n1, 1.0, 0.0, 0}));
+    // A22 -= L21 * L21^T (lower tiles)
+    DCA_TRY(launch_gemm(ctx, GemmArgs{L21, n1, MASK_NONE, L21, n1, MASK_NONE, M22, ld, nullptr, 0, n2, n2, n1, -1.0, 1.0, 1}));
+    DCA_TRY(cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo));
+    // T^T[j][i] = sum_k X11^T[j][k] * L21[i][k];  X11^T rows are the mirrored upper part of M11 (k >= j)
+    DCA_TRY(launch_gemm(ctx, GemmArgs{M11, ld, MASK_UPPER, L21, n1, MASK_NONE, Tt, n2, nullptr, 0, n1, n2, n1, 1.0, 0.0, 0}));
+    // X21[i][j] = -sum_k X22[i][k] * T^T[j][k];  X22 lower (k <= i); mirrored into the (1,2) block
+    DCA_TRY(launch_gemm(ctx, GemmArgs{M22, ld, MASK_LOWER, Tt, n2, MASK_NONE, M21, ld, M12, ld, n2, n1, n2, -1.0, 0.0, 0}));
+    ws.top = mark;
+    return DCA_OK;
+}
+
+}  // namespace
+
+int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* info_out)
+{
+    if (n % 64 != 0 || n <= 0) { dca_set_error("dca_spd_inverse_device: n must be a positive multiple of 64"); return DCA_ERR_ARG; }
+    ScopedKernelClock kc(ctx, "mf_inverse");
+    int* dInfo = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dInfo), sizeof(int)));
+    HIP_TRY(hipMemsetAsync(dInfo, 0, sizeof(int), ctx->stream));
+    Arena ws{dWork, (size_t)n * n};
+    int rc = cholinv_rec(ctx, dA, n, n, 0, ws, dInfo);
+    if (rc == DCA_OK) {
+        double* out = dWork + (size_t)n * n;
+        // inv(A)[i][j] = sum_{k >= max(i,j)} X[k][i] X[k][j] = sum_k Xt[i][k] Xt[j][k]
+        rc = launch_gemm(ctx, GemmArgs{dA, n, MASK_UPPER, dA, n, MASK_UPPER, out, n, out, n, n, n, n, 1.0, 0.0, 1});
+        if (rc == DCA_OK) {
+            hipError_t e = hipMemcpyAsync(dA, out, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) { dca_set_error("copy inverse: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
+        }
+    }
+    int info = 0;
+    hipError_t e = hipMemcpyAsync(&info, dInfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dInfo);
+    if (e != hipSuccess) { dca_set_error("cholinv: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
+    if (info_out) *info_out = info;
+    return rc;
+}

@@ -1,0 +1,145 @@
+// Internal declarations shared by the translation units of libdca_hip.so.
+// gfx950 (MI355X / CDNA4) only: wave = 64 lanes, 160 KiB LDS per CU, 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dca_hip.h"
+
+void dca_set_error(const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            dca_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DCA_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define DCA_TRY(expr)                  \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != DCA_OK) return _rc; \
+    } while (0)
+
+static inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// number of XCDs on MI355X; workgroup b is observed to run on XCD b % 8
+// (used for L2 locality only, never for correctness)
+constexpr int kNumXcd = 8;
+
+struct KernelClock {
+    double ms = 0.0;
+    int launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct PlmEngineBase;
+struct MfEngine;
+
+struct dca_ctx {
+    int device = 0;
+    int precision = DCA_F32;
+    hipStream_t stream = nullptr;
+
+    // alignment (device): row-major bytes, row stride Ls (multiple of 128), zero padded
+    int N = 0, L = 0, q = 0, Ls = 0;
+    uint8_t* dX = nullptr;
+    std::vector<uint8_t> hX;  // host copy, N x L
+
+    // weights
+    bool have_weights = false;
+    bool have_counts = false;
+    uint32_t* dCounts = nullptr;
+    double* dWd = nullptr;     // N doubles
+    double meff = 0.0;
+
+    // scratch scalars: device slots + pinned host mirror
+    double* dScal = nullptr;
+    double* hScal = nullptr;
+
+    PlmEngineBase* plm = nullptr;
+    MfEngine* mf = nullptr;
+
+    bool profiling = false;
+    std::map<std::string, KernelClock> clocks;
+};
+
+// RAII-less helpers for bracketing a kernel with events on ctx->stream
+struct ScopedKernelClock {
+    dca_ctx* ctx;
+    KernelClock* kc = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedKernelClock(dca_ctx* c, const char* tag) : ctx(c) {
+        if (!c->profiling) return;
+        kc = &c->clocks[tag];
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { kc = nullptr; return; }
+        hipEventRecord(a, c->stream);
+    }
+    ~ScopedKernelClock() {
+        if (!kc) return;
+        hipEventRecord(b, ctx->stream);
+        kc->pending.emplace_back(a, b);
+        kc->launches += 1;
+    }
+};
+void dca_flush_clocks(dca_ctx* ctx);
+
+// ---- weights.hip
+int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision);
+
+// ---- reductions.hip : deterministic device reductions
+// out[slot] = sum(partials[0..n)) ; single block, fixed tree
+int dca_reduce_partials(dca_ctx* ctx, const double* dPartials, int n, double* dOut);
+int dca_sum_doubles(dca_ctx* ctx, const double* dVals, int n, double* dOut);  // two-stage
+
+// ---- plm engine
+struct PlmEngineBase {
+    virtual ~PlmEngineBase() {}
+    virtual int configure(double lambda_h, double lambda_J, int carry_mode, int chunk, int warmup,
+                          int halo, int add_reg) = 0;
+    virtual int init_x() = 0;
+    virtual int set_x(const void* x, int dtype) = 0;
+    virtual int get_x(void* x, int dtype) = 0;
+    virtual int get_g(void* g, int dtype) = 0;
+    virtual int gradient(double* fx_out) = 0;
+    virtual int lbfgs_begin(int max_iterations, int verbose) = 0;
+    virtual int lbfgs_iterate(int iterations, dca_plm_stats* st) = 0;
+    virtual int scores(int apc, double* out) = 0;
+    dca_reduce_hook hook = nullptr;
+    void* hook_user = nullptr;
+};
+PlmEngineBase* dca_make_plm_engine(dca_ctx* ctx);
+
+// ---- scoring.hip
+// FN of (q-1)x(q-1) blocks.  src_kind 0: packed plm vector of element type `dtype`
+// (DCA_F32/DCA_F64); 1: dense n x n double couplings with leading dimension ld.
+int dca_fn_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L, int q, int ld,
+                  int apc, double* dScoresOut /* device, pairs */);
+
+// ---- mf engine
+struct MfEngine;
+MfEngine* dca_make_mf_engine(dca_ctx* ctx);
+void dca_free_mf_engine(MfEngine*);
+int dca_mf_engine_site_freqs(MfEngine*, double* fi_out);
+int dca_mf_engine_pair_freqs(MfEngine*, double* fij_out);
+int dca_mf_engine_corr(MfEngine*, double theta, double* corr_out);
+int dca_mf_engine_couplings(MfEngine*, double* out);
+int dca_mf_engine_scores(MfEngine*, int apc, double* out);
+
+// ---- cholinv.hip : in-place inverse of an SPD matrix on the device (f64 MFMA)
+// dA: n x n row-major (ld = n), n multiple of 64.  On return dA holds inv(A) (full, symmetric).
+// dWork: >= 2*n*n doubles.  info_out: 0 ok, >0 first non-positive pivot (1-based).
+int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* info_out);
+
+// ---- host_io.cpp
+int dca_read_msa_impl(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count);

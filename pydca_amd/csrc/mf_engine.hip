@@ -1,0 +1,302 @@
+// mfDCA on MI355X (all float64): weighted single/pair site counts, pseudocount
+// regularisation, correlation matrix, couplings = -inv(C), FN/APC scores.
+// Reference: pydca/meanfield_dca/msa_numerics.py:53-342 and meanfield_dca.py:902-988.
+//
+// Pair counts: Craw[(i,a)][(j,b)] = sum_n w_n [x_ni = a][x_nj = b] is a histogram, not a
+// dense GEMM (the one-hot matrix has one non-zero per q entries), so it is built as a
+// deterministic gather: for every site i the sequences are bucketed by their state a
+// (stable counting sort, once per alignment); a workgroup owns one (i,a) row of Craw,
+// walks its bucket in ascending n and lets thread j add w_n into its private LDS
+// histogram slot [x_nj][j].  N*L^2 LDS read-modify-writes in total, no atomics, and
+// Craw comes out exactly symmetric because both (i,a,j,b) and (j,b,i,a) add the same
+// weights in the same order.
+#include "dca_internal.h"
+
+namespace {
+
+__host__ __device__ __forceinline__ size_t pair_index(int L, int i, int j)
+{
+    return (size_t)L * (L - 1) / 2 - (size_t)(L - i) * (L - i - 1) / 2 + (size_t)(j - i - 1);
+}
+
+// thread = site: stable counting sort of the sequences by their state at that site
+__global__ void mf_site_sort_kernel(const uint8_t* __restrict__ X, uint32_t* __restrict__ perm, int* __restrict__ off,
+                                    int N, int L, int Ls, int q)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    int cnt[32], pos[32];
+    for (int b = 0; b < q; ++b) cnt[b] = 0;
+    for (int n = 0; n < N; ++n) cnt[X[(size_t)n * Ls + i]]++;
+    int run = 0;
+    for (int b = 0; b < q; ++b) { off[i * (q + 1) + b] = run; pos[b] = run; run += cnt[b]; }
+    off[i * (q + 1) + q] = run;
+    uint32_t* p = perm + (size_t)i * N;
+    for (int n = 0; n < N; ++n) { const int b = X[(size_t)n * Ls + i]; p[pos[b]++] = (uint32_t)n; }
+}
+
+constexpr int kCountThreads = 256;
+
+// one workgroup per (site i, state a) row of Craw
+__global__ __launch_bounds__(kCountThreads)
+void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ w, const uint32_t* __restrict__ perm,
+                      const int* __restrict__ off, double* __restrict__ Craw, int N, int L, int Ls, int q, int ldc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
+    double* hist = reinterpret_cast<double*>(dca_smem);       // [q][kCountThreads]
+    const int i = blockIdx.x / q, a = blockIdx.x % q;
+    const int k0 = off[i * (q + 1) + a], k1 = off[i * (q + 1) + a + 1];
+    const uint32_t* p = perm + (size_t)i * N;
+    const int t = threadIdx.x;
+    for (int j0 = 0; j0 < L; j0 += kCountThreads) {
+        const int j = j0 + t;
+        for (int b = 0; b < q; ++b) hist[b * kCountThreads + t] = 0.0;
+        if (j < L) {
+            for (int k = k0; k < k1; ++k) {
+                const uint32_t n = p[k];
+                const int b = X[(size_t)n * Ls + j];
+                hist[b * kCountThreads + t] += w[n];
+            }
+            double* dst = Craw + (size_t)(i * q + a) * ldc + (size_t)j * q;
+            for (int b = 0; b < q; ++b) dst[b] = hist[b * kCountThreads + t];
+        }
+    }
+}
+
+// f_i(a) = Craw[(i,a)][(i,a)] / Meff   (compute_single_site_freqs, msa_numerics.py:53-89)
+__global__ void mf_fi_kernel(const double* __restrict__ Craw, double* __restrict__ fi, int Lq, int ldc, double meff)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < Lq) fi[c] = Craw[(size_t)c * ldc + c] / meff;
+}
+
+// raw pair frequencies, non-gap states, pair order (msa_numerics.py:182-229)
+__global__ void mf_fij_export_kernel(const double* __restrict__ Craw, double* __restrict__ fij, int L, int q, int ldc, double meff)
+{
+    const int qm = q - 1;
+    const int i = blockIdx.y, j = blockIdx.x;
+    if (j <= i) return;
+    const size_t p = pair_index(L, i, j);
+    for (int e = threadIdx.x; e < qm * qm; e += blockDim.x) {
+        const int a = e / qm, b = e % qm;
+        fij[p * qm * qm + e] = Craw[(size_t)(i * q + a) * ldc + (size_t)j * q + b] / meff;
+    }
+}
+
+// correlation matrix from raw counts: regularisation (msa_numerics.py:92-125, :231-267)
+// fused with construct_corr_mat (:270-318).  Entries with i > j are mirrored from (j,i).
+// Rows/cols >= n (padding up to np) form an identity block.
+__global__ void mf_corr_kernel(const double* __restrict__ Craw, double* __restrict__ C, int L, int q, int ldc, int np,
+                               double meff, double theta)
+{
+    const int qm = q - 1, n = L * qm;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (col >= np) return;
+    double v;
+    if (row >= n || col >= n) {
+        v = (row == col) ? 1.0 : 0.0;
+    } else {
+        int r = row, c = col;
+        if (r > c) { const int t = r; r = c; c = t; }
+        const int i = r / qm, a = r % qm, j = c / qm, b = c % qm;
+        const double thq = theta / (double)q;
+        const double fia = thq + (1.0 - theta) * (Craw[(size_t)(i * q + a) * ldc + i * q + a] / meff);
+        const double fjb = thq + (1.0 - theta) * (Craw[(size_t)(j * q + b) * ldc + j * q + b] / meff);
+        if (i == j) {
+            v = (a == b) ? fia * (1.0 - fia) : -1.0 * fia * fjb;
+        } else {
+            const double fij = Craw[(size_t)(i * q + a) * ldc + (size_t)j * q + b] / meff;
+            const double rfij = theta / (double)(q * q) + (1.0 - theta) * fij;
+            v = rfij - fia * fjb;
+        }
+    }
+    C[(size_t)row * np + col] = v;
+}
+
+// construct_corr_mat from caller-provided regularised frequencies (stage API)
+__global__ void mf_corr_from_freqs_kernel(const double* __restrict__ fi, const double* __restrict__ fij,
+                                          double* __restrict__ C, int L, int q)
+{
+    const int qm = q - 1, n = L * qm;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (col >= n) return;
+    int r = row, c = col;
+    if (r > c) { const int t = r; r = c; c = t; }
+    const int i = r / qm, a = r % qm, j = c / qm, b = c % qm;
+    double v;
+    if (i == j) {
+        const double fia = fi[i * q + a], fib = fi[i * q + b];
+        v = (a == b) ? fia * (1.0 - fia) : -1.0 * fia * fib;
+    } else {
+        v = fij[pair_index(L, i, j) * qm * qm + a * qm + b] - fi[i * q + a] * fi[j * q + b];
+    }
+    C[(size_t)row * n + col] = v;
+}
+
+__global__ void negate_kernel(double* __restrict__ A, size_t n)
+{
+    for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) A[k] = -1.0 * A[k];
+}
+
+}  // namespace
+
+struct MfEngine {
+    dca_ctx* ctx;
+    int N, L, q, Ls, Lq, n, np;
+    uint32_t* dPerm = nullptr;
+    int* dOff = nullptr;
+    double *dCraw = nullptr, *dFi = nullptr, *dC = nullptr, *dJ = nullptr, *dWork = nullptr;
+    bool have_counts = false, have_corr = false, have_J = false;
+    ~MfEngine() { hipFree(dPerm); hipFree(dOff); hipFree(dCraw); hipFree(dFi); hipFree(dC); hipFree(dJ); hipFree(dWork); }
+};
+
+MfEngine* dca_make_mf_engine(dca_ctx* ctx)
+{
+    MfEngine* m = new MfEngine();
+    m->ctx = ctx; m->N = ctx->N; m->L = ctx->L; m->q = ctx->q; m->Ls = ctx->Ls;
+    m->Lq = m->L * m->q;
+    m->n = m->L * (m->q - 1);
+    m->np = (int)round_up((size_t)m->n, 64);
+    return m;
+}
+void dca_free_mf_engine(MfEngine* m) { delete m; }
+
+static int mf_counts(MfEngine* m)
+{
+    if (m->have_counts) return DCA_OK;
+    dca_ctx* ctx = m->ctx;
+    if (m->q > 32) { dca_set_error("q too large"); return DCA_ERR_ARG; }
+    if (!m->dPerm) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dPerm), (size_t)m->L * m->N * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dOff), (size_t)m->L * (m->q + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dCraw), (size_t)m->Lq * m->Lq * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dFi), (size_t)m->Lq * sizeof(double)));
+    }
+    hipLaunchKernelGGL(mf_site_sort_kernel, dim3(ceil_div(m->L, 64)), dim3(64), 0, ctx->stream, ctx->dX, m->dPerm, m->dOff,
+                       m->N, m->L, m->Ls, m->q);
+    {
+        ScopedKernelClock kc(ctx, "mf_counts");
+        const size_t lds = (size_t)m->q * kCountThreads * sizeof(double);
+        hipLaunchKernelGGL(mf_counts_kernel, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, ctx->dX, ctx->dWd,
+                           m->dPerm, m->dOff, m->dCraw, m->N, m->L, m->Ls, m->q, m->Lq);
+    }
+    hipLaunchKernelGGL(mf_fi_kernel, dim3(ceil_div(m->Lq, 256)), dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->Lq, m->Lq, ctx->meff);
+    HIP_TRY(hipGetLastError());
+    m->have_counts = true;
+    return DCA_OK;
+}
+
+int dca_mf_engine_site_freqs(MfEngine* m, double* fi_out)
+{
+    DCA_TRY(mf_counts(m));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    HIP_TRY(hipMemcpy(fi_out, m->dFi, (size_t)m->Lq * sizeof(double), hipMemcpyDeviceToHost));
+    return DCA_OK;
+}
+
+int dca_mf_engine_pair_freqs(MfEngine* m, double* fij_out)
+{
+    DCA_TRY(mf_counts(m));
+    const int qm = m->q - 1;
+    const size_t total = (size_t)m->L * (m->L - 1) / 2 * qm * qm;
+    double* dOut = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), total * sizeof(double)));
+    hipLaunchKernelGGL(mf_fij_export_kernel, dim3(m->L, m->L), dim3(64), 0, m->ctx->stream, m->dCraw, dOut, m->L, m->q, m->Lq, m->ctx->meff);
+    hipError_t e = hipStreamSynchronize(m->ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(fij_out, dOut, total * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dOut);
+    if (e != hipSuccess) { dca_set_error("pair freqs: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
+    return DCA_OK;
+}
+
+static int copy_out_square(MfEngine* m, const double* dSrc, double* out)
+{
+    // device matrices are np x np; hand back the leading n x n
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    HIP_TRY(hipMemcpy2D(out, (size_t)m->n * sizeof(double), dSrc, (size_t)m->np * sizeof(double),
+                        (size_t)m->n * sizeof(double), (size_t)m->n, hipMemcpyDeviceToHost));
+    return DCA_OK;
+}
+
+int dca_mf_engine_corr(MfEngine* m, double theta, double* corr_out)
+{
+    DCA_TRY(mf_counts(m));
+    dca_ctx* ctx = m->ctx;
+    if (!m->dC) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dC), (size_t)m->np * m->np * sizeof(double)));
+    dim3 grid(ceil_div(m->np, 256), m->np);
+    hipLaunchKernelGGL(mf_corr_kernel, grid, dim3(256), 0, ctx->stream, m->dCraw, m->dC, m->L, m->q, m->Lq, m->np, ctx->meff, theta);
+    HIP_TRY(hipGetLastError());
+    m->have_corr = true;
+    m->have_J = false;
+    if (corr_out) return copy_out_square(m, m->dC, corr_out);
+    return DCA_OK;
+}
+
+int dca_mf_engine_couplings(MfEngine* m, double* out)
+{
+    if (!m->have_corr) { dca_set_error("dca_mf_corr_mat first"); return DCA_ERR_STATE; }
+    dca_ctx* ctx = m->ctx;
+    const size_t nn = (size_t)m->np * m->np;
+    if (!m->dJ) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dJ), nn * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dWork), 2 * nn * sizeof(double)));
+    }
+    HIP_TRY(hipMemcpyAsync(m->dJ, m->dC, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    int info = 0;
+    DCA_TRY(dca_spd_inverse_device(ctx, m->dJ, m->np, m->dWork, &info));
+    if (info != 0) {
+        dca_set_error("Singular matrix: the correlation matrix is not positive definite (pivot %d)", info);
+        return DCA_ERR_NOT_SPD;
+    }
+    hipLaunchKernelGGL(negate_kernel, dim3(1024), dim3(256), 0, ctx->stream, m->dJ, nn);
+    HIP_TRY(hipGetLastError());
+    m->have_J = true;
+    if (out) return copy_out_square(m, m->dJ, out);
+    return DCA_OK;
+}
+
+int dca_mf_engine_scores(MfEngine* m, int apc, double* out)
+{
+    if (!m->have_J) { dca_set_error("dca_mf_couplings first"); return DCA_ERR_STATE; }
+    const size_t npairs = (size_t)m->L * (m->L - 1) / 2;
+    double* dOut = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
+    int rc = dca_fn_scores(m->ctx, m->dJ, 1, DCA_F64, m->L, m->q, m->np, apc, dOut);
+    if (rc == DCA_OK) {
+        hipError_t e = hipStreamSynchronize(m->ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, dOut, npairs * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { dca_set_error("scores: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
+    }
+    hipFree(dOut);
+    return rc;
+}
+
+// stage API: construct_corr_mat on caller-provided regularised frequencies
+extern "C" int dca_mf_corr_from_freqs(dca_ctx* ctx, const double* reg_fi, const double* reg_fij, int L, int q, double* corr_out)
+{
+    if (!ctx || !reg_fi || !reg_fij || !corr_out || L < 2 || q < 2) { dca_set_error("dca_mf_corr_from_freqs: bad arguments"); return DCA_ERR_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int qm = q - 1, n = L * qm;
+    const size_t nfij = (size_t)L * (L - 1) / 2 * qm * qm;
+    double *dFi = nullptr, *dFij = nullptr, *dC = nullptr;
+    int rc = DCA_OK;
+    if (hipMalloc(reinterpret_cast<void**>(&dFi), (size_t)L * q * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&dFij), nfij * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&dC), (size_t)n * n * sizeof(double)) != hipSuccess) {
+        dca_set_error("out of device memory");
+        rc = DCA_ERR_NOMEM;
+    }
+    if (rc == DCA_OK) {
+        hipMemcpy(dFi, reg_fi, (size_t)L * q * sizeof(double), hipMemcpyHostToDevice);
+        hipMemcpy(dFij, reg_fij, nfij * sizeof(double), hipMemcpyHostToDevice);
+        dim3 grid(ceil_div(n, 256), n);
+        hipLaunchKernelGGL(mf_corr_from_freqs_kernel, grid, dim3(256), 0, ctx->stream, dFi, dFij, dC, L, q);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(corr_out, dC, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { dca_set_error("corr_from_freqs: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
+    }
+    hipFree(dFi); hipFree(dFij); hipFree(dC);
+    return rc;
+}

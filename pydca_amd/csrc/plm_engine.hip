@@ -1,0 +1,1116 @@
+// plmDCA on MI355X: objective + "gradient" of the reference (PlmDCA::gradient,
+// pydca/plmdca/plmdca_numerics.cpp:436-607) and the L-BFGS driver the backend runs
+// (pydca/plmdca/plmdcaBackend.cpp:47-146, lbfgs/lib/lbfgs.cpp:248-644, :815-1004,
+// :1128-1295), re-designed for gfx950.
+//
+// One evaluation =
+//   expand : packed x -> symmetric table  W[(j,b)][(i,a)]              (HBM-bound, P floats in)
+//   logits : S[n][(i,a)] = sum_j W[(j,x_nj)][(i,a)]                     (LDS gather, lanes = sequences)
+//   softmax: per site, scan over n with the reference's carried-over probabilities,
+//            R[n][(i,a)] = w_n (p_ni(a) - delta(a,x_ni)),  fx -= w_n log p_ni(x_ni)   (lanes = sites)
+//   scatter: G[(j,b)][(i,a)] = sum_n [x_nj = b] R[n][(i,a)]             (LDS gather over per-chunk sorted lists)
+//   fold   : g = 2 lambda x + G + G^T in the packed layout, regulariser value
+// The two N*L^2*q stages (logits, scatter) are bound by LDS read bandwidth
+// (256 B/clk/CU); see DESIGN.md for the roofline model.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#include "dca_internal.h"
+
+namespace {
+
+template <typename T> struct V16;
+template <> struct V16<float> { using type = float4; static constexpr int n = 4; };
+template <> struct V16<double> { using type = double2; static constexpr int n = 2; };
+
+__device__ __forceinline__ void vadd(float* z, const float4& v) { z[0] += v.x; z[1] += v.y; z[2] += v.z; z[3] += v.w; }
+__device__ __forceinline__ void vadd(double* z, const double2& v) { z[0] += v.x; z[1] += v.y; }
+__device__ __forceinline__ float4 vpack(const float* z) { return make_float4(z[0], z[1], z[2], z[3]); }
+__device__ __forceinline__ double2 vpack(const double* z) { return make_double2(z[0], z[1]); }
+
+__device__ __forceinline__ float t_exp(float v) { return expf(v); }
+__device__ __forceinline__ double t_exp(double v) { return exp(v); }
+__device__ __forceinline__ float t_log(float v) { return logf(v); }
+__device__ __forceinline__ double t_log(double v) { return log(v); }
+
+__host__ __device__ __forceinline__ size_t pair_index(int L, int i, int j)
+{
+    return (size_t)L * (L - 1) / 2 - (size_t)(L - i) * (L - i - 1) / 2 + (size_t)(j - i - 1);
+}
+
+// block (i<j) from linear pair index (host side builds the table once)
+struct PairIJ { uint16_t i, j; };
+
+// ------------------------------------------------------------------ expand
+// W[(j,b)][(i,a)] = W[(i,a)][(j,b)] = J_ij(a,b); diagonal blocks and padding stay 0.
+// One workgroup per site pair; the q x q block goes through LDS so that both
+// writes are runs of q contiguous elements.
+template <typename T>
+__global__ void plm_expand_kernel(const T* __restrict__ x, T* __restrict__ W, const PairIJ* __restrict__ pairs,
+                                  int L, int q, int Cs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
+    T* tile = reinterpret_cast<T*>(dca_smem);
+    const int p = blockIdx.x;
+    const int i = pairs[p].i, j = pairs[p].j;
+    const int q2 = q * q;
+    const T* src = x + (size_t)L * q + (size_t)p * q2;
+    for (int t = threadIdx.x; t < q2; t += blockDim.x) tile[t] = src[t];   // tile[a*q+b]
+    __syncthreads();
+    for (int t = threadIdx.x; t < q2; t += blockDim.x) {
+        const int r = t / q, c = t % q;
+        // row (i,a=r), columns (j,b=c): contiguous in b
+        W[(size_t)(i * q + r) * Cs + j * q + c] = tile[r * q + c];
+        // row (j,b=r), columns (i,a=c): contiguous in a
+        W[(size_t)(j * q + r) * Cs + i * q + c] = tile[c * q + r];
+    }
+}
+
+// ------------------------------------------------------------------ logits
+// S[n][c] = sum_j W[j*q + x_nj][c] for a tile of CT columns.  Lanes = sequences, so
+// the data-dependent row index lives in the LDS *address* and the CT running sums
+// live in registers.  The (JT*Q) x CT slice of W for JT sites is staged in LDS and
+// shared by the workgroup's WAVES*64 sequences.  Row stride CT+16B keeps 16-byte
+// alignment and spreads rows over banks.
+template <typename T, int Q, int CT, int JT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64)
+void plm_logits_kernel(const T* __restrict__ W, const uint32_t* __restrict__ X4, T* __restrict__ S,
+                       int N, int Npad, int L, int Cs, int numColTiles, int numNBlocks)
+{
+    using V = typename V16<T>::type;
+    constexpr int VEC = V16<T>::n;
+    constexpr int VPR = CT / VEC;          // 16-byte vectors per tile row
+    constexpr int ROWS = JT * Q;
+    constexpr int STRIDE = CT + VEC;       // elements
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
+    T* tile = reinterpret_cast<T*>(dca_smem);
+
+    // XCD-aware decode: all sequence blocks of one column tile run on one XCD so that
+    // its slice of W is served by that XCD's L2.
+    const int id = blockIdx.x;
+    const int xcd = id % kNumXcd, k = id / kNumXcd;
+    const int ct = (k / numNBlocks) * kNumXcd + xcd;
+    const int nb = k % numNBlocks;
+    if (ct >= numColTiles) return;
+
+    const int tid = threadIdx.x;
+    const int n = nb * (WAVES * 64) + tid;
+    const int c0 = ct * CT;
+
+    T z[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) z[c] = 0;
+
+    const int numJT = (L + JT - 1) / JT;
+    for (int jt = 0; jt < numJT; ++jt) {
+        __syncthreads();
+        const T* src = W + (size_t)jt * ROWS * Cs + c0;
+        for (int v = tid; v < ROWS * VPR; v += WAVES * 64) {
+            const int r = v / VPR, cv = v % VPR;
+            *reinterpret_cast<V*>(tile + r * STRIDE + cv * VEC) =
+                *reinterpret_cast<const V*>(src + (size_t)r * Cs + cv * VEC);
+        }
+        uint32_t xw[JT / 4];
+#pragma unroll
+        for (int u = 0; u < JT / 4; ++u) xw[u] = X4[(size_t)(jt * (JT / 4) + u) * Npad + n];
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < JT; ++jj) {
+            const int b = (xw[jj >> 2] >> (8 * (jj & 3))) & 0xFF;
+            const T* row = tile + (jj * Q + b) * STRIDE;
+#pragma unroll
+            for (int cv = 0; cv < VPR; ++cv) vadd(z + cv * VEC, *reinterpret_cast<const V*>(row + cv * VEC));
+        }
+    }
+    if (n < N) {
+        T* dst = S + (size_t)n * Cs + c0;
+#pragma unroll
+        for (int cv = 0; cv < VPR; ++cv) *reinterpret_cast<V*>(dst + cv * VEC) = vpack(z + cv * VEC);
+    }
+}
+
+// ------------------------------------------------------------------ softmax scan
+// Lanes = sites, the q states of a site live in registers, so the softmax needs no
+// cross-lane traffic.  Each wave owns one chunk of consecutive sequences and walks it
+// serially carrying p_{n-1} (plmdca_numerics.cpp:492-530).  In chunked mode a chunk
+// starts `warm` sequences early from a zero carry: the carry enters the logits with
+// weight <= 1 and d softmax has 1-norm <= 1/2, so the start-up error shrinks by >= 2x
+// per step (2^-40 after the default 40) -- far below float/double rounding.
+// In: SR = S (logit sums).  Out: SR = R = w_n (p - delta), fxPart[wave] = -sum w_n log p(x_ni).
+template <typename T, int Q>
+__global__ __launch_bounds__(256)
+void plm_softmax_kernel(T* __restrict__ SR, const T* __restrict__ x, const uint8_t* __restrict__ X,
+                        const T* __restrict__ w, double* __restrict__ fxPart,
+                        int N, int L, int Ls, int Cs, int halo, int chunk, int warm, int carry, int numChunks)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int chunkId = blockIdx.y * 4 + wv;
+    const int i = blockIdx.x * 64 + lane;
+    double facc = 0.0;
+    if (chunkId < numChunks && i < L) {
+        const int s = halo + chunkId * chunk;
+        const int e = min(s + chunk, N);
+        const int ws = carry ? max(0, s - warm) : s;
+        T h[Q], p[Q], zc[Q], zn[Q];
+#pragma unroll
+        for (int a = 0; a < Q; ++a) { h[a] = x[(size_t)i * Q + a]; p[a] = 0; }
+        {
+            const T* row = SR + (size_t)ws * Cs + (size_t)i * Q;
+#pragma unroll
+            for (int a = 0; a < Q; ++a) zc[a] = row[a];
+        }
+        for (int n = ws; n < e; ++n) {
+            if (n + 1 < e) {   // prefetch next row while this one is reduced
+                const T* row = SR + (size_t)(n + 1) * Cs + (size_t)i * Q;
+#pragma unroll
+                for (int a = 0; a < Q; ++a) zn[a] = row[a];
+            }
+            T z[Q];
+#pragma unroll
+            for (int a = 0; a < Q; ++a) z[a] = zc[a] + h[a];
+            if (carry) {
+#pragma unroll
+                for (int a = 0; a < Q; ++a) z[a] += p[a];
+            }
+            T m = z[0];
+#pragma unroll
+            for (int a = 1; a < Q; ++a) m = z[a] > m ? z[a] : m;
+            T sum = 0;
+#pragma unroll
+            for (int a = 0; a < Q; ++a) { p[a] = t_exp(z[a] - m); sum += p[a]; }
+            const T inv = (T)1 / sum;
+#pragma unroll
+            for (int a = 0; a < Q; ++a) p[a] *= inv;
+            if (n >= s) {
+                const int xi = X[(size_t)n * Ls + i];
+                const T wn = w[n];
+                T px = p[0];
+#pragma unroll
+                for (int a = 1; a < Q; ++a) px = (a == xi) ? p[a] : px;
+                facc -= (double)(wn * t_log(px));
+                T* row = SR + (size_t)n * Cs + (size_t)i * Q;
+#pragma unroll
+                for (int a = 0; a < Q; ++a) {
+                    T r = wn * p[a];
+                    if (a == xi) r -= wn;
+                    row[a] = r;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < Q; ++a) zc[a] = zn[a];
+        }
+    }
+    // fixed-order wave reduction, one partial per wave
+    for (int off = 32; off > 0; off >>= 1) facc += __shfl_down(facc, off);
+    if (lane == 0) fxPart[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv] = facc;
+}
+
+// ------------------------------------------------------------------ per-chunk sorted lists
+// For every chunk of NC owned sequences and every site j: the chunk-local rows grouped
+// by state x_nj (counting sort, ascending n inside a group), stored as LDS byte offsets
+// (row * 512).  Groups are padded to a multiple of 4 with the offset of an all-zero row
+// so that the scatter kernel's inner loop needs no remainder handling.
+constexpr int kNC = 128;           // sequences per scatter chunk
+constexpr int kRowBytes = 512;     // bytes of one staged row (64 lanes x 8 B)
+
+__host__ __device__ constexpr int list_len(int q) { return (kNC + 3 * q + 3) / 4 * 4; }
+
+__global__ void plm_build_lists_kernel(const uint8_t* __restrict__ X, uint32_t* __restrict__ lists,
+                                       int* __restrict__ offs, int N, int L, int Ls, int q, int halo, int numChunks)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= numChunks * L) return;
+    const int c = t / L, j = t % L;
+    const int LP = list_len(q);
+    const int n0 = halo + c * kNC;
+    int cnt[32], pos[32];
+    for (int b = 0; b < q; ++b) cnt[b] = 0;
+    for (int r = 0; r < kNC; ++r) {
+        const int n = n0 + r;
+        if (n < N) cnt[X[(size_t)n * Ls + j]]++;
+    }
+    int* of = offs + (size_t)t * (q + 1);
+    int run = 0;
+    for (int b = 0; b < q; ++b) { of[b] = run; pos[b] = run; run += (cnt[b] + 3) / 4 * 4; }
+    of[q] = run;
+    uint32_t* lst = lists + (size_t)t * LP;
+    for (int k = 0; k < LP; ++k) lst[k] = kNC * kRowBytes;   // zero row
+    for (int r = 0; r < kNC; ++r) {
+        const int n = n0 + r;
+        if (n < N) { const int b = X[(size_t)n * Ls + j]; lst[pos[b]++] = r * kRowBytes; }
+    }
+}
+
+// ------------------------------------------------------------------ scatter (as a gather)
+// G[(j,b)][c] = sum_{n : x_nj = b} R[n][c].  Lanes = columns (8 bytes per lane), the
+// q running sums of a site sit in registers because the groups are visited in state
+// order with a compile-time unrolled loop over b; the rows of R come from an LDS tile
+// through wave-uniform offsets (scalar loads of the sorted lists).
+template <typename T, int Q, int JW, int WAVES>
+__global__ __launch_bounds__(WAVES * 64)
+void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ lists, const int* __restrict__ offs,
+                        T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int numColTiles, int numJG)
+{
+    constexpr int EPL = 8 / sizeof(T);     // elements per lane
+    constexpr int CW = 64 * EPL;           // columns per tile
+    constexpr int JG = WAVES * JW;         // sites per workgroup
+    constexpr int LP = list_len(Q);
+    struct alignas(8) Acc { T v[EPL]; };
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
+
+    const int id = blockIdx.x;
+    const int xcd = id % kNumXcd, k = id / kNumXcd;
+    const int ct = (k / numJG) * kNumXcd + xcd;
+    const int jg = k % numJG;
+    if (ct >= numColTiles) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jbase = jg * JG + wave * JW;
+
+    Acc acc[JW][Q];
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+        for (int b = 0; b < Q; ++b)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[jj][b].v[e] = 0;
+
+    for (int t = tid; t < kRowBytes / 4; t += WAVES * 64)
+        reinterpret_cast<uint32_t*>(dca_smem + kNC * kRowBytes)[t] = 0u;
+
+    const unsigned char* laneBase = dca_smem + lane * 8;
+    for (int c = 0; c < numChunks; ++c) {
+        __syncthreads();
+        const int n0 = halo + c * kNC;
+        for (int v = tid; v < kNC * (kRowBytes / 16); v += WAVES * 64) {
+            const int r = v / (kRowBytes / 16), cv = v % (kRowBytes / 16);
+            const int n = n0 + r;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (n < N)
+                val = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(R + (size_t)n * Cs + (size_t)ct * CW) + cv * 16);
+            *reinterpret_cast<uint4*>(dca_smem + r * kRowBytes + cv * 16) = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) {
+            const int j = jbase + jj;
+            if (j < L) {
+                const uint32_t* lst = lists + ((size_t)c * L + j) * LP;
+                const int* of = offs + ((size_t)c * L + j) * (Q + 1);
+#pragma unroll
+                for (int b = 0; b < Q; ++b) {
+                    const int k0 = of[b], k1 = of[b + 1];
+                    for (int kk = k0; kk < k1; kk += 4) {
+                        const uint4 e = *reinterpret_cast<const uint4*>(lst + kk);
+                        const Acc v0 = *reinterpret_cast<const Acc*>(laneBase + e.x);
+                        const Acc v1 = *reinterpret_cast<const Acc*>(laneBase + e.y);
+                        const Acc v2 = *reinterpret_cast<const Acc*>(laneBase + e.z);
+                        const Acc v3 = *reinterpret_cast<const Acc*>(laneBase + e.w);
+#pragma unroll
+                        for (int u = 0; u < EPL; ++u) {
+                            T a = acc[jj][b].v[u];
+                            a += v0.v[u]; a += v1.v[u]; a += v2.v[u]; a += v3.v[u];
+                            acc[jj][b].v[u] = a;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+        const int j = jbase + jj;
+        if (j < L) {
+#pragma unroll
+            for (int b = 0; b < Q; ++b)
+                *reinterpret_cast<Acc*>(reinterpret_cast<unsigned char*>(G + (size_t)(j * Q + b) * Cs + (size_t)ct * CW) + lane * 8) = acc[jj][b];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fold
+// g[J_ij(a,b)] = 2 lambda_J J + G[(j,b)][(i,a)] + G[(i,a)][(j,b)]   (plmdca_numerics.cpp:541-602:
+// the site-i and the site-j conditional both contribute), regulariser value per pair
+// (:473-486) as a double partial.
+template <typename T>
+__global__ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
+                                      const PairIJ* __restrict__ pairs, double* __restrict__ regPart,
+                                      int L, int q, int Cs, T lambdaJ, int addReg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
+    T* tile = reinterpret_cast<T*>(dca_smem);                 // G[(j,b)][(i,a)] stored as tile[b*q+a]
+    double* red = reinterpret_cast<double*>(dca_smem + ((size_t)q * q * sizeof(T) + 15) / 16 * 16);
+    const int p = blockIdx.x;
+    const int i = pairs[p].i, j = pairs[p].j;
+    const int q2 = q * q;
+    for (int t = threadIdx.x; t < q2; t += blockDim.x) {
+        const int b = t / q, a = t % q;
+        tile[t] = G[(size_t)(j * q + b) * Cs + i * q + a];
+    }
+    __syncthreads();
+    const size_t base = (size_t)L * q + (size_t)p * q2;
+    double reg = 0.0;
+    for (int t = threadIdx.x; t < q2; t += blockDim.x) {
+        const int a = t / q, b = t % q;
+        const T xv = x[base + t];
+        T gv = addReg ? (T)2 * lambdaJ * xv : (T)0;
+        gv += G[(size_t)(i * q + a) * Cs + j * q + b];
+        gv += tile[b * q + a];
+        g[base + t] = gv;
+        if (addReg) reg += (double)lambdaJ * (double)xv * (double)xv;
+    }
+    red[threadIdx.x] = reg;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) regPart[p] = red[0];
+}
+
+// g[h_i(a)] = 2 lambda_h h + sum_n R[n][(i,a)]; the column sum of R is the sum over b of
+// any site's rows of G (site 0 here).  (:463-471, :538-539, :573-578)
+template <typename T>
+__global__ void plm_fold_fields_kernel(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
+                                       double* __restrict__ regPart, int Lq, int q, int Cs, T lambdaH, int addReg)
+{
+    __shared__ double red[256];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    double reg = 0.0;
+    if (c < Lq) {
+        const T xv = x[c];
+        T gv = addReg ? (T)2 * lambdaH * xv : (T)0;
+        T s = 0;
+        for (int b = 0; b < q; ++b) s += G[(size_t)b * Cs + c];
+        g[c] = gv + s;
+        if (addReg) reg = (double)lambdaH * (double)xv * (double)xv;
+    }
+    red[threadIdx.x] = reg;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) regPart[blockIdx.x] = red[0];
+}
+
+// ------------------------------------------------------------------ L-BFGS vector kernels
+constexpr int kVecBlocks = 1024;
+constexpr int kVecThreads = 256;
+
+template <typename T>
+__global__ void vec_neg_kernel(T* __restrict__ d, const T* __restrict__ g, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = -g[i];
+}
+template <typename T>
+__global__ void vec_axpy_kernel(T* __restrict__ y, T a, const T* __restrict__ x, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+template <typename T>
+__global__ void vec_scale_kernel(T* __restrict__ y, T a, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] *= a;
+}
+// x = xp + stp*d, as lbfgs.cpp:902-903 (copy, then add the rounded product)
+template <typename T>
+__global__ void vec_step_kernel(T* __restrict__ x, const T* __restrict__ xp, T stp, const T* __restrict__ d, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        T v = stp * d[i];
+        x[i] = xp[i] + v;
+    }
+}
+
+__device__ __forceinline__ void block_reduce_store(double v, double* red, double* out)
+{
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+    __syncthreads();
+}
+
+// partials[k*gridDim.x + block] for k = 0..2 : a.b, c.c, a.a   (g.d, x.x, g.g)
+template <typename T>
+__global__ void vec_dot3_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, size_t n,
+                                double* __restrict__ partials)
+{
+    __shared__ double red[kVecThreads];
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double av = a[i], bv = b[i], cv = c[i];
+        s0 += av * bv; s1 += cv * cv; s2 += av * av;
+    }
+    block_reduce_store(s0, red, partials + blockIdx.x);
+    block_reduce_store(s1, red, partials + gridDim.x + blockIdx.x);
+    block_reduce_store(s2, red, partials + 2 * gridDim.x + blockIdx.x);
+}
+template <typename T>
+__global__ void vec_dot_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n, double* __restrict__ partials)
+{
+    __shared__ double red[kVecThreads];
+    double s0 = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        s0 += (double)a[i] * (double)b[i];
+    block_reduce_store(s0, red, partials + blockIdx.x);
+}
+// s = x - xp, y = g - gp, partials: y.s, y.y   (lbfgs.cpp:546-558)
+template <typename T>
+__global__ void vec_diff_kernel(T* __restrict__ s, T* __restrict__ y, const T* __restrict__ x, const T* __restrict__ xp,
+                                const T* __restrict__ g, const T* __restrict__ gp, size_t n, double* __restrict__ partials)
+{
+    __shared__ double red[kVecThreads];
+    double s0 = 0, s1 = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const T sv = x[i] - xp[i], yv = g[i] - gp[i];
+        s[i] = sv; y[i] = yv;
+        s0 += (double)yv * (double)sv; s1 += (double)yv * (double)yv;
+    }
+    block_reduce_store(s0, red, partials + blockIdx.x);
+    block_reduce_store(s1, red, partials + gridDim.x + blockIdx.x);
+}
+// out[k] = sum_b partials[k*nb + b], k < nk; one block, fixed tree
+__global__ void vec_final_kernel(const double* __restrict__ partials, int nb, int nk, double* __restrict__ out)
+{
+    __shared__ double red[256];
+    for (int k = 0; k < nk; ++k) {
+        double s = 0;
+        for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partials[(size_t)k * nb + b];
+        block_reduce_store(s, red, out + k);
+    }
+}
+// out[0] = (add ? out[0] : 0) + sum partials[0..n)
+__global__ void sum_partials_kernel(const double* __restrict__ partials, int n, double* __restrict__ out, int add)
+{
+    __shared__ double red[256];
+    double s = 0;
+    for (int b = threadIdx.x; b < n; b += blockDim.x) s += partials[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (add ? out[0] : 0.0) + red[0];
+}
+
+template <typename T>
+__global__ void cast_weights_kernel(const double* __restrict__ wd, T* __restrict__ w, int N)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) w[n] = (T)wd[n];
+}
+
+// X4[u][n] = bytes X[n][4u..4u+3]
+__global__ void pack_x4_kernel(const uint8_t* __restrict__ X, uint32_t* __restrict__ X4, int N, int Npad, int Ls, int Ls4)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = blockIdx.y;
+    if (n >= Npad || u >= Ls4) return;
+    uint32_t v = 0;
+    if (n < N && u * 4 < Ls) v = *reinterpret_cast<const uint32_t*>(X + (size_t)n * Ls + u * 4);
+    X4[(size_t)u * Npad + n] = v;
+}
+
+// ======================================================================
+// More-Thuente trial-interval update, restated from More & Thuente (1994) with the
+// safeguards the reference's library applies (lbfgs.cpp:1128-1295).  Scalars are double.
+struct LsPoint { double st, f, d; };
+
+double cubic_min(double u, double fu, double du, double v, double fv, double dv)
+{
+    const double d = v - u;
+    const double theta = (fu - fv) * 3 / d + du + dv;
+    const double s = std::max(std::fabs(theta), std::max(std::fabs(du), std::fabs(dv)));
+    const double a = theta / s;
+    double gamma = s * std::sqrt(a * a - (du / s) * (dv / s));
+    if (v < u) gamma = -gamma;
+    const double p = gamma - du + theta, q = gamma - du + gamma + dv;
+    return u + (p / q) * d;
+}
+double cubic_min_clamped(double u, double fu, double du, double v, double fv, double dv, double lo, double hi)
+{
+    const double d = v - u;
+    const double theta = (fu - fv) * 3 / d + du + dv;
+    const double s = std::max(std::fabs(theta), std::max(std::fabs(du), std::fabs(dv)));
+    const double a = theta / s;
+    double gamma = s * std::sqrt(std::max(0.0, a * a - (du / s) * (dv / s)));
+    if (u < v) gamma = -gamma;
+    const double p = gamma - dv + theta, q = gamma - dv + gamma + du;
+    const double r = p / q;
+    if (r < 0. && gamma != 0.) return v - r * d;
+    return a < 0 ? hi : lo;
+}
+double quad_min_f(double u, double fu, double du, double v, double fv)
+{
+    const double a = v - u;
+    return u + du / ((fu - fv) / a + du) / 2 * a;
+}
+double quad_min_d(double u, double du, double v, double dv)
+{
+    const double a = u - v;
+    return v + dv / (dv - du) * a;
+}
+
+enum {
+    LB_OUTOFINTERVAL = -1003, LB_INCORRECT_TMINMAX = -1002, LB_ROUNDING_ERROR = -1001, LB_MINIMUMSTEP = -1000,
+    LB_MAXIMUMSTEP = -999, LB_MAXIMUMLINESEARCH = -998, LB_MAXIMUMITERATION = -997, LB_WIDTHTOOSMALL = -996,
+    LB_INVALIDPARAMETERS = -995, LB_INCREASEGRADIENT = -994, LB_ALREADY_MINIMIZED = 2
+};
+
+int mt_update(LsPoint& best, LsPoint& other, double& t, double ft, double dt, double tmin, double tmax, bool& brackt)
+{
+    const bool opposite = (dt * (best.d / std::fabs(best.d)) < 0.);
+    bool bound;
+    double newt;
+    if (brackt) {
+        if (t <= std::min(best.st, other.st) || std::max(best.st, other.st) <= t) return LB_OUTOFINTERVAL;
+        if (0. <= best.d * (t - best.st)) return LB_INCREASEGRADIENT;
+        if (tmax < tmin) return LB_INCORRECT_TMINMAX;
+    }
+    if (best.f < ft) {
+        brackt = true; bound = true;
+        const double mc = cubic_min(best.st, best.f, best.d, t, ft, dt);
+        const double mq = quad_min_f(best.st, best.f, best.d, t, ft);
+        newt = (std::fabs(mc - best.st) < std::fabs(mq - best.st)) ? mc : mc + 0.5 * (mq - mc);
+    } else if (opposite) {
+        brackt = true; bound = false;
+        const double mc = cubic_min(best.st, best.f, best.d, t, ft, dt);
+        const double mq = quad_min_d(best.st, best.d, t, dt);
+        newt = (std::fabs(mc - t) > std::fabs(mq - t)) ? mc : mq;
+    } else if (std::fabs(dt) < std::fabs(best.d)) {
+        bound = true;
+        const double mc = cubic_min_clamped(best.st, best.f, best.d, t, ft, dt, tmin, tmax);
+        const double mq = quad_min_d(best.st, best.d, t, dt);
+        if (brackt) newt = (std::fabs(t - mc) < std::fabs(t - mq)) ? mc : mq;
+        else newt = (std::fabs(t - mc) > std::fabs(t - mq)) ? mc : mq;
+    } else {
+        bound = false;
+        if (brackt) newt = cubic_min(t, ft, dt, other.st, other.f, other.d);
+        else newt = (best.st < t) ? tmax : tmin;
+    }
+    if (best.f < ft) {
+        other = LsPoint{t, ft, dt};
+    } else {
+        if (opposite) other = best;
+        best = LsPoint{t, ft, dt};
+    }
+    newt = std::min(newt, tmax);
+    newt = std::max(newt, tmin);
+    if (brackt && bound) {
+        const double mq = best.st + 0.66 * (other.st - best.st);
+        if (best.st < other.st) newt = std::min(newt, mq);
+        else newt = std::max(newt, mq);
+    }
+    t = newt;
+    return 0;
+}
+
+template <typename T> struct Geo;
+template <> struct Geo<float> { static constexpr int CT = 64; };
+template <> struct Geo<double> { static constexpr int CT = 32; };
+
+template <typename T>
+struct PlmEngine : PlmEngineBase {
+    dca_ctx* ctx;
+    int N, L, q, Ls;
+    size_t P = 0;
+    int Cs = 0;                  // row stride (elements) of W, SR, G
+    int Wrows = 0, Grows = 0;
+    int Npad = 0, Ls4 = 0;
+    double lambda_h = 0, lambda_J = 0;
+    int carry_mode = DCA_CARRY_CHUNKED, chunk = 128, warm = 40, halo = 0, add_reg = 1;
+    bool configured = false;
+    int numScanChunks = 0, numScatChunks = 0;
+    static constexpr int kLogitWaves = 8;
+    static constexpr int kScatWaves = 8;
+
+    T *dx = nullptr, *dg = nullptr, *dxp = nullptr, *dgp = nullptr, *dd = nullptr;
+    T* dS[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    T* dY[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    T *dWt = nullptr, *dSR = nullptr, *dG = nullptr, *dw = nullptr;
+    uint32_t *dX4 = nullptr, *dLists = nullptr;
+    int* dOffs = nullptr;
+    PairIJ* dPairs = nullptr;
+    double *dFxPart = nullptr, *dRegPart = nullptr, *dVecPart = nullptr;
+    int nFxPart = 0, nRegPart = 0;
+    bool lbfgs_alloc = false;
+
+    // optimiser state (resumable)
+    struct {
+        bool begun = false, finished = false;
+        int status = 0, k = 1, end = 0, iters = 0, evals = 0, max_iterations = 0, verbose = 0;
+        double fx = 0, step = 0, xnorm = 0, gnorm = 0, seconds = 0;
+        double ys[5] = {0, 0, 0, 0, 0}, alpha[5] = {0, 0, 0, 0, 0};
+    } o;
+
+    explicit PlmEngine(dca_ctx* c) : ctx(c), N(c->N), L(c->L), q(c->q), Ls(c->Ls) {}
+
+    template <typename U> int dalloc(U** p, size_t n)
+    {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(U)));
+        return DCA_OK;
+    }
+    void freeall()
+    {
+        hipFree(dx); hipFree(dg); hipFree(dxp); hipFree(dgp); hipFree(dd);
+        for (int i = 0; i < 5; ++i) { hipFree(dS[i]); hipFree(dY[i]); }
+        hipFree(dWt); hipFree(dSR); hipFree(dG); hipFree(dw); hipFree(dX4); hipFree(dLists); hipFree(dOffs);
+        hipFree(dPairs); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
+    }
+    ~PlmEngine() override { freeall(); }
+
+    int jt() const { return q <= 8 ? 32 : 8; }
+    int jw() const { return q <= 8 ? 8 : 2; }
+
+    int configure(double lh, double lJ, int cmode, int chunk_, int warm_, int halo_, int add_reg_) override
+    {
+        if (q != 21 && q != 5) { dca_set_error("plmDCA kernels are built for q = 21 (protein) and q = 5 (RNA); got %d", q); return DCA_ERR_ARG; }
+        if (!ctx->have_weights) { dca_set_error("weights must be computed or set before dca_plm_configure"); return DCA_ERR_STATE; }
+        if (halo_ < 0 || halo_ >= N) { dca_set_error("halo out of range"); return DCA_ERR_ARG; }
+        if (L > 65535) { dca_set_error("L too large"); return DCA_ERR_ARG; }
+        lambda_h = lh; lambda_J = lJ; carry_mode = cmode; halo = halo_; add_reg = add_reg_;
+        chunk = chunk_ > 0 ? chunk_ : 128;
+        warm = warm_ > 0 ? warm_ : 40;
+        if (carry_mode == DCA_CARRY_SERIAL) { chunk = N - halo; warm = halo; }
+        if (carry_mode == DCA_CARRY_EXACT) warm = 0;
+        numScanChunks = ceil_div(N - halo, chunk);
+        numScatChunks = ceil_div(N - halo, kNC);
+
+        freeall();
+        dx = dg = dxp = dgp = dd = nullptr;
+        for (int i = 0; i < 5; ++i) dS[i] = dY[i] = nullptr;
+        dWt = dSR = dG = dw = nullptr; dX4 = dLists = nullptr; dOffs = nullptr; dPairs = nullptr;
+        dFxPart = dRegPart = dVecPart = nullptr;
+        lbfgs_alloc = false;
+        o = decltype(o)();
+
+        P = dca_plm_num_params(L, q);
+        const int Lq = L * q;
+        Cs = (int)round_up(Lq, 128);
+        const int JT = jt();
+        Wrows = ceil_div(L, JT) * JT * q;
+        const int JG = kScatWaves * jw();
+        Grows = ceil_div(L, JG) * JG * q;
+        Npad = (int)round_up(N, 64 * kLogitWaves);
+        Ls4 = ceil_div(L, JT) * JT / 4;
+
+        DCA_TRY(dalloc(&dx, P)); DCA_TRY(dalloc(&dg, P));
+        DCA_TRY(dalloc(&dWt, (size_t)Wrows * Cs));
+        DCA_TRY(dalloc(&dSR, (size_t)N * Cs));
+        DCA_TRY(dalloc(&dG, (size_t)Grows * Cs));
+        DCA_TRY(dalloc(&dw, N));
+        DCA_TRY(dalloc(&dX4, (size_t)Ls4 * Npad));
+        DCA_TRY(dalloc(&dLists, (size_t)numScatChunks * L * list_len(q)));
+        DCA_TRY(dalloc(&dOffs, (size_t)numScatChunks * L * (q + 1)));
+        const size_t npairs = (size_t)L * (L - 1) / 2;
+        DCA_TRY(dalloc(&dPairs, npairs));
+        nFxPart = ceil_div(L, 64) * ceil_div(numScanChunks, 4) * 4;
+        nRegPart = (int)npairs + ceil_div(Lq, 256);
+        DCA_TRY(dalloc(&dFxPart, nFxPart));
+        DCA_TRY(dalloc(&dRegPart, nRegPart));
+        DCA_TRY(dalloc(&dVecPart, 3 * kVecBlocks));
+
+        HIP_TRY(hipMemsetAsync(dx, 0, P * sizeof(T), ctx->stream));
+        HIP_TRY(hipMemsetAsync(dg, 0, P * sizeof(T), ctx->stream));
+        HIP_TRY(hipMemsetAsync(dWt, 0, (size_t)Wrows * Cs * sizeof(T), ctx->stream));
+        HIP_TRY(hipMemsetAsync(dG, 0, (size_t)Grows * Cs * sizeof(T), ctx->stream));
+
+        std::vector<PairIJ> hp(npairs);
+        {
+            size_t k = 0;
+            for (int i = 0; i < L - 1; ++i) for (int j = i + 1; j < L; ++j) hp[k++] = PairIJ{(uint16_t)i, (uint16_t)j};
+        }
+        HIP_TRY(hipMemcpyAsync(dPairs, hp.data(), npairs * sizeof(PairIJ), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+        // weights in T.  1/count is formed in T exactly as the reference does
+        // (1.f/count, plmdca_numerics.cpp:669) when the counts are known.
+        std::vector<T> hw(N);
+        {
+            std::vector<double> wd(N);
+            HIP_TRY(hipMemcpy(wd.data(), ctx->dWd, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+            if (ctx->have_counts) {
+                std::vector<uint32_t> cnt(N);
+                HIP_TRY(hipMemcpy(cnt.data(), ctx->dCounts, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                for (int n = 0; n < N; ++n) hw[n] = (T)1 / (T)cnt[n];
+            } else {
+                for (int n = 0; n < N; ++n) hw[n] = (T)wd[n];
+            }
+        }
+        HIP_TRY(hipMemcpy(dw, hw.data(), (size_t)N * sizeof(T), hipMemcpyHostToDevice));
+
+        {
+            dim3 grid(ceil_div(Npad, 256), Ls4);
+            hipLaunchKernelGGL(pack_x4_kernel, grid, dim3(256), 0, ctx->stream, ctx->dX, dX4, N, Npad, Ls, Ls4);
+            const int nt = numScatChunks * L;
+            hipLaunchKernelGGL(plm_build_lists_kernel, dim3(ceil_div(nt, 128)), dim3(128), 0, ctx->stream,
+                               ctx->dX, dLists, dOffs, N, L, Ls, q, halo, numScatChunks);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        configured = true;
+        return DCA_OK;
+    }
+
+    // PlmDCA::initFieldsAndCouplings (plmdca_numerics.cpp:207-249) in T, host side
+    // (L*q values from an N*L pass; not worth a kernel).
+    int init_x() override
+    {
+        if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
+        std::vector<T> hw(N);
+        HIP_TRY(hipMemcpy(hw.data(), dw, (size_t)N * sizeof(T), hipMemcpyDeviceToHost));
+        T meff = 0;
+        for (int n = 0; n < N; ++n) meff += hw[n];
+        std::vector<T> h((size_t)L * q, (T)0);
+        const uint8_t* X = ctx->hX.data();
+        for (int n = 0; n < N; ++n)
+            for (int i = 0; i < L; ++i) h[(size_t)i * q + X[(size_t)n * L + i]] += hw[n];
+        for (int i = 0; i < L; ++i) {
+            T* hi = h.data() + (size_t)i * q;
+            for (int a = 0; a < q; ++a) hi[a] /= meff;
+            for (int a = 0; a < q; ++a) hi[a] = std::log(hi[a] * meff + (T)1);
+            T s = 0;
+            for (int a = 0; a < q; ++a) s += hi[a];
+            const T av = s / (T)q;
+            for (int a = 0; a < q; ++a) hi[a] -= av;
+        }
+        HIP_TRY(hipMemsetAsync(dx, 0, P * sizeof(T), ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dx, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return DCA_OK;
+    }
+
+    template <typename U> int upload(const U* src, T* dst)
+    {
+        std::vector<T> tmp(P);
+        for (size_t i = 0; i < P; ++i) tmp[i] = (T)src[i];
+        HIP_TRY(hipMemcpy(dst, tmp.data(), P * sizeof(T), hipMemcpyHostToDevice));
+        return DCA_OK;
+    }
+    template <typename U> int download(const T* src, U* dst)
+    {
+        std::vector<T> tmp(P);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(tmp.data(), src, P * sizeof(T), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < P; ++i) dst[i] = (U)tmp[i];
+        return DCA_OK;
+    }
+    int set_x(const void* x, int dtype) override
+    {
+        if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
+        if (dtype == DCA_F32) return upload(static_cast<const float*>(x), dx);
+        if (dtype == DCA_F64) return upload(static_cast<const double*>(x), dx);
+        return DCA_ERR_ARG;
+    }
+    int get_x(void* x, int dtype) override
+    {
+        if (!configured) return DCA_ERR_STATE;
+        if (dtype == DCA_F32) return download(dx, static_cast<float*>(x));
+        if (dtype == DCA_F64) return download(dx, static_cast<double*>(x));
+        return DCA_ERR_ARG;
+    }
+    int get_g(void* g, int dtype) override
+    {
+        if (!configured) return DCA_ERR_STATE;
+        if (dtype == DCA_F32) return download(dg, static_cast<float*>(g));
+        if (dtype == DCA_F64) return download(dg, static_cast<double*>(g));
+        return DCA_ERR_ARG;
+    }
+
+    template <int Q> int launch_eval()
+    {
+        hipStream_t st = ctx->stream;
+        const size_t npairs = (size_t)L * (L - 1) / 2;
+        const int Lq = L * q;
+        {
+            ScopedKernelClock kc(ctx, "plm_expand");
+            hipLaunchKernelGGL(plm_expand_kernel<T>, dim3((unsigned)npairs), dim3(256), (size_t)q * q * sizeof(T), st,
+                               dx, dWt, dPairs, L, q, Cs);
+        }
+        {
+            constexpr int CT = Geo<T>::CT;
+            constexpr int JT = (Q <= 8) ? 32 : 8;
+            constexpr int W = kLogitWaves;
+            const int numCT = Cs / CT;
+            const int numNB = Npad / (64 * W);
+            const int blocks = kNumXcd * ceil_div(numCT, kNumXcd) * numNB;
+            const size_t lds = (size_t)JT * Q * (CT + V16<T>::n) * sizeof(T);
+            auto kern = plm_logits_kernel<T, Q, CT, JT, W>;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ScopedKernelClock kc(ctx, "plm_logits");
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(W * 64), lds, st, dWt, dX4, dSR, N, Npad, L, Cs, numCT, numNB);
+        }
+        {
+            dim3 grid(ceil_div(L, 64), ceil_div(numScanChunks, 4));
+            ScopedKernelClock kc(ctx, "plm_softmax");
+            hipLaunchKernelGGL((plm_softmax_kernel<T, Q>), grid, dim3(256), 0, st, dSR, dx, ctx->dX, dw, dFxPart,
+                               N, L, Ls, Cs, halo, chunk, warm, carry_mode != DCA_CARRY_EXACT ? 1 : 0, numScanChunks);
+        }
+        {
+            constexpr int JW = (Q <= 8) ? 8 : 2;
+            constexpr int W = kScatWaves;
+            constexpr int CW = 64 * (8 / (int)sizeof(T));
+            const int numCT = Cs / CW;
+            const int numJG = ceil_div(L, W * JW);
+            const int blocks = kNumXcd * ceil_div(numCT, kNumXcd) * numJG;
+            const size_t lds = (size_t)(kNC + 1) * kRowBytes;
+            auto kern = plm_scatter_kernel<T, Q, JW, W>;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ScopedKernelClock kc(ctx, "plm_scatter");
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(W * 64), lds, st, dSR, dLists, dOffs, dG, N, L, Cs, halo,
+                               numScatChunks, numCT, numJG);
+        }
+        {
+            ScopedKernelClock kc(ctx, "plm_fold");
+            const size_t lds = ((size_t)q * q * sizeof(T) + 15) / 16 * 16 + 256 * sizeof(double);
+            hipLaunchKernelGGL(plm_fold_pairs_kernel<T>, dim3((unsigned)npairs), dim3(256), lds, st, dx, dG, dg, dPairs,
+                               dRegPart, L, q, Cs, (T)lambda_J, add_reg);
+            hipLaunchKernelGGL(plm_fold_fields_kernel<T>, dim3(ceil_div(Lq, 256)), dim3(256), 0, st, dx, dG, dg,
+                               dRegPart + npairs, Lq, q, Cs, (T)lambda_h, add_reg);
+        }
+        // fx = regulariser + data term  -> ctx->dScal[0]
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, dRegPart, nRegPart, ctx->dScal, 0);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, dFxPart, nFxPart, ctx->dScal, 1);
+        HIP_TRY(hipGetLastError());
+        return DCA_OK;
+    }
+
+    // leaves fx in ctx->dScal[0] (device); no host sync unless a reduce hook is set
+    int evaluate_async()
+    {
+        if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
+        int rc = (q == 21) ? launch_eval<21>() : launch_eval<5>();
+        if (rc != DCA_OK) return rc;
+        o.evals += 1;
+        if (hook) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (hook(hook_user, dg, P, (int)sizeof(T) * 8, ctx->dScal) != 0) {
+                dca_set_error("reduce hook failed");
+                return DCA_ERR_ARG;
+            }
+        }
+        return DCA_OK;
+    }
+
+    int read_scalars(int n)
+    {
+        HIP_TRY(hipMemcpyAsync(ctx->hScal, ctx->dScal, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return DCA_OK;
+    }
+
+    int gradient(double* fx_out) override
+    {
+        DCA_TRY(evaluate_async());
+        DCA_TRY(read_scalars(1));
+        if (fx_out) *fx_out = ctx->hScal[0];
+        return DCA_OK;
+    }
+
+    // ---------------- vector helpers
+    void v_neg(T* d, const T* g) { hipLaunchKernelGGL(vec_neg_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, d, g, P); }
+    void v_axpy(T* y, double a, const T* x) { hipLaunchKernelGGL(vec_axpy_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, y, (T)a, x, P); }
+    void v_scale(T* y, double a) { hipLaunchKernelGGL(vec_scale_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, y, (T)a, P); }
+    void v_step(T* x, const T* xp, double stp, const T* d) { hipLaunchKernelGGL(vec_step_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, x, xp, (T)stp, d, P); }
+    int v_copy(T* dst, const T* src) { HIP_TRY(hipMemcpyAsync(dst, src, P * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream)); return DCA_OK; }
+    int v_dot(const T* a, const T* b, double* out)
+    {
+        hipLaunchKernelGGL(vec_dot_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, a, b, P, dVecPart);
+        hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 1, ctx->dScal + 1);
+        HIP_TRY(hipMemcpyAsync(ctx->hScal + 1, ctx->dScal + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        *out = ctx->hScal[1];
+        return DCA_OK;
+    }
+    // after an evaluation: fx (slot 0), g.d, x.x, g.g (slots 1..3) in one round trip
+    int eval_scalars(double* fx, double* gd, double* xx, double* gg)
+    {
+        hipLaunchKernelGGL(vec_dot3_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dg, dd, dx, P, dVecPart);
+        hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 3, ctx->dScal + 1);
+        DCA_TRY(read_scalars(4));
+        *fx = ctx->hScal[0]; *gd = ctx->hScal[1]; *xx = ctx->hScal[2]; *gg = ctx->hScal[3];
+        return DCA_OK;
+    }
+
+    int lbfgs_begin(int max_iterations, int verbose) override
+    {
+        if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
+        if (!lbfgs_alloc) {
+            DCA_TRY(dalloc(&dxp, P)); DCA_TRY(dalloc(&dgp, P)); DCA_TRY(dalloc(&dd, P));
+            for (int i = 0; i < 5; ++i) { DCA_TRY(dalloc(&dS[i], P)); DCA_TRY(dalloc(&dY[i], P)); }
+            lbfgs_alloc = true;
+        }
+        o = decltype(o)();
+        o.max_iterations = max_iterations;
+        o.verbose = verbose;
+        auto t0 = std::chrono::steady_clock::now();
+        DCA_TRY(evaluate_async());
+        v_neg(dd, dg);
+        double fx, gd, xx, gg;
+        DCA_TRY(eval_scalars(&fx, &gd, &xx, &gg));
+        o.fx = fx;
+        o.xnorm = std::sqrt(xx); o.gnorm = std::sqrt(gg);
+        const double xn = std::max(o.xnorm, 1.0);
+        o.begun = true;
+        if (o.gnorm / xn <= 1e-3) { o.status = LB_ALREADY_MINIMIZED; o.finished = true; }
+        o.step = 1.0 / std::sqrt(gg);      // 1/|d| with d = -g   (lbfgs.cpp:459)
+        o.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return DCA_OK;
+    }
+
+    // More-Thuente line search (lbfgs.cpp:815-1004) on device vectors.  Returns the number
+    // of evaluations (>0) or a libLBFGS error code; *rc_hip carries runtime failures.
+    int line_search(double* stp, double* f, double* xx, double* gg, int* rc_hip)
+    {
+        const double ftol = 1e-4, gtol = 0.9, xtol = 1e-16, min_step = 1e-20, max_step = 1e20;
+        const int max_ls = 5;
+        int count = 0, uinfo = 0;
+        bool brackt = false, stage1 = true;
+        double dginit;
+        *rc_hip = v_dot(dg, dd, &dginit);
+        if (*rc_hip) return 0;
+        if (*stp <= 0.) return LB_INVALIDPARAMETERS;
+        if (0 < dginit) return LB_INCREASEGRADIENT;
+        const double finit = *f, dgtest = ftol * dginit;
+        double width = max_step - min_step, prev_width = 2.0 * width;
+        LsPoint bx{0., finit, dginit}, by{0., finit, dginit};
+        for (;;) {
+            double stmin, stmax;
+            if (brackt) { stmin = std::min(bx.st, by.st); stmax = std::max(bx.st, by.st); }
+            else { stmin = bx.st; stmax = *stp + 4.0 * (*stp - bx.st); }
+            if (*stp < min_step) *stp = min_step;
+            if (max_step < *stp) *stp = max_step;
+            if ((brackt && ((*stp <= stmin || stmax <= *stp) || max_ls <= count + 1 || uinfo != 0)) ||
+                (brackt && (stmax - stmin <= xtol * stmax)))
+                *stp = bx.st;
+            v_step(dx, dxp, *stp, dd);
+            if ((*rc_hip = evaluate_async())) return 0;
+            double dg_;
+            if ((*rc_hip = eval_scalars(f, &dg_, xx, gg))) return 0;
+            const double ftest1 = finit + *stp * dgtest;
+            ++count;
+            if (brackt && ((*stp <= stmin || stmax <= *stp) || uinfo != 0)) return LB_ROUNDING_ERROR;
+            if (*stp == max_step && *f <= ftest1 && dg_ <= dgtest) return LB_MAXIMUMSTEP;
+            if (*stp == min_step && (ftest1 < *f || dgtest <= dg_)) return LB_MINIMUMSTEP;
+            if (brackt && (stmax - stmin) <= xtol * stmax) return LB_WIDTHTOOSMALL;
+            if (max_ls <= count) return LB_MAXIMUMLINESEARCH;
+            if (*f <= ftest1 && std::fabs(dg_) <= gtol * (-dginit)) return count;
+            if (stage1 && *f <= ftest1 && std::min(ftol, gtol) * dginit <= dg_) stage1 = false;
+            if (stage1 && ftest1 < *f && *f <= bx.f) {
+                LsPoint mx{bx.st, bx.f - bx.st * dgtest, bx.d - dgtest};
+                LsPoint my{by.st, by.f - by.st * dgtest, by.d - dgtest};
+                uinfo = mt_update(mx, my, *stp, *f - *stp * dgtest, dg_ - dgtest, stmin, stmax, brackt);
+                bx = LsPoint{mx.st, mx.f + mx.st * dgtest, mx.d + dgtest};
+                by = LsPoint{my.st, my.f + my.st * dgtest, my.d + dgtest};
+            } else {
+                uinfo = mt_update(bx, by, *stp, *f, dg_, stmin, stmax, brackt);
+            }
+            if (brackt) {
+                if (0.66 * prev_width <= std::fabs(by.st - bx.st)) *stp = bx.st + 0.5 * (by.st - bx.st);
+                prev_width = width;
+                width = std::fabs(by.st - bx.st);
+            }
+        }
+    }
+
+    int lbfgs_iterate(int iterations, dca_plm_stats* st) override
+    {
+        if (!o.begun) { dca_set_error("dca_plm_lbfgs_begin first"); return DCA_ERR_STATE; }
+        auto t0 = std::chrono::steady_clock::now();
+        constexpr int M = 5;
+        for (int it = 0; it < iterations && !o.finished; ++it) {
+            DCA_TRY(v_copy(dxp, dx));
+            DCA_TRY(v_copy(dgp, dg));
+            double xx = 0, gg = 0;
+            int rc = 0;
+            const int ls = line_search(&o.step, &o.fx, &xx, &gg, &rc);
+            if (rc) return rc;
+            if (ls < 0) {   // revert to the previous point (lbfgs.cpp:478-484)
+                DCA_TRY(v_copy(dx, dxp));
+                DCA_TRY(v_copy(dg, dgp));
+                o.status = ls; o.finished = true;
+                break;
+            }
+            o.xnorm = std::sqrt(xx); o.gnorm = std::sqrt(gg);
+            o.iters = o.k;
+            if (o.verbose) {
+                fprintf(stderr, "Iteration %d:\n", o.k);
+                fprintf(stderr, "fx = %f, xnorm = %f, gnorm = %f, step = %f\n\n", o.fx, o.xnorm, o.gnorm, o.step);
+            }
+            const double xn = std::max(o.xnorm, 1.0);
+            if (o.gnorm / xn <= 1e-3) { o.status = 0; o.finished = true; break; }
+            if (o.max_iterations != 0 && o.max_iterations < o.k + 1) { o.status = LB_MAXIMUMITERATION; o.finished = true; break; }
+
+            hipLaunchKernelGGL(vec_diff_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream,
+                               dS[o.end], dY[o.end], dx, dxp, dg, dgp, P, dVecPart);
+            hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 2, ctx->dScal + 1);
+            DCA_TRY(read_scalars(3));
+            const double ys = ctx->hScal[1], yy = ctx->hScal[2];
+            o.ys[o.end] = ys;
+            const int bound = (M <= o.k) ? M : o.k;
+            ++o.k;
+            o.end = (o.end + 1) % M;
+            {
+                ScopedKernelClock kc(ctx, "lbfgs_vec");
+                v_neg(dd, dg);
+                int j = o.end;
+                for (int i = 0; i < bound; ++i) {
+                    j = (j + M - 1) % M;
+                    double sd;
+                    DCA_TRY(v_dot(dS[j], dd, &sd));
+                    o.alpha[j] = sd / o.ys[j];
+                    v_axpy(dd, -o.alpha[j], dY[j]);
+                }
+                v_scale(dd, ys / yy);
+                for (int i = 0; i < bound; ++i) {
+                    double yd;
+                    DCA_TRY(v_dot(dY[j], dd, &yd));
+                    const double beta = yd / o.ys[j];
+                    v_axpy(dd, o.alpha[j] - beta, dS[j]);
+                    j = (j + 1) % M;
+                }
+            }
+            o.step = 1.0;
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        o.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (st) {
+            st->status = o.status; st->iterations = o.iters; st->evaluations = o.evals; st->finished = o.finished ? 1 : 0;
+            st->fx = o.fx; st->xnorm = o.xnorm; st->gnorm = o.gnorm; st->step = o.step; st->seconds = o.seconds;
+        }
+        return DCA_OK;
+    }
+
+    int scores(int apc, double* out) override
+    {
+        if (!configured) return DCA_ERR_STATE;
+        const size_t npairs = (size_t)L * (L - 1) / 2;
+        double* dOut = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
+        int rc = dca_fn_scores(ctx, dx, 0, (int)sizeof(T) * 8, L, q, 0, apc, dOut);
+        if (rc == DCA_OK) {
+            hipError_t e = hipMemcpy(out, dOut, npairs * sizeof(double), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { dca_set_error("copy scores: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
+        }
+        hipFree(dOut);
+        return rc;
+    }
+};
+
+}  // namespace
+
+PlmEngineBase* dca_make_plm_engine(dca_ctx* ctx)
+{
+    if (ctx->precision == DCA_F64) return new PlmEngine<double>(ctx);
+    return new PlmEngine<float>(ctx);
+}

@@ -1,0 +1,142 @@
+// Frobenius-norm (+ average-product-corrected) scores of coupling blocks.
+// Reference: PlmDCA.get_couplings_no_gap_state / compute_sorted_FN / compute_sorted_FN_APC
+// (pydca/plmdca/plmdca.py:246-268, :437-524) and MeanFieldDCA.compute_sorted_FN[_APC]
+// (pydca/meanfield_dca/meanfield_dca.py:902-988).  The gap row/column is dropped, the
+// (q-1)x(q-1) block is double-centred, FN = sqrt(sum J'^2); APC subtracts av_i*av_j/av.
+// HBM-bound (each coupling is read once); float64 arithmetic for both paths.
+#include "dca_internal.h"
+
+namespace {
+
+__host__ __device__ __forceinline__ size_t pair_index(int L, int i, int j)
+{
+    return (size_t)L * (L - 1) / 2 - (size_t)(L - i) * (L - i - 1) / 2 + (size_t)(j - i - 1);
+}
+
+// one 64-lane workgroup per site pair; block values go through LDS
+template <typename S>
+__global__ __launch_bounds__(64)
+void fn_kernel(const S* __restrict__ src, int kind, int L, int q, int ld, double* __restrict__ fn)
+{
+    __shared__ double blk[20 * 20];
+    __shared__ double rowm[20], colm[20];
+    __shared__ double tot;
+    const int qm = q - 1;
+    // decode (i,j) from blockIdx: rows of the upper triangle
+    const size_t p = blockIdx.x;
+    int i = 0;
+    {
+        // largest i with pair_index(L,i,i+1) <= p  (solve the quadratic, then fix up)
+        const double Ld = (double)L;
+        double t = (2.0 * Ld - 1.0 - sqrt((2.0 * Ld - 1.0) * (2.0 * Ld - 1.0) - 8.0 * (double)p)) / 2.0;
+        i = (int)t;
+        if (i < 0) i = 0;
+        if (i > L - 2) i = L - 2;
+        while (i > 0 && pair_index(L, i, i + 1) > p) --i;
+        while (i < L - 2 && pair_index(L, i + 1, i + 2) <= p) ++i;
+    }
+    const int j = (int)(p - pair_index(L, i, i + 1)) + i + 1;
+    const int t = threadIdx.x;
+    for (int e = t; e < qm * qm; e += 64) {
+        const int a = e / qm, b = e % qm;
+        double v;
+        if (kind == 0) v = (double)src[(size_t)L * q + p * (size_t)q * q + (size_t)a * q + b];
+        else v = (double)src[(size_t)(i * qm + a) * ld + (size_t)j * qm + b];
+        blk[e] = v;
+    }
+    __syncthreads();
+    if (t < qm) {
+        double s = 0;
+        for (int b = 0; b < qm; ++b) s += blk[t * qm + b];
+        rowm[t] = s / qm;           // mean over b (axis=1)
+        double c = 0;
+        for (int a = 0; a < qm; ++a) c += blk[a * qm + t];
+        colm[t] = c / qm;           // mean over a (axis=0)
+    }
+    __syncthreads();
+    if (t == 0) {
+        double s = 0;
+        for (int e = 0; e < qm * qm; ++e) s += blk[e];
+        tot = s / (double)(qm * qm);
+    }
+    __syncthreads();
+    double acc = 0;
+    for (int e = t; e < qm * qm; e += 64) {
+        const int a = e / qm, b = e % qm;
+        const double v = blk[e] - colm[b] - rowm[a] + tot;
+        acc += v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (t == 0) fn[p] = sqrt(acc);
+}
+
+// av[i] = sum_{j != i} FN_ij / (L-1)
+__global__ __launch_bounds__(256)
+void apc_site_kernel(const double* __restrict__ fn, int L, double* __restrict__ av)
+{
+    __shared__ double red[256];
+    const int i = blockIdx.x;
+    double s = 0;
+    for (int j = threadIdx.x; j < L; j += 256) {
+        if (j == i) continue;
+        const int a = j < i ? j : i, b = j < i ? i : j;
+        s += fn[pair_index(L, a, b)];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) av[i] = red[0] / (double)(L - 1);
+}
+
+__global__ __launch_bounds__(256)
+void apc_mean_kernel(const double* __restrict__ av, int L, double* __restrict__ out)
+{
+    __shared__ double red[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < L; i += 256) s += av[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] / (double)L;
+}
+
+// FN_ij - av_i * (av_j / av)    (same association as the reference expression)
+__global__ void apc_apply_kernel(double* __restrict__ fn, const double* __restrict__ av, const double* __restrict__ avAll, int L)
+{
+    const int i = blockIdx.x;
+    for (int j = i + 1 + threadIdx.x; j < L; j += blockDim.x) {
+        const size_t p = pair_index(L, i, j);
+        fn[p] = fn[p] - av[i] * (av[j] / avAll[0]);
+    }
+}
+
+}  // namespace
+
+int dca_fn_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L, int q, int ld, int apc, double* dOut)
+{
+    if (q - 1 > 20) { dca_set_error("q too large for the scoring kernel"); return DCA_ERR_ARG; }
+    const size_t npairs = (size_t)L * (L - 1) / 2;
+    ScopedKernelClock kc(ctx, "scores");
+    if (dtype == DCA_F32)
+        hipLaunchKernelGGL(fn_kernel<float>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const float*>(src), src_kind, L, q, ld, dOut);
+    else
+        hipLaunchKernelGGL(fn_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const double*>(src), src_kind, L, q, ld, dOut);
+    if (apc) {
+        double* dAv = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dAv), (size_t)(L + 1) * sizeof(double)));
+        hipLaunchKernelGGL(apc_site_kernel, dim3(L), dim3(256), 0, ctx->stream, dOut, L, dAv);
+        hipLaunchKernelGGL(apc_mean_kernel, dim3(1), dim3(256), 0, ctx->stream, dAv, L, dAv + L);
+        hipLaunchKernelGGL(apc_apply_kernel, dim3(L - 1), dim3(256), 0, ctx->stream, dOut, dAv, dAv + L, L);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        hipFree(dAv);
+        if (e != hipSuccess) { dca_set_error("apc: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
+    }
+    HIP_TRY(hipGetLastError());
+    return DCA_OK;
+}

@@ -1,0 +1,330 @@
+"""GPU parity tests: the HIP path (through the C-ABI, pydca_amd._lib.Context) against the
+CPU oracle and the golden fixtures produced by the real reference.  Run on an MI355X:
+    python -m pytest tests -m gpu -x -q
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, data_file, golden, perturbed, rel_err
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def L_():
+    from pydca_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def make_ctx(L_, X, q, precision, seqid=0.8, cmp=None):
+    ctx = L_.Context(0, precision)
+    ctx.set_msa(X, q)
+    ctx.compute_weights(seqid, cmp if cmp is not None else precision)
+    return ctx
+
+
+PLM_TAGS = ["toy_rna", "toy_protein", "rf71", "rf00167"]
+
+
+@pytest.mark.parametrize("tag", PLM_TAGS)
+def test_weights_bit_exact(L_, oracle_plm, tag):
+    """plmdca_numerics.cpp:611-671 -- integer counts and float32 1/count, bit for bit."""
+    G = golden("plm_" + tag)
+    ctx = make_ctx(L_, G["X"], int(G["q"]), L_.DCA_F32, float(G["seqid"]))
+    counts = ctx.weight_counts()
+    ref_counts = np.rint(1.0 / G["w"].astype(np.float64)).astype(np.uint32)
+    assert np.array_equal(counts, ref_counts)
+    assert np.array_equal((1.0 / counts.astype(np.float32)).astype(np.float32), G["w"])
+    # double-compare variant (meanfield_dca/msa_numerics.py:13-50) vs the oracle
+    ctx64 = make_ctx(L_, G["X"], int(G["q"]), L_.DCA_F64, 0.8, L_.DCA_F64)
+    w64 = oracle_plm.weights(G["X"], 0.8, np.float64)
+    assert np.array_equal(ctx64.weights(), w64)
+    ctx.close(); ctx64.close()
+
+
+def test_weights_thresholds_and_ragged_sizes(L_, oracle_plm):
+    """Sizes that are not multiples of the 64x64 tile / 128-site stage, several seqid values."""
+    rng = np.random.default_rng(5)
+    for (N, L, q) in [(1, 7, 5), (65, 129, 21), (200, 33, 5), (513, 130, 21)]:
+        base = rng.integers(0, q, size=(max(1, N // 8), L), dtype=np.uint8)
+        X = base[rng.integers(len(base), size=N)].copy()
+        flip = rng.random((N, L)) < 0.2
+        X[flip] = rng.integers(0, q, size=int(flip.sum()), dtype=np.uint8)
+        for seqid in (0.5, 0.8, 0.9, 0.999):
+            ctx = L_.Context(0, L_.DCA_F32)
+            ctx.set_msa(X, q)
+            w = ctx.compute_weights(seqid, L_.DCA_F32)
+            assert np.array_equal(w.astype(np.float32), oracle_plm.weights(X, seqid, np.float32)), (N, L, q, seqid)
+            ctx.close()
+
+
+@pytest.mark.parametrize("tag", PLM_TAGS)
+def test_init_x(L_, oracle_plm, tag):
+    G = golden("plm_" + tag)
+    L, q = int(G["L"]), int(G["q"])
+    ctx = make_ctx(L_, G["X"], q, L_.DCA_F32, float(G["seqid"]))
+    ctx.plm_configure(float(G["lambda_h"]), float(G["lambda_J"]))
+    ctx.plm_init_x()
+    x0 = ctx.plm_get_x(np.float32)
+    ref = oracle_plm.init_x(G["X"], G["w"], q)
+    np.testing.assert_allclose(x0, ref, rtol=2e-6, atol=2e-6)
+    ctx.close()
+
+
+@pytest.mark.parametrize("tag", PLM_TAGS)
+@pytest.mark.parametrize("mode", ["chunked", "serial"])
+def test_gradient_float32_vs_reference_and_oracle(L_, oracle_plm, tag, mode):
+    """Fixed-x (fx, g) of PlmDCA::gradient (plmdca_numerics.cpp:436-607).  float32 kernels:
+    <= 1e-5 relative against the reference's own float32 output (golden) and against the
+    float64 oracle."""
+    G = golden("plm_" + tag)
+    L, q = int(G["L"]), int(G["q"])
+    lh, lJ = float(G["lambda_h"]), float(G["lambda_J"])
+    ctx = make_ctx(L_, G["X"], q, L_.DCA_F32, float(G["seqid"]))
+    ctx.plm_configure(lh, lJ, L_.CARRY_CHUNKED if mode == "chunked" else L_.CARRY_SERIAL)
+    x0 = oracle_plm.init_x(G["X"], G["w"], q)
+    full = "g0" in G.files
+    for x, fk, gk in ((x0, "fx0", "g0"), (perturbed(x0, L, q), "fx1", "g1")):
+        ctx.plm_set_x(x)
+        fx = ctx.plm_gradient()
+        g = ctx.plm_get_g(np.float32)
+        fx64, g64 = oracle_plm.gradient(G["X"], G["w"].astype(np.float64), q, lh, lJ, x.astype(np.float64), carry=True)
+        assert abs(fx - fx64) <= 2e-6 * abs(fx64)
+        assert rel_err(g, g64) < 1e-5
+        if full:
+            assert rel_err(g, G[gk]) < 1e-5
+        else:
+            assert rel_err(g[G["idx"]], G[gk + "_sub"]) < 1e-5
+        assert abs(fx - float(G[fk])) <= 5e-5 * abs(float(G[fk]))
+    ctx.close()
+
+
+@pytest.mark.parametrize("tag", ["toy_rna", "toy_protein", "rf71"])
+def test_gradient_float64_vs_oracle(L_, oracle_plm, tag):
+    """float64 kernels vs the float64 oracle: summation order is the only difference."""
+    G = golden("plm_" + tag)
+    L, q = int(G["L"]), int(G["q"])
+    lh, lJ = float(G["lambda_h"]), float(G["lambda_J"])
+    w64 = oracle_plm.weights(G["X"], 0.8, np.float64)
+    x = perturbed(oracle_plm.init_x(G["X"], w64, q), L, q)
+    for mode, carry in ((L_.CARRY_SERIAL, True), (L_.CARRY_CHUNKED, True), (L_.CARRY_EXACT, False)):
+        ctx = make_ctx(L_, G["X"], q, L_.DCA_F64, 0.8, L_.DCA_F64)
+        ctx.plm_configure(lh, lJ, mode)
+        ctx.plm_set_x(x)
+        fx = ctx.plm_gradient()
+        g = ctx.plm_get_g(np.float64)
+        fx_o, g_o = oracle_plm.gradient(G["X"], w64, q, lh, lJ, x, carry=carry)
+        assert abs(fx - fx_o) <= 1e-11 * abs(fx_o), (mode, fx, fx_o)
+        assert rel_err(g, g_o) < 1e-11, mode
+        ctx.close()
+
+
+def test_chunked_scan_equals_serial_chain(L_, oracle_plm):
+    """The chunk-parallel scan with 40 warm-up steps must reproduce the strictly serial
+    carry chain (start-up error <= 2^-40)."""
+    G = golden("plm_rf71")
+    L, q = int(G["L"]), int(G["q"])
+    x = perturbed(oracle_plm.init_x(G["X"], G["w"], q), L, q)
+    out = {}
+    for name, mode, chunk in (("serial", L_.CARRY_SERIAL, 0), ("c128", L_.CARRY_CHUNKED, 128), ("c64", L_.CARRY_CHUNKED, 64)):
+        ctx = make_ctx(L_, G["X"], q, L_.DCA_F64, 0.8, L_.DCA_F64)
+        ctx.plm_configure(1.0, 20.0, mode, chunk, 40)
+        ctx.plm_set_x(x.astype(np.float64))
+        fx = ctx.plm_gradient()
+        out[name] = (fx, ctx.plm_get_g(np.float64))
+        ctx.close()
+    for name in ("c128", "c64"):
+        assert abs(out[name][0] - out["serial"][0]) <= 1e-12 * abs(out["serial"][0])
+        assert rel_err(out[name][1], out["serial"][1]) < 1e-12
+
+
+def test_gradient_synthetic_multi_tile(L_, oracle_plm):
+    """A shape that spans several column tiles, sequence blocks and scatter chunks
+    (L*q = 1008 -> 8 column tiles of 128; N = 1500 -> 3 logits blocks, 12 chunks)."""
+    from tools.gen_msa import dedup, generate
+    X = dedup(generate(48, 1500, 21, 99))
+    q = 21
+    w = oracle_plm.weights(X, 0.8, np.float32)
+    x = perturbed(oracle_plm.init_x(X, w, q), X.shape[1], q)
+    fx_o, g_o = oracle_plm.gradient(X, w.astype(np.float64), q, 1.0, 50.0, x.astype(np.float64), carry=True)
+    for prec, tol in ((L_.DCA_F32, 1e-5), (L_.DCA_F64, 1e-6)):
+        ctx = make_ctx(L_, X, q, prec, 0.8, L_.DCA_F32)
+        ctx.plm_configure(1.0, 50.0)
+        ctx.plm_set_x(x)
+        fx = ctx.plm_gradient()
+        g = ctx.plm_get_g(np.float64)
+        assert abs(fx - fx_o) <= tol * abs(fx_o)
+        assert rel_err(g, g_o) < tol
+        ctx.close()
+    # RNA-shaped: q = 5
+    X = dedup(generate(70, 900, 5, 98))
+    w = oracle_plm.weights(X, 0.8, np.float32)
+    x = perturbed(oracle_plm.init_x(X, w, 5), X.shape[1], 5)
+    fx_o, g_o = oracle_plm.gradient(X, w.astype(np.float64), 5, 13.8, 13.8, x.astype(np.float64), carry=True)
+    ctx = make_ctx(L_, X, 5, L_.DCA_F32, 0.8)
+    ctx.plm_configure(13.8, 13.8)
+    ctx.plm_set_x(x)
+    fx = ctx.plm_gradient()
+    assert abs(fx - fx_o) <= 1e-5 * abs(fx_o)
+    assert rel_err(ctx.plm_get_g(np.float64), g_o) < 1e-5
+    ctx.close()
+
+
+def _topL_same(a, b, L):
+    return list(np.argsort(-a, kind="stable")[:L]) == list(np.argsort(-b, kind="stable")[:L])
+
+
+@pytest.mark.parametrize("tag,iters", [("toy_rna", 60), ("toy_protein", 30), ("rf71", 40)])
+def test_lbfgs_float64_matches_oracle_at_equal_iteration_cap(L_, oracle_plm, oracle_mf, tag, iters):
+    """P3 of SURVEY 8c4 / north_star: same restated optimiser, same semantics, same cap =>
+    FN and FN_APC within 1e-4 relative and identical top-L order (float64)."""
+    G = golden("plm_" + tag)
+    L, q = int(G["L"]), int(G["q"])
+    lh, lJ = float(G["lambda_h"]), float(G["lambda_J"])
+    w64 = oracle_plm.weights(G["X"], 0.8, np.float64)
+    x0 = oracle_plm.init_x(G["X"], w64, q)
+    ref = oracle_plm.lbfgs(G["X"], w64, q, lh, lJ, iters, x0, carry=True)
+    ctx = make_ctx(L_, G["X"], q, L_.DCA_F64, 0.8, L_.DCA_F64)
+    ctx.plm_configure(lh, lJ, L_.CARRY_SERIAL)
+    ctx.plm_init_x()
+    ctx.plm_lbfgs_begin(iters)
+    st = ctx.plm_lbfgs_iterate(iters)
+    assert (st.status, st.iterations) == (ref["status"], ref["iterations"])
+    assert st.evaluations == ref["evaluations"]
+    for apc in (False, True):
+        s_gpu = ctx.plm_scores(apc)
+        s_ref = oracle_mf.plm_fn(ref["x"], L, q, apc_correct=apc)
+        np.testing.assert_allclose(s_gpu, s_ref, rtol=1e-4, atol=1e-9)
+        assert _topL_same(s_gpu, s_ref, L)
+    ctx.close()
+
+
+def test_lbfgs_float32_default_path_scores_close(L_, oracle_plm, oracle_mf):
+    """Fast mode (float32 storage, float64 reductions, chunked scan): report-level check
+    against the float64 oracle at the same cap -- expected ~1e-3 (SURVEY 8c4, P4 regime)."""
+    G = golden("plm_rf71")
+    L, q = 71, 5
+    w64 = oracle_plm.weights(G["X"], 0.8, np.float64)
+    ref = oracle_plm.lbfgs(G["X"], w64, q, 1.0, 20.0, 40, oracle_plm.init_x(G["X"], w64, q), carry=True)
+    ctx = make_ctx(L_, G["X"], q, L_.DCA_F32, 0.8)
+    ctx.plm_configure(1.0, 20.0)
+    ctx.plm_init_x()
+    ctx.plm_lbfgs_begin(40)
+    st = ctx.plm_lbfgs_iterate(40)
+    assert st.iterations == 40 and st.status == -997
+    s_gpu = ctx.plm_scores(True)
+    s_ref = oracle_mf.plm_fn(ref["x"], L, q)
+    top = np.argsort(-s_ref, kind="stable")[:L]
+    assert np.max(np.abs(s_gpu[top] - s_ref[top]) / np.abs(s_ref[top])) < 2e-2
+    assert len(set(top) & set(np.argsort(-s_gpu, kind="stable")[:L])) >= L - 3
+    ctx.close()
+
+
+def test_scores_kernel(L_, oracle_mf):
+    """FN / FN_APC kernel vs plmdca.py:437-524 restated in numpy (float64)."""
+    rng = np.random.default_rng(3)
+    for (L, q) in ((9, 5), (12, 21)):
+        X = rng.integers(0, q, size=(30, L), dtype=np.uint8)
+        ctx = make_ctx(L_, X, q, L_.DCA_F64, 0.8, L_.DCA_F64)
+        ctx.plm_configure(1.0, 1.0)
+        x = rng.standard_normal(ctx.num_params())
+        ctx.plm_set_x(x)
+        for apc in (False, True):
+            np.testing.assert_allclose(ctx.plm_scores(apc), oracle_mf.plm_fn(x, L, q, apc_correct=apc), rtol=1e-12)
+        ctx.close()
+
+
+def test_dropin_plmdcaBackend_symbol(L_, oracle_plm, oracle_mf):
+    """The reference's own FFI (plmdcaBackend.cpp:151-156), bound as plmdca.py:79-89 does."""
+    G = golden("plm_toy_rna")
+    L, q = int(G["L"]), int(G["q"])
+    P = oracle_plm.num_params(L, q)
+    lib = L_.lib()
+    ptr = lib.plmdcaBackend(2, q, os.fsencode(data_file("toy_rna.fa")), L, 0.8, 1.8, 1.8, 100, 1, False)
+    assert ptr, lib.dca_last_error()
+    x = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(P,)).copy()
+    lib.freeFieldsAndCouplings(ptr)
+    fn_ref = oracle_mf.plm_fn(G["run_a"], L, q)
+    fn_our = oracle_mf.plm_fn(x, L, q)
+    assert rel_err(fn_our, fn_ref) < 2e-2
+    # error path: NULL + message instead of a C++ exception across the boundary
+    assert not lib.plmdcaBackend(2, q, b"/nonexistent.fa", L, 0.8, 1.0, 1.0, 5, 1, False)
+    assert b"Unable to open" in lib.dca_last_error()
+
+
+# ----------------------------------------------------------------------------- mfDCA
+def _mf_ctx(L_, X1, q, seqid):
+    ctx = L_.Context(0, L_.DCA_F64)
+    ctx.set_msa((X1 - 1).astype(np.uint8), q)
+    if seqid < 1.0:
+        ctx.compute_weights(seqid, L_.DCA_F64)
+    else:
+        ctx.set_weights(np.ones(X1.shape[0]))
+    return ctx
+
+
+@pytest.mark.parametrize("tag", ["toy_rna", "toy_protein", "toy_rna_theta02_seqid1"])
+def test_mf_stages_vs_reference(L_, tag):
+    G = golden("mf_" + tag)
+    X1, q = G["X"], int(G["q"])
+    theta, seqid = float(G["pseudocount"]), float(G["seqid"])
+    ctx = _mf_ctx(L_, X1, q, seqid)
+    np.testing.assert_array_equal(ctx.weights(), G["w"])
+    np.testing.assert_allclose(ctx.mf_single_site_freqs(), G["fi"], rtol=1e-13, atol=1e-16)
+    np.testing.assert_allclose(ctx.mf_pair_site_freqs(), G["fij"], rtol=1e-12, atol=1e-16)
+    np.testing.assert_allclose(ctx.mf_corr_mat(theta), G["corr_mat"], rtol=1e-11, atol=1e-15)
+    np.testing.assert_allclose(ctx.mf_couplings(), G["couplings"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(ctx.mf_corr_from_freqs(G["reg_fi"], G["reg_fij"], X1.shape[1], q), G["corr_mat"],
+                               rtol=1e-13, atol=1e-16)
+    ctx.close()
+
+
+@pytest.mark.parametrize("tag", ["toy_rna", "toy_protein", "toy_rna_theta02_seqid1", "rf71", "rf00167"])
+def test_mf_scores_and_full_ranking_vs_reference(L_, oracle_mf, tag):
+    """mfdca compute_fn: FN and FN_APC <= 1e-9 relative, identical full ranking
+    (SURVEY 8c5); rf71 also covers the notebook's published top-5."""
+    G = golden("mf_" + tag)
+    X1, q = G["X"], int(G["q"])
+    L = X1.shape[1]
+    ctx = _mf_ctx(L_, X1, q, float(G["seqid"]))
+    for apc, pk, sk in ((False, "fn_pairs", "fn_scores"), (True, "apc_pairs", "apc_scores")):
+        scores = ctx.mf_run(float(G["pseudocount"]), apc)
+        ranked = oracle_mf.sort_scores(scores, L)
+        assert [p for p, _ in ranked] == [tuple(p) for p in G[pk]]
+        np.testing.assert_allclose([s for _, s in ranked], G[sk], rtol=1e-9)
+    ctx.close()
+
+
+def test_mf_singular_matrix_is_an_error(L_):
+    """pseudocount 0 on a tiny alignment: not positive definite -> error code, no crash
+    (reference: LinAlgError path, meanfield_dca.py:542-548)."""
+    X = np.zeros((4, 6), dtype=np.uint8)
+    ctx = L_.Context(0, L_.DCA_F64)
+    ctx.set_msa(X, 5)
+    ctx.set_weights(np.ones(4))
+    with pytest.raises(L_.DcaBackendError) as ei:
+        ctx.mf_run(0.0, True)
+    assert ei.value.code == L_.DCA_ERR_NOT_SPD
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [1, 64, 100, 200, 500])
+def test_spd_inverse_f64_mfma(L_, n):
+    """Blocked Cholesky inverse on v_mfma_f64_16x16x4_f64 vs LAPACK; asymmetric-looking
+    test matrices (random SPD, no special structure)."""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n + 8))
+    A = B @ B.T / n + 0.5 * np.diag(rng.random(n) + 0.5)
+    ctx = L_.Context(0, L_.DCA_F64)
+    inv = ctx.spd_inverse(A)
+    ref = np.linalg.inv(A)
+    assert rel_err(inv, ref) < 1e-11
+    assert np.array_equal(inv, inv.T)
+    ctx.close()
