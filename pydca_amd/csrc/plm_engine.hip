@@ -1099,7 +1099,9 @@ struct PlmEngine : PlmEngineBase {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
         int rc = dca_fn_scores(ctx, dx, 0, (int)sizeof(T) * 8, L, q, 0, apc, dOut);
         if (rc == DCA_OK) {
-            hipError_t e = hipMemcpy(out, dOut, npairs * sizeof(double), hipMemcpyDeviceToHost);
+            // ctx->stream is non-blocking: the null-stream copy below does not wait for it
+            hipError_t e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = hipMemcpy(out, dOut, npairs * sizeof(double), hipMemcpyDeviceToHost);
             if (e != hipSuccess) { dca_set_error("copy scores: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
         }
         hipFree(dOut);

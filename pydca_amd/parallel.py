@@ -1,0 +1,129 @@
+"""Sequence sharding of the plmDCA evaluation across GPUs (one process per GPU).
+
+The de-duplicated, file-ordered sequences are cut into `world` contiguous blocks.  Each
+rank holds its block plus a halo of the `warmup` preceding sequences, which only warm up
+the carry-over scan (see csrc/plm_engine.hip, plm_softmax_kernel) and do not contribute
+to fx or g.  x is replicated; every evaluation ends with ONE exchange step: an
+all-reduce(sum) of the P gradient entries and of fx over RCCL/xGMI, issued through
+torch.distributed from the library's reduce hook.  The regulariser is added on rank 0
+only.  Weights depend on the whole alignment, so they are computed once on the full MSA
+(it is tens of MB) and the shard's slice is handed to the shard context.
+
+No reference counterpart: pydca is single-process.
+"""
+import ctypes as C
+
+import numpy as np
+
+
+def shard_bounds(n_seqs, world, rank):
+    """Contiguous, balanced [start, stop) of rank's owned sequences."""
+    base, rem = divmod(n_seqs, world)
+    start = rank * base + min(rank, rem)
+    stop = start + base + (1 if rank < rem else 0)
+    return start, stop
+
+
+def shard_with_halo(n_seqs, world, rank, warmup):
+    """-> (first_row, stop_row, halo): rows [first_row, stop_row) go to the rank, the
+    leading `halo` of them are warm-up only."""
+    start, stop = shard_bounds(n_seqs, world, rank)
+    halo = min(warmup, start)
+    return start - halo, stop, halo
+
+
+_hip = None
+
+
+def _hip_rt():
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipMemcpy.restype = C.c_int
+    return _hip
+
+
+_D2D = 3  # hipMemcpyDeviceToDevice
+
+
+class TorchAllReduceHook:
+    """Reduce hook for `Context.plm_set_reduce_hook`: sums g and fx over the process group.
+
+    The library hands over raw device pointers; they are staged through torch tensors
+    (two device-to-device copies of P elements, negligible next to the evaluation) so that
+    torch.distributed (backend "nccl" = RCCL on ROCm) can run the collective.
+    """
+
+    def __init__(self, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.device = torch.device("cuda", device)
+        self.gbuf = None
+        self.fbuf = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.calls = 0
+        self.seconds = 0.0
+
+    def __call__(self, g_dev, count, dtype, fx_dev):
+        import time
+        torch, dist = self.torch, self.dist
+        t0 = time.perf_counter()
+        tdt = torch.float32 if dtype == 32 else torch.float64
+        if self.gbuf is None or self.gbuf.numel() != count or self.gbuf.dtype != tdt:
+            self.gbuf = torch.empty(count, dtype=tdt, device=self.device)
+        hip = _hip_rt()
+        nbytes = count * (4 if dtype == 32 else 8)
+        if hip.hipMemcpy(self.gbuf.data_ptr(), g_dev, nbytes, _D2D) != 0:
+            return 1
+        if hip.hipMemcpy(self.fbuf.data_ptr(), fx_dev, 8, _D2D) != 0:
+            return 1
+        dist.all_reduce(self.gbuf, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(self.fbuf, op=dist.ReduceOp.SUM, group=self.group)
+        torch.cuda.synchronize(self.device)
+        if hip.hipMemcpy(g_dev, self.gbuf.data_ptr(), nbytes, _D2D) != 0:
+            return 1
+        if hip.hipMemcpy(fx_dev, self.fbuf.data_ptr(), 8, _D2D) != 0:
+            return 1
+        self.calls += 1
+        self.seconds += time.perf_counter() - t0
+        return 0
+
+
+def make_sharded_plm_context(lib_mod, X, q, weights, lambda_h, lambda_J, rank, world, device,
+                             precision=32, carry_mode=1, chunk=0, warmup=40):
+    """Build the rank's shard context (alignment slice + halo, sliced weights, hook unset)."""
+    N = X.shape[0]
+    first, stop, halo = shard_with_halo(N, world, rank, warmup if carry_mode != 0 else 0)
+    ctx = lib_mod.Context(device, precision)
+    ctx.set_msa(np.ascontiguousarray(X[first:stop]), q)
+    ctx.set_weights(np.ascontiguousarray(weights[first:stop], dtype=np.float64))
+    ctx.plm_configure(lambda_h, lambda_J, carry_mode, chunk, warmup, halo, 1 if rank == 0 else 0)
+    return ctx
+
+
+def initial_x(X, weights, q, dtype=np.float32):
+    """PlmDCA::initFieldsAndCouplings (plmdca_numerics.cpp:207-249) on the FULL alignment,
+    host side, in `dtype` arithmetic and the reference's accumulation order (ascending n).
+    Used by sharded runs, where no single context sees every sequence."""
+    X = np.asarray(X)
+    N, L = X.shape
+    w = np.asarray(weights).astype(dtype)
+    meff = dtype(0)
+    for n in range(N):
+        meff = dtype(meff + w[n])
+    h = np.zeros((L, q), dtype=dtype)
+    cols = np.arange(L)
+    for n in range(N):
+        h[cols, X[n]] += w[n]
+    h = (h / meff).astype(dtype)
+    h = np.log((h * meff + dtype(1)).astype(dtype)).astype(dtype)
+    for i in range(L):
+        s = dtype(0)
+        for a in range(q):
+            s = dtype(s + h[i, a])
+        h[i] -= dtype(s / dtype(q))
+    P = L * q + L * (L - 1) // 2 * q * q
+    x = np.zeros(P, dtype=dtype)
+    x[:L * q] = h.reshape(-1)
+    return x
