@@ -211,14 +211,18 @@ void plm_softmax_kernel(T* __restrict__ SR, const T* __restrict__ x, const uint8
 // For every chunk of NC owned sequences and every site j: the chunk-local rows grouped
 // by state x_nj (counting sort, ascending n inside a group), stored as LDS byte offsets
 // (row * 512).  Groups are padded to a multiple of 4 with the offset of an all-zero row
-// so that the scatter kernel's inner loop needs no remainder handling.
+// so that the scatter kernel's inner loop needs no remainder handling.  The group of the
+// site's most frequent state is left empty: its sum is recovered as (column sum of R) -
+// (sum of the other groups), which removes the largest group -- typically about half of
+// the entries -- from the gather.
 constexpr int kNC = 128;           // sequences per scatter chunk
 constexpr int kRowBytes = 512;     // bytes of one staged row (64 lanes x 8 B)
 
 __host__ __device__ constexpr int list_len(int q) { return (kNC + 3 * q + 3) / 4 * 4; }
 
-__global__ void plm_build_lists_kernel(const uint8_t* __restrict__ X, uint32_t* __restrict__ lists,
-                                       int* __restrict__ offs, int N, int L, int Ls, int q, int halo, int numChunks)
+__global__ void plm_build_lists_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ dom,
+                                       uint32_t* __restrict__ lists, int* __restrict__ offs, int N, int L, int Ls,
+                                       int q, int halo, int numChunks)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= numChunks * L) return;
@@ -227,9 +231,10 @@ __global__ void plm_build_lists_kernel(const uint8_t* __restrict__ X, uint32_t* 
     const int n0 = halo + c * kNC;
     int cnt[32], pos[32];
     for (int b = 0; b < q; ++b) cnt[b] = 0;
+    const int skip = dom[j];   // rows in the site's dominant state are not listed (complement trick)
     for (int r = 0; r < kNC; ++r) {
         const int n = n0 + r;
-        if (n < N) cnt[X[(size_t)n * Ls + j]]++;
+        if (n < N) { const int b = X[(size_t)n * Ls + j]; if (b != skip) cnt[b]++; }
     }
     int* of = offs + (size_t)t * (q + 1);
     int run = 0;
@@ -239,24 +244,38 @@ __global__ void plm_build_lists_kernel(const uint8_t* __restrict__ X, uint32_t* 
     for (int k = 0; k < LP; ++k) lst[k] = kNC * kRowBytes;   // zero row
     for (int r = 0; r < kNC; ++r) {
         const int n = n0 + r;
-        if (n < N) { const int b = X[(size_t)n * Ls + j]; lst[pos[b]++] = r * kRowBytes; }
+        if (n < N) { const int b = X[(size_t)n * Ls + j]; if (b != skip) lst[pos[b]++] = r * kRowBytes; }
     }
 }
 
 // ------------------------------------------------------------------ scatter (as a gather)
 // G[(j,b)][c] = sum_{n : x_nj = b} R[n][c].  Lanes = columns (8 bytes per lane), the
 // q running sums of a site sit in registers because the groups are visited in state
-// order with a compile-time unrolled loop over b; the rows of R come from an LDS tile
-// through wave-uniform offsets (scalar loads of the sorted lists).
+// order with a compile-time unrolled loop over b; the rows of R come from an LDS tile.
+// The sorted list of a (chunk, site) is fetched with coalesced vector loads before the
+// staging barrier (lane l holds entries l, 64+l, 128+l) and its entries are broadcast
+// with v_readlane, so the inner loop touches no memory but LDS:
+// readlane -> address add -> ds_read_b64 -> add, four entries per trip.
+// 16-wave workgroups, JW sites per wave, <= 64 VGPRs => two workgroups (32 waves) per CU:
+// the kernel is bound by per-wave issue latency, so resident waves are what matters.
+// The dominant state's group of every site is not gathered (see plm_build_lists_kernel);
+// each wave also sums an 8-row slice of every tile, the slices combine to the column sum
+// at the end, and G[(j,dom)] = colsum - sum of the other groups.
 template <typename T, int Q, int JW, int WAVES>
-__global__ __launch_bounds__(WAVES * 64)
+__global__ __launch_bounds__(WAVES * 64, WAVES / 2)
 void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ lists, const int* __restrict__ offs,
-                        T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int numColTiles, int numJG)
+                        const uint8_t* __restrict__ dom, T* __restrict__ G,
+                        int N, int L, int Cs, int halo, int numChunks, int numColTiles, int numJG,
+                        int chunksPerSplit, size_t slabElems)
 {
     constexpr int EPL = 8 / sizeof(T);     // elements per lane
     constexpr int CW = 64 * EPL;           // columns per tile
     constexpr int JG = WAVES * JW;         // sites per workgroup
     constexpr int LP = list_len(Q);
+    constexpr int NB = (LP + 63) / 64;     // 64-entry list blocks per (chunk, site)
+    constexpr int SLICE = kNC / WAVES;     // tile rows each wave adds to the column sum
+    static_assert(NB <= 3, "list longer than three lane blocks");
+    static_assert(kNC % WAVES == 0, "tile rows must divide over the waves");
     struct alignas(8) Acc { T v[EPL]; };
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
 
@@ -272,6 +291,9 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ li
     const int jbase = jg * JG + wave * JW;
 
     Acc acc[JW][Q];
+    Acc colsum;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) colsum.v[e] = 0;
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj)
 #pragma unroll
@@ -282,8 +304,29 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ li
     for (int t = tid; t < kRowBytes / 4; t += WAVES * 64)
         reinterpret_cast<uint32_t*>(dca_smem + kNC * kRowBytes)[t] = 0u;
 
+    // blockIdx.y splits the chunk range; every split writes its own slab of G (summed by
+    // plm_sum_slabs_kernel in a fixed order), so small L*q shapes still fill the chip.
+    const int cBegin = blockIdx.y * chunksPerSplit;
+    const int cEnd = min(numChunks, cBegin + chunksPerSplit);
+    G += (size_t)blockIdx.y * slabElems;
+
     const unsigned char* laneBase = dca_smem + lane * 8;
-    for (int c = 0; c < numChunks; ++c) {
+    for (int c = cBegin; c < cEnd; ++c) {
+        // this wave's sorted lists and group offsets for the chunk (in flight across the barrier).
+        // Separate statically indexed arrays per field: an aggregate lets the compiler turn the
+        // block select below into a scratch lookup.
+        uint32_t la[JW], lb[JW], lc[JW];
+        int lo[JW];
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) {
+            const int jc = min(jbase + jj, L - 1);
+            const uint32_t* lst = lists + ((size_t)c * L + jc) * LP;
+            const uint32_t zrow = (uint32_t)(kNC * kRowBytes);
+            la[jj] = (lane < LP) ? lst[lane] : zrow;
+            lb[jj] = (NB > 1 && 64 + lane < LP) ? lst[64 + lane] : zrow;
+            lc[jj] = (NB > 2 && 128 + lane < LP) ? lst[128 + lane] : zrow;
+            lo[jj] = (lane <= Q) ? offs[((size_t)c * L + jc) * (Q + 1) + lane] : 0;
+        }
         __syncthreads();
         const int n0 = halo + c * kNC;
         for (int v = tid; v < kNC * (kRowBytes / 16); v += WAVES * 64) {
@@ -295,40 +338,85 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ li
             *reinterpret_cast<uint4*>(dca_smem + r * kRowBytes + cv * 16) = val;
         }
         __syncthreads();
+        // column-sum slice of this wave
+#pragma unroll
+        for (int r = 0; r < SLICE; ++r) {
+            const Acc v = *reinterpret_cast<const Acc*>(laneBase + (wave * SLICE + r) * kRowBytes);
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) colsum.v[u] += v.v[u];
+        }
 #pragma unroll
         for (int jj = 0; jj < JW; ++jj) {
-            const int j = jbase + jj;
-            if (j < L) {
-                const uint32_t* lst = lists + ((size_t)c * L + j) * LP;
-                const int* of = offs + ((size_t)c * L + j) * (Q + 1);
+            if (jbase + jj < L) {
 #pragma unroll
                 for (int b = 0; b < Q; ++b) {
-                    const int k0 = of[b], k1 = of[b + 1];
-                    for (int kk = k0; kk < k1; kk += 4) {
-                        const uint4 e = *reinterpret_cast<const uint4*>(lst + kk);
-                        const Acc v0 = *reinterpret_cast<const Acc*>(laneBase + e.x);
-                        const Acc v1 = *reinterpret_cast<const Acc*>(laneBase + e.y);
-                        const Acc v2 = *reinterpret_cast<const Acc*>(laneBase + e.z);
-                        const Acc v3 = *reinterpret_cast<const Acc*>(laneBase + e.w);
+                    int k0 = __builtin_amdgcn_readlane(lo[jj], b);
+                    const int k1 = __builtin_amdgcn_readlane(lo[jj], b + 1);
+                    while (k0 < k1) {
+                        const int blk = k0 >> 6;
+                        const int segEnd = min(k1, (blk + 1) << 6);
+                        uint32_t vsel = la[jj];
+                        if (blk == 1) vsel = lb[jj];
+                        if (blk == 2) vsel = lc[jj];
+                        for (; k0 < segEnd; k0 += 4) {
+                            const int t = k0 & 63;
+                            const Acc v0 = *reinterpret_cast<const Acc*>(laneBase + __builtin_amdgcn_readlane(vsel, t));
+                            const Acc v1 = *reinterpret_cast<const Acc*>(laneBase + __builtin_amdgcn_readlane(vsel, t + 1));
+                            const Acc v2 = *reinterpret_cast<const Acc*>(laneBase + __builtin_amdgcn_readlane(vsel, t + 2));
+                            const Acc v3 = *reinterpret_cast<const Acc*>(laneBase + __builtin_amdgcn_readlane(vsel, t + 3));
 #pragma unroll
-                        for (int u = 0; u < EPL; ++u) {
-                            T a = acc[jj][b].v[u];
-                            a += v0.v[u]; a += v1.v[u]; a += v2.v[u]; a += v3.v[u];
-                            acc[jj][b].v[u] = a;
+                            for (int u = 0; u < EPL; ++u) {
+                                T a = acc[jj][b].v[u];
+                                a += v0.v[u]; a += v1.v[u]; a += v2.v[u]; a += v3.v[u];
+                                acc[jj][b].v[u] = a;
+                            }
                         }
                     }
                 }
             }
         }
     }
+
+    // total column sum of the tile = sum of the waves' slices (fixed order)
+    __syncthreads();
+    *reinterpret_cast<Acc*>(dca_smem + wave * kRowBytes + lane * 8) = colsum;
+    __syncthreads();
+    Acc total;
+#pragma unroll
+    for (int u = 0; u < EPL; ++u) total.v[u] = 0;
+    for (int w = 0; w < WAVES; ++w) {
+        const Acc v = *reinterpret_cast<const Acc*>(laneBase + w * kRowBytes);
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) total.v[u] += v.v[u];
+    }
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj) {
         const int j = jbase + jj;
         if (j < L) {
+            const int dj = dom[j];
+            Acc rest = total;   // becomes colsum - sum of the listed groups = the dominant group
 #pragma unroll
             for (int b = 0; b < Q; ++b)
-                *reinterpret_cast<Acc*>(reinterpret_cast<unsigned char*>(G + (size_t)(j * Q + b) * Cs + (size_t)ct * CW) + lane * 8) = acc[jj][b];
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) rest.v[u] -= acc[jj][b].v[u];
+#pragma unroll
+            for (int b = 0; b < Q; ++b) {
+                Acc out = acc[jj][b];
+                if (b == dj) out = rest;
+                *reinterpret_cast<Acc*>(reinterpret_cast<unsigned char*>(G + (size_t)(j * Q + b) * Cs + (size_t)ct * CW) + lane * 8) = out;
+            }
         }
+    }
+}
+
+// G[0] += G[1] + ... + G[nsplit-1], fixed order (deterministic)
+template <typename T>
+__global__ void plm_sum_slabs_kernel(T* __restrict__ G, size_t slabElems, int nsplit)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < slabElems; i += (size_t)gridDim.x * blockDim.x) {
+        T a = G[i];
+        for (int sidx = 1; sidx < nsplit; ++sidx) a += G[(size_t)sidx * slabElems + i];
+        G[i] = a;
     }
 }
 
@@ -632,13 +720,15 @@ struct PlmEngine : PlmEngineBase {
     bool configured = false;
     int numScanChunks = 0, numScatChunks = 0;
     static constexpr int kLogitWaves = 8;
-    static constexpr int kScatWaves = 8;
+    static constexpr int kScatWaves = 16;
+    int scatSplit = 1, scatChunksPerSplit = 0;
 
     T *dx = nullptr, *dg = nullptr, *dxp = nullptr, *dgp = nullptr, *dd = nullptr;
     T* dS[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     T* dY[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     T *dWt = nullptr, *dSR = nullptr, *dG = nullptr, *dw = nullptr;
     uint32_t *dX4 = nullptr, *dLists = nullptr;
+    uint8_t* dDom = nullptr;
     int* dOffs = nullptr;
     PairIJ* dPairs = nullptr;
     double *dFxPart = nullptr, *dRegPart = nullptr, *dVecPart = nullptr;
@@ -665,12 +755,12 @@ struct PlmEngine : PlmEngineBase {
         hipFree(dx); hipFree(dg); hipFree(dxp); hipFree(dgp); hipFree(dd);
         for (int i = 0; i < 5; ++i) { hipFree(dS[i]); hipFree(dY[i]); }
         hipFree(dWt); hipFree(dSR); hipFree(dG); hipFree(dw); hipFree(dX4); hipFree(dLists); hipFree(dOffs);
-        hipFree(dPairs); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
+        hipFree(dPairs); hipFree(dDom); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
     }
     ~PlmEngine() override { freeall(); }
 
     int jt() const { return q <= 8 ? 32 : 8; }
-    int jw() const { return q <= 8 ? 8 : 2; }
+    int jw() const { return q <= 8 ? 2 : 1; }
 
     int configure(double lh, double lJ, int cmode, int chunk_, int warm_, int halo_, int add_reg_) override
     {
@@ -689,7 +779,7 @@ struct PlmEngine : PlmEngineBase {
         freeall();
         dx = dg = dxp = dgp = dd = nullptr;
         for (int i = 0; i < 5; ++i) dS[i] = dY[i] = nullptr;
-        dWt = dSR = dG = dw = nullptr; dX4 = dLists = nullptr; dOffs = nullptr; dPairs = nullptr;
+        dWt = dSR = dG = dw = nullptr; dX4 = dLists = nullptr; dDom = nullptr; dOffs = nullptr; dPairs = nullptr;
         dFxPart = dRegPart = dVecPart = nullptr;
         lbfgs_alloc = false;
         o = decltype(o)();
@@ -707,7 +797,16 @@ struct PlmEngine : PlmEngineBase {
         DCA_TRY(dalloc(&dx, P)); DCA_TRY(dalloc(&dg, P));
         DCA_TRY(dalloc(&dWt, (size_t)Wrows * Cs));
         DCA_TRY(dalloc(&dSR, (size_t)N * Cs));
-        DCA_TRY(dalloc(&dG, (size_t)Grows * Cs));
+        {
+            // split the chunk range until the scatter grid has ~2048 workgroups
+            const int cw = 64 * (8 / (int)sizeof(T));
+            const int wgs = kNumXcd * ceil_div(Cs / cw, kNumXcd) * ceil_div(L, JG);
+            scatSplit = std::max(1, std::min(numScatChunks, ceil_div(2048, wgs)));
+            scatChunksPerSplit = ceil_div(numScatChunks, scatSplit);
+            scatSplit = ceil_div(numScatChunks, scatChunksPerSplit);
+        }
+        DCA_TRY(dalloc(&dG, (size_t)scatSplit * Grows * Cs));
+        DCA_TRY(dalloc(&dDom, L));
         DCA_TRY(dalloc(&dw, N));
         DCA_TRY(dalloc(&dX4, (size_t)Ls4 * Npad));
         DCA_TRY(dalloc(&dLists, (size_t)numScatChunks * L * list_len(q)));
@@ -723,7 +822,7 @@ struct PlmEngine : PlmEngineBase {
         HIP_TRY(hipMemsetAsync(dx, 0, P * sizeof(T), ctx->stream));
         HIP_TRY(hipMemsetAsync(dg, 0, P * sizeof(T), ctx->stream));
         HIP_TRY(hipMemsetAsync(dWt, 0, (size_t)Wrows * Cs * sizeof(T), ctx->stream));
-        HIP_TRY(hipMemsetAsync(dG, 0, (size_t)Grows * Cs * sizeof(T), ctx->stream));
+        HIP_TRY(hipMemsetAsync(dG, 0, (size_t)scatSplit * Grows * Cs * sizeof(T), ctx->stream));
 
         std::vector<PairIJ> hp(npairs);
         {
@@ -731,6 +830,20 @@ struct PlmEngine : PlmEngineBase {
             for (int i = 0; i < L - 1; ++i) for (int j = i + 1; j < L; ++j) hp[k++] = PairIJ{(uint16_t)i, (uint16_t)j};
         }
         HIP_TRY(hipMemcpyAsync(dPairs, hp.data(), npairs * sizeof(PairIJ), hipMemcpyHostToDevice, ctx->stream));
+        // most frequent state of every site among the owned sequences (ties -> lowest code)
+        std::vector<uint8_t> hdom(L);
+        {
+            std::vector<int> cnt((size_t)L * q, 0);
+            const uint8_t* X = ctx->hX.data();
+            for (int n = halo; n < N; ++n)
+                for (int i = 0; i < L; ++i) cnt[(size_t)i * q + X[(size_t)n * L + i]]++;
+            for (int i = 0; i < L; ++i) {
+                int best = 0;
+                for (int a = 1; a < q; ++a) if (cnt[(size_t)i * q + a] > cnt[(size_t)i * q + best]) best = a;
+                hdom[i] = (uint8_t)best;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(dDom, hdom.data(), L, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
 
         // weights in T.  1/count is formed in T exactly as the reference does
@@ -754,7 +867,7 @@ struct PlmEngine : PlmEngineBase {
             hipLaunchKernelGGL(pack_x4_kernel, grid, dim3(256), 0, ctx->stream, ctx->dX, dX4, N, Npad, Ls, Ls4);
             const int nt = numScatChunks * L;
             hipLaunchKernelGGL(plm_build_lists_kernel, dim3(ceil_div(nt, 128)), dim3(128), 0, ctx->stream,
-                               ctx->dX, dLists, dOffs, N, L, Ls, q, halo, numScatChunks);
+                               ctx->dX, dDom, dLists, dOffs, N, L, Ls, q, halo, numScatChunks);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
@@ -857,7 +970,7 @@ struct PlmEngine : PlmEngineBase {
                                N, L, Ls, Cs, halo, chunk, warm, carry_mode != DCA_CARRY_EXACT ? 1 : 0, numScanChunks);
         }
         {
-            constexpr int JW = (Q <= 8) ? 8 : 2;
+            constexpr int JW = (Q <= 8) ? 2 : 1;
             constexpr int W = kScatWaves;
             constexpr int CW = 64 * (8 / (int)sizeof(T));
             const int numCT = Cs / CW;
@@ -867,8 +980,10 @@ struct PlmEngine : PlmEngineBase {
             auto kern = plm_scatter_kernel<T, Q, JW, W>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ScopedKernelClock kc(ctx, "plm_scatter");
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(W * 64), lds, st, dSR, dLists, dOffs, dG, N, L, Cs, halo,
-                               numScatChunks, numCT, numJG);
+            hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(W * 64), lds, st, dSR, dLists, dOffs, dDom, dG, N, L, Cs, halo,
+                               numScatChunks, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
+            if (scatSplit > 1)
+                hipLaunchKernelGGL(plm_sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, st, dG, (size_t)Grows * Cs, scatSplit);
         }
         {
             ScopedKernelClock kc(ctx, "plm_fold");
