@@ -264,9 +264,9 @@ __global__ void plm_build_lists_kernel(const uint8_t* __restrict__ X, const uint
 template <typename T, int Q, int JW, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 2)
 void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ lists, const int* __restrict__ offs,
-                        const uint8_t* __restrict__ dom, T* __restrict__ G,
+                        const uint8_t* __restrict__ dom, const unsigned char* __restrict__ zeros, T* __restrict__ G,
                         int N, int L, int Cs, int halo, int numChunks, int numColTiles, int numJG,
-                        int chunksPerSplit, size_t slabElems)
+                        int chunksPerSplit, size_t slabElems, int ablate)
 {
     constexpr int EPL = 8 / sizeof(T);     // elements per lane
     constexpr int CW = 64 * EPL;           // columns per tile
@@ -274,6 +274,7 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ li
     constexpr int LP = list_len(Q);
     constexpr int NB = (LP + 63) / 64;     // 64-entry list blocks per (chunk, site)
     constexpr int SLICE = kNC / WAVES;     // tile rows each wave adds to the column sum
+    constexpr int DMA_PER_WAVE = kNC / 2 / WAVES;   // LDS-DMA instructions per wave and tile
     static_assert(NB <= 3, "list longer than three lane blocks");
     static_assert(kNC % WAVES == 0, "tile rows must divide over the waves");
     struct alignas(8) Acc { T v[EPL]; };
@@ -311,6 +312,8 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ li
     G += (size_t)blockIdx.y * slabElems;
 
     const unsigned char* laneBase = dca_smem + lane * 8;
+    const unsigned char* Rtile = reinterpret_cast<const unsigned char*>(R + (size_t)ct * CW) + (lane & 31) * 16;
+    const size_t rowStrideBytes = (size_t)Cs * sizeof(T);
     for (int c = cBegin; c < cEnd; ++c) {
         // this wave's sorted lists and group offsets for the chunk (in flight across the barrier).
         // Separate statically indexed arrays per field: an aggregate lets the compiler turn the
@@ -322,32 +325,39 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ li
             const int jc = min(jbase + jj, L - 1);
             const uint32_t* lst = lists + ((size_t)c * L + jc) * LP;
             const uint32_t zrow = (uint32_t)(kNC * kRowBytes);
-            la[jj] = (lane < LP) ? lst[lane] : zrow;
-            lb[jj] = (NB > 1 && 64 + lane < LP) ? lst[64 + lane] : zrow;
-            lc[jj] = (NB > 2 && 128 + lane < LP) ? lst[128 + lane] : zrow;
-            lo[jj] = (lane <= Q) ? offs[((size_t)c * L + jc) * (Q + 1) + lane] : 0;
+            la[jj] = (lane < LP && !(ablate & 4)) ? lst[lane] : zrow;
+            lb[jj] = (NB > 1 && 64 + lane < LP && !(ablate & 4)) ? lst[64 + lane] : zrow;
+            lc[jj] = (NB > 2 && 128 + lane < LP && !(ablate & 4)) ? lst[128 + lane] : zrow;
+            lo[jj] = (lane <= Q && !(ablate & 4)) ? offs[((size_t)c * L + jc) * (Q + 1) + lane] : 0;
         }
-        __syncthreads();
-        const int n0 = halo + c * kNC;
-        for (int v = tid; v < kNC * (kRowBytes / 16); v += WAVES * 64) {
-            const int r = v / (kRowBytes / 16), cv = v % (kRowBytes / 16);
-            const int n = n0 + r;
-            uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if (n < N)
-                val = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(R + (size_t)n * Cs + (size_t)ct * CW) + cv * 16);
-            *reinterpret_cast<uint4*>(dca_smem + r * kRowBytes + cv * 16) = val;
+        __syncthreads();   // every wave is done with the previous tile
+        // stage the tile by LDS-DMA (global_load_lds_dwordx4: 1 KiB = two 512-byte rows per wave
+        // instruction, no staging VGPRs -- the kernel runs at the 64-VGPR budget, where register
+        // staging spills).  Rows past N come from a zero row in global memory.
+        {
+            const int n0 = halo + c * kNC;
+#pragma unroll
+            for (int i = 0; i < DMA_PER_WAVE && !(ablate & 8); ++i) {
+                const int pairIdx = wave * DMA_PER_WAVE + i;              // wave-uniform
+                const int n = n0 + pairIdx * 2 + (lane >> 5);
+                const unsigned char* g = (n < N) ? Rtile + (size_t)n * rowStrideBytes : zeros + (lane & 31) * 16;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)g,
+                    (__attribute__((address_space(3))) void*)(dca_smem + pairIdx * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         // column-sum slice of this wave
 #pragma unroll
-        for (int r = 0; r < SLICE; ++r) {
+        for (int r = 0; r < SLICE && !(ablate & 16); ++r) {
             const Acc v = *reinterpret_cast<const Acc*>(laneBase + (wave * SLICE + r) * kRowBytes);
 #pragma unroll
             for (int u = 0; u < EPL; ++u) colsum.v[u] += v.v[u];
         }
 #pragma unroll
         for (int jj = 0; jj < JW; ++jj) {
-            if (jbase + jj < L) {
+            if (jbase + jj < L && !(ablate & 2)) {
 #pragma unroll
                 for (int b = 0; b < Q; ++b) {
                     int k0 = __builtin_amdgcn_readlane(lo[jj], b);
@@ -729,6 +739,7 @@ struct PlmEngine : PlmEngineBase {
     T *dWt = nullptr, *dSR = nullptr, *dG = nullptr, *dw = nullptr;
     uint32_t *dX4 = nullptr, *dLists = nullptr;
     uint8_t* dDom = nullptr;
+    unsigned char* dZeros = nullptr;
     int* dOffs = nullptr;
     PairIJ* dPairs = nullptr;
     double *dFxPart = nullptr, *dRegPart = nullptr, *dVecPart = nullptr;
@@ -755,7 +766,7 @@ struct PlmEngine : PlmEngineBase {
         hipFree(dx); hipFree(dg); hipFree(dxp); hipFree(dgp); hipFree(dd);
         for (int i = 0; i < 5; ++i) { hipFree(dS[i]); hipFree(dY[i]); }
         hipFree(dWt); hipFree(dSR); hipFree(dG); hipFree(dw); hipFree(dX4); hipFree(dLists); hipFree(dOffs);
-        hipFree(dPairs); hipFree(dDom); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
+        hipFree(dPairs); hipFree(dDom); hipFree(dZeros); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
     }
     ~PlmEngine() override { freeall(); }
 
@@ -779,7 +790,7 @@ struct PlmEngine : PlmEngineBase {
         freeall();
         dx = dg = dxp = dgp = dd = nullptr;
         for (int i = 0; i < 5; ++i) dS[i] = dY[i] = nullptr;
-        dWt = dSR = dG = dw = nullptr; dX4 = dLists = nullptr; dDom = nullptr; dOffs = nullptr; dPairs = nullptr;
+        dWt = dSR = dG = dw = nullptr; dX4 = dLists = nullptr; dDom = nullptr; dZeros = nullptr; dOffs = nullptr; dPairs = nullptr;
         dFxPart = dRegPart = dVecPart = nullptr;
         lbfgs_alloc = false;
         o = decltype(o)();
@@ -807,6 +818,8 @@ struct PlmEngine : PlmEngineBase {
         }
         DCA_TRY(dalloc(&dG, (size_t)scatSplit * Grows * Cs));
         DCA_TRY(dalloc(&dDom, L));
+        DCA_TRY(dalloc(&dZeros, kRowBytes));
+        HIP_TRY(hipMemsetAsync(dZeros, 0, kRowBytes, ctx->stream));
         DCA_TRY(dalloc(&dw, N));
         DCA_TRY(dalloc(&dX4, (size_t)Ls4 * Npad));
         DCA_TRY(dalloc(&dLists, (size_t)numScatChunks * L * list_len(q)));
@@ -980,8 +993,9 @@ struct PlmEngine : PlmEngineBase {
             auto kern = plm_scatter_kernel<T, Q, JW, W>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ScopedKernelClock kc(ctx, "plm_scatter");
-            hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(W * 64), lds, st, dSR, dLists, dOffs, dDom, dG, N, L, Cs, halo,
-                               numScatChunks, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
+            hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(W * 64), lds, st, dSR, dLists, dOffs, dDom, dZeros, dG, N, L, Cs, halo,
+                               numScatChunks, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs,
+                               getenv("DCA_SCATTER_ABLATE") ? atoi(getenv("DCA_SCATTER_ABLATE")) : 0);
             if (scatSplit > 1)
                 hipLaunchKernelGGL(plm_sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, st, dG, (size_t)Grows * Cs, scatSplit);
         }
