@@ -1,0 +1,83 @@
+"""FASTA input for the mfDCA path with the semantics of the reference's reader
+(pydca/fasta_reader/fasta_reader.py): multi-line records, upper-casing, 1-based integer
+states with gap = q, characters outside the table mapped to the gap state (:138-149),
+exact duplicates dropped keeping the first occurrence (:153).  Host-side string work only;
+no Biopython dependency."""
+import logging
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+RES_TO_INT_ALL = {
+    'PROTEIN': {
+        'A': 1, 'C': 2, 'D': 3, 'E': 4, 'F': 5, 'G': 6, 'H': 7, 'I': 8, 'K': 9, 'L': 10,
+        'M': 11, 'N': 12, 'P': 13, 'Q': 14, 'R': 15, 'S': 16, 'T': 17, 'V': 18, 'W': 19, 'Y': 20,
+        '-': 21, '.': 21, '~': 21,
+    },
+    'RNA': {'A': 1, 'C': 2, 'G': 3, 'U': 4, '-': 5, '.': 5, '~': 5},
+}
+
+
+class FastaReaderError(Exception):
+    """Raised for problems while reading alignment data."""
+
+
+def get_alignment_from_fasta_file(file_name):
+    """-> list of upper-cased sequence strings (fasta_reader.py:81-119)."""
+    alignment, name, cur = [], None, []
+    try:
+        with open(file_name) as fh:
+            for line in fh:
+                line = line.strip()
+                if not line:
+                    continue
+                if line.startswith('>'):
+                    if name is not None:
+                        alignment.append(''.join(cur))
+                    name, cur = line[1:], []
+                elif name is not None:
+                    cur.append(line)
+        if name is not None:
+            alignment.append(''.join(cur))
+    except Exception as expt:
+        logger.error('\n\tError occured while reading from fasta file: {}.\n\tError type:{}\n\tArguments:{!r}'.format(
+            file_name, type(expt).__name__, expt.args))
+        raise
+    alignment = [s.strip().upper() for s in alignment if s.strip()]
+    if not alignment:
+        logger.error('\n\tNo sequences found in {}'.format(file_name))
+        raise ValueError
+    lengths = {len(s) for s in alignment}
+    if len(lengths) != 1:
+        raise ValueError('Sequences in {} do not all have the same length'.format(file_name))
+    return alignment
+
+
+def alignment_letter2int(alignment, biomolecule='protein'):
+    """-> list of lists of 1-based integer states, duplicates removed (fasta_reader.py:122-163)."""
+    biomolecule = biomolecule.strip().upper()
+    if biomolecule not in ('PROTEIN', 'RNA'):
+        logger.error('\n\t{} entered. Biomolecule must be either PROTEIN or RNA'.format(biomolecule))
+        raise ValueError
+    q = 21 if biomolecule == 'PROTEIN' else 5
+    table = np.full(256, q, dtype=np.int32)
+    for ch, v in RES_TO_INT_ALL[biomolecule].items():
+        table[ord(ch)] = v
+    rows, seen = [], set()
+    for seq in alignment:
+        r = table[np.frombuffer(str(seq).upper().encode('latin-1'), dtype=np.uint8)]
+        key = r.tobytes()
+        if key not in seen:
+            seen.add(key)
+            rows.append(r.tolist())
+    logger.info('\n\tTotal number of sequences read from file: {}'.format(len(alignment)))
+    if not rows:
+        logger.error('\n\tNo data found in alignment in integer representation')
+        raise ValueError
+    return rows
+
+
+def get_alignment_int_form(file_name, biomolecule='protein'):
+    """fasta_reader.py:166-188."""
+    return alignment_letter2int(get_alignment_from_fasta_file(file_name), biomolecule)

@@ -1,0 +1,199 @@
+"""MeanFieldDCA -- same class surface as pydca/meanfield_dca/meanfield_dca.py for the
+`mfdca compute_fn` path; numerics on the GPU (one resident context per instance: the
+alignment and the weighted pair counts stay in HBM between calls)."""
+import logging
+
+import numpy as np
+
+from .. import _lib
+from ..fasta_reader import fasta_reader
+from . import msa_numerics
+
+logger = logging.getLogger(__name__)
+
+
+class MeanFieldDCAException(Exception):
+    """Errors related to mean-field DCA computation."""
+
+
+def _ranked(scores, L):
+    """[((i, j), score), ...] sorted by score, descending; ties keep (i, j) order, as
+    Python's stable sorted(..., reverse=True) does in the reference (meanfield_dca.py:940)."""
+    iu, ju = np.triu_indices(L, k=1)
+    order = np.argsort(-scores, kind='stable')
+    return [((int(iu[k]), int(ju[k])), scores[k]) for k in order]
+
+
+class MeanFieldDCA:
+    """Mean-field DCA (meanfield_dca.py:43-139)."""
+
+    def __init__(self, msa, biomolecule, pseudocount=None, seqid=None, device=0):
+        self.__pseudocount = pseudocount if pseudocount is not None else 0.5
+        self.__seqid = seqid if seqid is not None else 0.8
+        if self.__pseudocount >= 1.0 or self.__pseudocount < 0:
+            logger.error('\n\tValue of relative pseudo-count must be between 0 and 1.0. Typical value is 0.5')
+            raise ValueError
+        if self.__seqid > 1.0 or self.__seqid <= 0.0:
+            logger.error('\n\tValue of sequence-identity must not exceed 1 nor less than 0. Typical values are 0.7, 0.8., 0.9')
+            raise ValueError
+        biomolecule = biomolecule.strip().upper()
+        self.__msa = msa
+        if biomolecule == 'RNA':
+            self.__num_site_states = 5
+        elif biomolecule == 'PROTEIN':
+            self.__num_site_states = 21
+        else:
+            logger.error('\n\tUnknown biomolecule ... must be protein (PROTEIN) or rna (RNA)')
+            raise ValueError
+        if isinstance(msa, str):
+            self.__sequences = fasta_reader.get_alignment_int_form(msa, biomolecule=biomolecule)
+        elif isinstance(msa, (list, tuple)) or hasattr(msa, '__iter__'):
+            # an in-memory alignment: records with a .seq attribute (Bio.Align.MultipleSeqAlignment
+            # in the reference, :102-104) or plain strings
+            seqs = [str(getattr(rec, 'seq', rec)).strip().upper() for rec in msa]
+            self.__sequences = fasta_reader.alignment_letter2int([s for s in seqs if s], biomolecule)
+        else:
+            raise ValueError("Alignment input parameter is invalid")
+        self.__num_sequences = len(self.__sequences)
+        self.__sequences_len = len(self.__sequences[0])
+        self.__biomolecule = biomolecule
+        self.__X = np.array(self.__sequences, dtype=np.int32)
+        self.__ctx = _lib.Context(int(device), _lib.DCA_F64)
+        self.__ctx.set_msa((self.__X - 1).astype(np.uint8), self.__num_site_states)
+        if self.__seqid < 1.0:
+            self.__sequences_weight = self.compute_sequences_weight()
+        else:
+            self.__sequences_weight = np.ones((self.__num_sequences,), dtype=np.float64)
+            self.__ctx.set_weights(self.__sequences_weight)
+        self.__effective_num_sequences = np.sum(self.__sequences_weight)
+        self.__couplings = None
+        logger.info('\n\tCreated a MeanFieldDCA object: biomolecule {}, states {}, pseudocount {}, seqid {}, '
+                    'L {}, unique sequences {}, Meff {}'.format(
+                        biomolecule, self.__num_site_states, self.__pseudocount, self.__seqid,
+                        self.__sequences_len, self.__num_sequences, self.__effective_num_sequences))
+
+    def __str__(self):
+        return '<instance of MeanFieldDCA>'
+
+    def __call__(self, pseudocount=0.5, seqid=0.8):
+        """Resets pseudocount / seqid without recomputing the weights (meanfield_dca.py:160-190)."""
+        self.__pseudocount = pseudocount
+        self.__seqid = seqid
+        logger.warning('\n\tYou have changed one of the parameters (pseudo count or sequence identity)'
+                       '\n\tpseudocount: {} \n\tsequence_identity: {}'.format(self.__pseudocount, self.__seqid))
+        return None
+
+    # ---- properties (meanfield_dca.py:193-347)
+    @property
+    def alignment(self):
+        return self.__sequences
+
+    @property
+    def biomolecule(self):
+        return self.__biomolecule
+
+    @property
+    def sequences_len(self):
+        return self.__sequences_len
+
+    @property
+    def num_site_states(self):
+        return self.__num_site_states
+
+    @property
+    def num_sequences(self):
+        return self.__num_sequences
+
+    @property
+    def sequence_identity(self):
+        return self.__seqid
+
+    @property
+    def pseudocount(self):
+        return self.__pseudocount
+
+    @property
+    def sequences_weight(self):
+        return self.__sequences_weight
+
+    @property
+    def effective_num_sequences(self):
+        return np.sum(self.__sequences_weight)
+
+    # ---- stages (meanfield_dca.py:350-553)
+    def compute_sequences_weight(self):
+        logger.info('\n\tComputing sequences weights')
+        return self.__ctx.compute_weights(self.__seqid, _lib.DCA_F64)
+
+    def get_single_site_freqs(self):
+        logger.info('\n\tComputing single site frequencies')
+        return self.__ctx.mf_single_site_freqs()
+
+    def get_reg_single_site_freqs(self):
+        return msa_numerics.get_reg_single_site_freqs(
+            single_site_freqs=self.get_single_site_freqs(), seqs_len=self.__sequences_len,
+            num_site_states=self.__num_site_states, pseudocount=self.__pseudocount)
+
+    def get_pair_site_freqs(self):
+        logger.info('\n\tComputing pair site frequencies')
+        return self.__ctx.mf_pair_site_freqs()
+
+    def get_reg_pair_site_freqs(self):
+        return msa_numerics.get_reg_pair_site_freqs(
+            pair_site_freqs=self.get_pair_site_freqs(), seqs_len=self.__sequences_len,
+            num_site_states=self.__num_site_states, pseudocount=self.__pseudocount)
+
+    def construct_corr_mat(self, reg_fi, reg_fij):
+        logger.info('\n\tConstructing the correlation matrix')
+        return msa_numerics.construct_corr_mat(reg_fi=reg_fi, reg_fij=reg_fij, seqs_len=self.__sequences_len,
+                                               num_site_states=self.__num_site_states)
+
+    def compute_couplings(self, corr_mat):
+        logger.info('\n\tComputing couplings')
+        try:
+            couplings = msa_numerics.compute_couplings(corr_mat=corr_mat)
+        except Exception as e:
+            logger.error('\n\tCorrelation {}\n\tYou set the pseudocount {}. You might need to increase it.'.format(
+                e, self.__pseudocount))
+            raise
+        self.__couplings = couplings
+        return couplings
+
+    # ---- the compute_fn path, fused on the device
+    def _device_scores(self, apc):
+        try:
+            return self.__ctx.mf_run(self.__pseudocount, apc)
+        except _lib.DcaBackendError as exc:
+            if exc.code == _lib.DCA_ERR_NOT_SPD:
+                e = np.linalg.LinAlgError('Singular matrix')
+                logger.error('\n\tCorrelation {}\n\tYou set the pseudocount {}. You might need to increase it.'.format(
+                    e, self.__pseudocount))
+                raise e
+            raise
+
+    def compute_sorted_FN(self, seqbackmapper=None):
+        """meanfield_dca.py:902-943."""
+        if seqbackmapper is not None:
+            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
+        logger.info('\n\tComputing Frobenius norm of couplings')
+        return _ranked(self._device_scores(False), self.__sequences_len)
+
+    def compute_sorted_FN_APC(self, seqbackmapper=None):
+        """meanfield_dca.py:946-988."""
+        if seqbackmapper is not None:
+            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
+        logger.info('\n\tPerforming average product correction (APC) to Frobenius norm of couplings.')
+        return _ranked(self._device_scores(True), self.__sequences_len)
+
+    def get_couplings(self):
+        """-inv(C) of the current pseudocount as float64[L(q-1), L(q-1)] (device resident
+        result of the last run is copied out)."""
+        self.__ctx.mf_corr_mat(self.__pseudocount, want=False)
+        self.__couplings = self.__ctx.mf_couplings()
+        return self.__couplings
+
+    def compute_sorted_DI(self, seqbackmapper=None):
+        raise NotImplementedError('DI scoring is the next row of the scope table (SURVEY 8f1); compute_fn is accelerated')
+
+    def compute_sorted_DI_APC(self, seqbackmapper=None):
+        raise NotImplementedError('DI scoring is the next row of the scope table (SURVEY 8f1); compute_fn is accelerated')

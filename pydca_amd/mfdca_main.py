@@ -1,0 +1,75 @@
+"""`mfdca` command line (mirror of pydca/mfdca_main.py:310-394).  compute_fn runs on the GPU;
+the other sub-commands exist with the same flags and report that they are not accelerated yet."""
+import logging
+import os
+import sys
+from argparse import ArgumentParser
+
+from .dca_utilities import dca_utilities
+from .meanfield_dca import meanfield_dca
+
+logger = logging.getLogger(__name__)
+SUBCOMMANDS = ('compute_di', 'compute_fn', 'compute_params', 'compute_fi', 'compute_fij')
+
+
+def configure_logging():
+    logging.basicConfig(level=logging.INFO, format='%(levelname)s %(name)s: %(message)s')
+
+
+def execute_from_command_line(msa_file=None, biomolecule=None, seqid=None, pseudocount=None, the_command=None,
+                              refseq_file=None, verbose=False, output_dir=None, apc=False, ranked_by=None,
+                              linear_dist=None, num_site_pairs=None, device=0):
+    if verbose:
+        configure_logging()
+    if refseq_file:
+        raise NotImplementedError('--refseq_file (reference-sequence back-mapping) is outside the accelerated path')
+    if the_command.strip() != 'compute_fn':
+        raise NotImplementedError('{} is not part of the accelerated compute_fn path yet'.format(the_command))
+    mfdca_instance = meanfield_dca.MeanFieldDCA(msa_file, biomolecule, pseudocount=pseudocount, seqid=seqid, device=device)
+    param_metadata = dca_utilities.mfdca_param_metadata(mfdca_instance)
+    if not output_dir:
+        msa_file_base_name, _ext = os.path.splitext(os.path.basename(msa_file))
+        output_dir = 'MFDCA_output_' + msa_file_base_name
+    dca_utilities.create_directories(output_dir)
+    if apc:
+        score_type = 'MFDCA Frobenius norm, average product corrected (APC)'
+        sorted_FN = mfdca_instance.compute_sorted_FN_APC()
+        fn_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='MFDCA_apc_fn_scores_', postfix='.txt')
+    else:
+        score_type = 'MFDCA raw Frobenius norm'
+        sorted_FN = mfdca_instance.compute_sorted_FN()
+        fn_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='MFDCA_raw_fn_scores_', postfix='.txt')
+    dca_utilities.write_sorted_dca_scores(fn_file_path, sorted_FN, metadata=param_metadata, score_type=score_type)
+    return fn_file_path
+
+
+def run_meanfield_dca(argv=None):
+    parser = ArgumentParser(prog='mfdca')
+    subparsers = parser.add_subparsers(dest='subcommand_name')
+    for name in SUBCOMMANDS:
+        p = subparsers.add_parser(name)
+        p.add_argument('biomolecule')
+        p.add_argument('msa_file')
+        p.add_argument('--seqid', type=float)
+        p.add_argument('--pseudocount', type=float)
+        p.add_argument('--refseq_file')
+        p.add_argument('--output_dir')
+        p.add_argument('--verbose', action='store_true')
+        p.add_argument('--apc', action='store_true')
+        p.add_argument('--device', type=int, default=0, help='GPU index (addition)')
+        if name == 'compute_params':
+            p.add_argument('--ranked_by', choices=('FN', 'FN_APC', 'DI', 'DI_APC', 'fn', 'fn_apc', 'di', 'di_apc'))
+            p.add_argument('--linear_dist', type=int)
+            p.add_argument('--num_site_pairs', type=int)
+    argv = sys.argv[1:] if argv is None else argv
+    args = vars(parser.parse_args(args=argv if argv else ['--help']))
+    return execute_from_command_line(
+        biomolecule=args.get('biomolecule'), msa_file=args.get('msa_file'), seqid=args.get('seqid'),
+        pseudocount=args.get('pseudocount'), the_command=args.get('subcommand_name'), refseq_file=args.get('refseq_file'),
+        verbose=args.get('verbose'), output_dir=args.get('output_dir'), apc=args.get('apc'),
+        ranked_by=args.get('ranked_by'), linear_dist=args.get('linear_dist'), num_site_pairs=args.get('num_site_pairs'),
+        device=args.get('device'))
+
+
+if __name__ == '__main__':
+    run_meanfield_dca()

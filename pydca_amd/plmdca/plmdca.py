@@ -1,0 +1,190 @@
+"""PlmDCA -- same class surface as pydca/plmdca/plmdca.py for the `plmdca compute_fn`
+path.  The reference crosses into native code once (plmdca.py:202-243, ctypes call of
+plmdcaBackend); here that call goes to libdca_hip.so and the O(L^2 q^2) Python loops that
+follow it in the reference (gap stripping :246-268, Frobenius norm :437-481, APC :484-524)
+run as device kernels as well."""
+import logging
+
+import numpy as np
+
+from .. import _lib
+
+logger = logging.getLogger(__name__)
+
+
+class PlmDCAException(Exception):
+    """Exceptions related to PlmDCA computation."""
+
+
+def _ranked(scores, L):
+    iu, ju = np.triu_indices(L, k=1)
+    order = np.argsort(-scores, kind='stable')
+    return [((int(iu[k]), int(ju[k])), scores[k]) for k in order]
+
+
+class PlmDCA:
+    """plmdca.py:25-104.  Extra keyword arguments (not in the reference): device,
+    precision (32: float storage as the reference; 64: float64 checking mode) and
+    exact_gradient (opt-in mathematically exact pseudolikelihood gradient instead of the
+    reference's carried-over probabilities)."""
+
+    def __init__(self, msa_file, biomolecule, seqid=None, lambda_h=None, lambda_J=None, max_iterations=None,
+                 num_threads=None, verbose=False, device=0, precision=32, exact_gradient=False):
+        self.__biomolecule = biomolecule.strip().upper()
+        if self.__biomolecule not in ('PROTEIN', 'RNA'):
+            logger.error('\n\tInvalid biomolecule type {}'.format(self.__biomolecule))
+            raise PlmDCAException
+        self.__msa_file = msa_file
+        self.__biomolecule_int = 1 if self.__biomolecule == 'PROTEIN' else 2
+        self.__num_site_states = 21 if self.__biomolecule == 'PROTEIN' else 5
+        self.__num_seqs, self.__seqs_len = self._get_num_and_len_of_seqs()
+        self.__seqid = 0.8 if seqid is None else seqid
+        if self.__seqid <= 0 or self.__seqid > 1.0:
+            logger.error('\n\t{} is an invalid value of sequences identity (seqid) parameter'.format(self.__seqid))
+            raise PlmDCAException
+        self.__lambda_h = 0.2 * (self.__seqs_len - 1) if lambda_h is None else lambda_h
+        if self.__lambda_h < 0:
+            logger.error('\n\tlambda_h must be a positive number. You passed lambda_h={}'.format(self.__lambda_h))
+            raise PlmDCAException
+        self.__lambda_J = 0.2 * (self.__seqs_len - 1) if lambda_J is None else lambda_J
+        if self.__lambda_J < 0:
+            logger.error('\n\tlambda_J must be a positive number. You passed lambda_J={}'.format(self.__lambda_J))
+            raise PlmDCAException
+        self.__max_iterations = max_iterations if max_iterations is not None else 100
+        self.__num_threads = 1 if num_threads is None else num_threads   # accepted, unused: the work runs on the GPU
+        self.__verbose = True if verbose else False
+        self.__device = int(device)
+        self.__precision = _lib.DCA_F64 if int(precision) == 64 else _lib.DCA_F32
+        self.__carry = _lib.CARRY_EXACT if exact_gradient else _lib.CARRY_CHUNKED
+        self.__data_size = int((self.__seqs_len * (self.__seqs_len - 1) * (self.__num_site_states ** 2)) / 2
+                               + self.__seqs_len * self.__num_site_states)
+        self.__ctx = None
+        self.__fields_and_couplings_all = None
+        self.last_status = None
+        logger.info('Created plmDCA instance: biomolecule {}, L {}, sequences {}, seqid {}, lambda_h {}, lambda_J {}, '
+                    'iterations {}'.format(self.__biomolecule, self.__seqs_len, self.__num_seqs, self.__seqid,
+                                           self.__lambda_h, self.__lambda_J, self.__max_iterations))
+
+    # ---- properties (plmdca.py:107-160)
+    @property
+    def biomolecule(self):
+        return self.__biomolecule
+
+    @property
+    def sequence_identity(self):
+        return self.__seqid
+
+    @property
+    def lambda_h(self):
+        return self.__lambda_h
+
+    @property
+    def lambda_J(self):
+        return self.__lambda_J
+
+    @property
+    def max_iterations(self):
+        return self.__max_iterations
+
+    @property
+    def sequences_len(self):
+        return self.__seqs_len
+
+    @property
+    def num_sequences(self):
+        return self.__num_seqs
+
+    @property
+    def effective_num_sequences(self):
+        raise NotImplementedError
+
+    def _get_num_and_len_of_seqs(self):
+        """Raw number of records and alignment length (plmdca.py:163-180)."""
+        from ..fasta_reader import fasta_reader
+        msa_data = fasta_reader.get_alignment_from_fasta_file(self.__msa_file)
+        return len(msa_data), len(msa_data[0])
+
+    def map_index_couplings(self, i, j, a, b):
+        """plmdca.py:183-199."""
+        q = self.__num_site_states
+        L = self.__seqs_len
+        site = int(((L * (L - 1) / 2) - (L - i) * ((L - i) - 1) / 2 + j - i - 1) * q * q)
+        return L * q + site + b + a * q
+
+    # ---- the native call
+    def _run_backend(self):
+        """Read + de-duplicate (C++ reader semantics), weights, initial parameters and L-BFGS
+        on the device; leaves the optimised parameters resident in the context."""
+        X, _raw = _lib.read_msa(self.__msa_file, self.__biomolecule_int, self.__seqs_len)
+        if self.__ctx is not None:
+            self.__ctx.close()
+        ctx = _lib.Context(self.__device, self.__precision)
+        ctx.set_msa(X, self.__num_site_states)
+        # the reference's C++ compares in float (plmdca_numerics.cpp:642); the float64 checking
+        # mode compares in double like the float64 oracle
+        ctx.compute_weights(self.__seqid, self.__precision)
+        ctx.plm_configure(self.__lambda_h, self.__lambda_J, self.__carry)
+        ctx.plm_init_x()
+        ctx.plm_lbfgs_begin(self.__max_iterations, self.__verbose)
+        st = ctx.plm_lbfgs_iterate(self.__max_iterations if self.__max_iterations else 1 << 30)
+        self.last_status = dict(status=st.status, iterations=st.iterations, evaluations=st.evaluations, fx=st.fx,
+                                seconds=st.seconds)
+        self.__ctx = ctx
+        return ctx
+
+    def get_fields_and_couplings_from_backend(self):
+        """plmdca.py:202-243 -> float32[L*q + L(L-1)/2*q*q] (one bulk copy instead of the
+        reference's element-by-element Python loop)."""
+        logger.info('\n\tComputing fields and couplings using gradient decent')
+        ctx = self._run_backend()
+        fields_and_couplings = ctx.plm_get_x(np.float32)
+        assert fields_and_couplings.size == self.__data_size
+        return fields_and_couplings
+
+    def get_couplings_no_gap_state(self, fields_and_couplings_all):
+        """plmdca.py:246-268, vectorised: the a,b < q-1 sub-block of every pair."""
+        L, q = self.__seqs_len, self.__num_site_states
+        J = np.asarray(fields_and_couplings_all)[L * q:].reshape(L * (L - 1) // 2, q, q)
+        return np.ascontiguousarray(J[:, :q - 1, :q - 1]).reshape(-1)
+
+    def get_fields_no_gap_state(self, fields_and_couplings_all):
+        """plmdca.py:271-292."""
+        L, q = self.__seqs_len, self.__num_site_states
+        h = np.asarray(fields_and_couplings_all)[:L * q].reshape(L, q)
+        return list(h[:, :q - 1].reshape(-1))
+
+    def get_fields_and_couplings_no_gap_state(self, fields_and_couplings_all):
+        return (self.get_fields_no_gap_state(fields_and_couplings_all),
+                self.get_couplings_no_gap_state(fields_and_couplings_all))
+
+    def shift_couplings(self, couplings_ij):
+        """plmdca.py:320-342 (zero-sum gauge of one block)."""
+        qm1 = self.__num_site_states - 1
+        couplings_ij = np.reshape(couplings_ij, (qm1, qm1))
+        avx = np.reshape(np.mean(couplings_ij, axis=1), (qm1, 1))
+        avy = np.reshape(np.mean(couplings_ij, axis=0), (1, qm1))
+        return couplings_ij - avx - avy + np.mean(couplings_ij)
+
+    # ---- scores
+    def compute_sorted_FN(self, seqbackmapper=None):
+        """plmdca.py:437-481."""
+        if seqbackmapper is not None:
+            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
+        ctx = self._run_backend()
+        self.__fields_and_couplings_all = None
+        logger.info('\n\tComputing non-APC sorted DCA score')
+        return _ranked(ctx.plm_scores(False), self.__seqs_len)
+
+    def compute_sorted_FN_APC(self, seqbackmapper=None):
+        """plmdca.py:484-524."""
+        if seqbackmapper is not None:
+            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
+        ctx = self._run_backend()
+        logger.info('\n\tPerforming average product correction (APC) of FN  of DCA scores')
+        return _ranked(ctx.plm_scores(True), self.__seqs_len)
+
+    def compute_sorted_DI(self, seqbackmapper=None):
+        raise NotImplementedError('DI scoring is the next row of the scope table (SURVEY 8f1); compute_fn is accelerated')
+
+    def compute_sorted_DI_APC(self, seqbackmapper=None):
+        raise NotImplementedError('DI scoring is the next row of the scope table (SURVEY 8f1); compute_fn is accelerated')

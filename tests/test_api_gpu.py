@@ -1,0 +1,163 @@
+"""GPU tests of the Python surface that mirrors the reference (PlmDCA / MeanFieldDCA classes,
+msa_numerics module, command lines) and of the sharded evaluation."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, data_file, golden, perturbed, rel_err
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, ROOT)
+
+
+def test_meanfield_class_full_ranking_rf00167():
+    """mfdca compute_fn rna MSA_RF00167.fa --pseudocount 0.5 --apc (config 1 of BASELINE.json):
+    identical ranked list as the real reference (golden), scores <= 1e-9."""
+    from pydca_amd.meanfield_dca.meanfield_dca import MeanFieldDCA
+    G = golden("mf_rf00167")
+    inst = MeanFieldDCA(data_file("MSA_RF00167.fa"), "rna", pseudocount=0.5, seqid=0.8)
+    assert (inst.num_sequences, inst.sequences_len, inst.num_site_states) == (2544, 102, 5)
+    assert abs(inst.effective_num_sequences - 1608.8065456172653) < 1e-9
+    apc = inst.compute_sorted_FN_APC()
+    assert [p for p, _ in apc] == [tuple(p) for p in G["apc_pairs"]]
+    np.testing.assert_allclose([s for _, s in apc], G["apc_scores"], rtol=1e-9)
+    raw = inst.compute_sorted_FN()
+    assert [p for p, _ in raw] == [tuple(p) for p in G["fn_pairs"]]
+
+
+def test_meanfield_file_and_in_memory_alignment_agree():
+    """The reference's own consistency test (tests/meanfield_dca_test.py:50-61): FN_APC from a
+    file path equals FN_APC from an in-memory alignment."""
+    from pydca_amd.fasta_reader import fasta_reader
+    from pydca_amd.meanfield_dca.meanfield_dca import MeanFieldDCA
+    f = data_file("toy_protein.fa")
+    a = MeanFieldDCA(f, "protein").compute_sorted_FN_APC()
+    b = MeanFieldDCA(fasta_reader.get_alignment_from_fasta_file(f), "protein").compute_sorted_FN_APC()
+    assert a == b
+
+
+def test_meanfield_notebook_kat():
+    """examples/pydca_demo.ipynb cell 10: published top-5 FN_APC on trimmed RF00167."""
+    from pydca_amd.meanfield_dca.meanfield_dca import MeanFieldDCA
+    K = golden("kat_notebook")
+    top = MeanFieldDCA(data_file("MSA_RF00167_trimmed71.fa"), "rna", pseudocount=0.5, seqid=0.8).compute_sorted_FN_APC()[:5]
+    assert [p for p, _ in top] == [tuple(p) for p in K["mf_pairs"]]
+    np.testing.assert_allclose([s for _, s in top], K["mf_scores"], rtol=1e-11)
+
+
+def test_msa_numerics_module_stage_functions():
+    from pydca_amd.meanfield_dca import msa_numerics as mn
+    G = golden("mf_toy_protein")
+    X, q = G["X"], int(G["q"])
+    L = X.shape[1]
+    w = mn.compute_sequences_weight(alignment_data=X, seqid=0.8)
+    np.testing.assert_array_equal(w, G["w"])
+    fi = mn.compute_single_site_freqs(alignment_data=X, num_site_states=q, seqs_weight=w)
+    np.testing.assert_allclose(fi, G["fi"], rtol=1e-13, atol=1e-16)
+    reg_fi = mn.get_reg_single_site_freqs(single_site_freqs=fi, seqs_len=L, num_site_states=q, pseudocount=0.5)
+    assert reg_fi is fi
+    np.testing.assert_allclose(reg_fi, G["reg_fi"], rtol=1e-13)
+    fij = mn.compute_pair_site_freqs(alignment_data=X, num_site_states=q, seqs_weight=w)
+    reg_fij = mn.get_reg_pair_site_freqs(pair_site_freqs=fij, seqs_len=L, num_site_states=q, pseudocount=0.5)
+    np.testing.assert_allclose(reg_fij, G["reg_fij"], rtol=1e-12)
+    corr = mn.construct_corr_mat(reg_fi=reg_fi, reg_fij=reg_fij, seqs_len=L, num_site_states=q)
+    np.testing.assert_allclose(corr, G["corr_mat"], rtol=1e-11, atol=1e-15)
+    np.testing.assert_allclose(mn.compute_couplings(corr_mat=corr), G["couplings"], rtol=1e-8, atol=1e-10)
+    with pytest.raises(np.linalg.LinAlgError):
+        mn.compute_couplings(corr_mat=np.zeros((8, 8)))
+
+
+def test_plmdca_class_against_reference_run(oracle_mf):
+    """PlmDCA.compute_sorted_FN_APC on the toy RNA alignment vs the reference's own 1-thread
+    plmdcaBackend run held in the fixture (float32, chaotic last digits: P4 regime)."""
+    from pydca_amd.plmdca.plmdca import PlmDCA
+    G = golden("plm_toy_rna")
+    L, q = int(G["L"]), int(G["q"])
+    inst = PlmDCA(data_file("toy_rna.fa"), "rna", seqid=0.8, lambda_h=1.8, lambda_J=1.8, max_iterations=100)
+    apc = inst.compute_sorted_FN_APC()
+    ref = oracle_mf.sort_scores(oracle_mf.plm_fn(G["run_a"], L, q), L)
+    assert len(apc) == L * (L - 1) // 2
+    assert [p for p, _ in apc[:3]] == [p for p, _ in ref[:3]]
+    d = dict(ref)
+    assert max(abs(s - d[p]) / abs(d[p]) for p, s in apc[:L]) < 2e-2
+    x = inst.get_fields_and_couplings_from_backend()
+    assert x.dtype == np.float32 and x.size == L * q + L * (L - 1) // 2 * q * q
+    assert inst.get_couplings_no_gap_state(x).size == L * (L - 1) // 2 * (q - 1) ** 2
+
+
+def test_command_lines_write_reference_named_files(tmp_path):
+    from pydca_amd import mfdca_main, plmdca_main
+    out = plmdca_main.run_plm_dca(["compute_fn", "rna", data_file("toy_rna.fa"), "--max_iterations", "5", "--apc",
+                                   "--output_dir", str(tmp_path / "p")])
+    assert os.path.basename(out) == "PLMDCA_apc_fn_scores_toy_rna.txt"
+    lines = [ln for ln in open(out).read().splitlines() if not ln.startswith("#")]
+    assert len(lines) == 45 and len(lines[0].split()) == 3
+    out = mfdca_main.run_meanfield_dca(["compute_fn", "rna", data_file("toy_rna.fa"), "--pseudocount", "0.5",
+                                        "--output_dir", str(tmp_path / "m")])
+    assert os.path.basename(out) == "MFDCA_raw_fn_scores_toy_rna.txt"
+    G = golden("mf_toy_rna")
+    first = [ln for ln in open(out).read().splitlines() if not ln.startswith("#")][0].split()
+    assert (int(first[0]) - 1, int(first[1]) - 1) == tuple(G["fn_pairs"][0])
+    assert abs(float(first[2]) - G["fn_scores"][0]) < 1e-9 * G["fn_scores"][0]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_contexts_sum_to_unsharded(oracle_plm, world):
+    """In-process emulation of `world` ranks on one GPU: shard + halo contexts, sum of their
+    (fx, g) in rank order == the unsharded evaluation (float64 kernels, reference semantics)."""
+    from pydca_amd import _lib, parallel
+    G = golden("plm_rf71")
+    X, q, L = G["X"], int(G["q"]), int(G["L"])
+    w = oracle_plm.weights(X, 0.8, np.float64)
+    x = perturbed(oracle_plm.init_x(X, w, q), L, q)
+    full = _lib.Context(0, _lib.DCA_F64)
+    full.set_msa(X, q)
+    full.set_weights(w)
+    full.plm_configure(1.0, 20.0)
+    full.plm_set_x(x)
+    fx_full = full.plm_gradient()
+    g_full = full.plm_get_g(np.float64)
+    full.close()
+    fx_sum, g_sum = 0.0, np.zeros_like(g_full)
+    for rank in range(world):
+        ctx = parallel.make_sharded_plm_context(_lib, X, q, w, 1.0, 20.0, rank, world, 0, precision=64)
+        ctx.plm_set_x(x)
+        fx_sum += ctx.plm_gradient()
+        g_sum += ctx.plm_get_g(np.float64)
+        ctx.close()
+    assert abs(fx_sum - fx_full) <= 1e-11 * abs(fx_full)
+    assert rel_err(g_sum, g_full) < 1e-11
+
+
+def test_reduce_hook_through_torch_distributed():
+    """The all-reduce hook path (torch.distributed, backend nccl = RCCL) with a 1-rank group:
+    the gradient must come back unchanged and the optimiser must still run."""
+    import torch
+    import torch.distributed as dist
+    from pydca_amd import _lib, parallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29591")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        G = golden("plm_toy_protein")
+        X, q = G["X"], int(G["q"])
+        ctx = _lib.Context(0, _lib.DCA_F32)
+        ctx.set_msa(X, q)
+        ctx.compute_weights(0.8, _lib.DCA_F32)
+        ctx.plm_configure(1.0, 5.0)
+        ctx.plm_init_x()
+        fx0 = ctx.plm_gradient()
+        g0 = ctx.plm_get_g(np.float32)
+        hook = parallel.TorchAllReduceHook(0)
+        ctx.plm_set_reduce_hook(hook)
+        fx1 = ctx.plm_gradient()
+        g1 = ctx.plm_get_g(np.float32)
+        assert hook.calls == 1 and fx1 == fx0 and np.array_equal(g0, g1)
+        ctx.plm_lbfgs_begin(5)
+        st = ctx.plm_lbfgs_iterate(5)
+        assert st.iterations == 5 and hook.calls == 1 + st.evaluations
+        ctx.close()
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,182 @@
+"""CPU-only tests: host logic of the product (readers, sharding, writers, CLI surface), the
+C-ABI library's exports, and the rule that the product never touches oracle/."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, data_file, golden
+
+sys.path.insert(0, ROOT)
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/dca_hip.h is exported by libdca_hip.so (no compute calls)."""
+    from pydca_amd import _lib
+    header = open(os.path.join(ROOT, "include", "dca_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    header = re.sub(r"typedef[^;{]*(\{[^}]*\})?[^;]*;", "", header, flags=re.S)
+    header = re.sub(r"^\s*#.*$", "", header, flags=re.M)          # preprocessor lines
+    declared = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", header))
+    declared -= {"dca_reduce_hook"}
+    assert {"plmdcaBackend", "freeFieldsAndCouplings", "dca_plm_gradient", "dca_mf_run"} <= declared
+    lib = C.CDLL(_lib.LIB_PATH)
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) <= declared | {"dca_mf_corr_from_freqs"}
+
+
+def test_no_gpu_fails_loudly_instead_of_falling_back():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from pydca_amd import _lib
+    with pytest.raises(_lib.DcaBackendError) as ei:
+        _lib.Context(0, _lib.DCA_F32)
+    assert "no CPU fallback" in str(ei.value) or ei.value.code == -6
+    # the drop-in symbol reports NULL + message, it does not crash or compute on the host
+    lib = _lib.lib()
+    assert not lib.plmdcaBackend(2, 5, os.fsencode(data_file("toy_rna.fa")), 10, 0.8, 1.0, 1.0, 3, 1, False)
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _dirs, files in os.walk(os.path.join(ROOT, "pydca_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "oracle/" in txt and f.endswith((".hip", ".cpp", ".h")):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("tag,fname,bio", [("toy_rna", "toy_rna.fa", 2), ("toy_protein", "toy_protein.fa", 1),
+                                            ("rf71", "MSA_RF00167_trimmed71.fa", 2), ("rf00167", "MSA_RF00167.fa", 2)])
+def test_cxx_reader_semantics_bit_exact(tag, fname, bio):
+    """dca_read_msa == PlmDCA::readSequencesFromFile (plmdca_numerics.cpp:685-767) on the
+    rows the real reference kept (golden)."""
+    from pydca_amd import _lib
+    G = golden("plm_" + tag)
+    X, raw = _lib.read_msa(data_file(fname), bio, int(G["L"]))
+    assert raw == int(G["raw_count"])
+    assert np.array_equal(X, G["X"])
+
+
+def test_cxx_reader_errors(tmp_path):
+    from pydca_amd import _lib
+    p = tmp_path / "bad.fa"
+    p.write_text(">a\nACGT\n")            # 'T' is not in the reference's RNA table (it throws)
+    with pytest.raises(_lib.DcaBackendError) as ei:
+        _lib.read_msa(str(p), 2, 4)
+    assert ei.value.code == -3
+    with pytest.raises(_lib.DcaBackendError) as ei:
+        _lib.read_msa(str(tmp_path / "missing.fa"), 2, 4)
+    assert ei.value.code == -2
+    p2 = tmp_path / "ok.fa"
+    p2.write_text(">a\nacgu-\n\n>b\nACGU-\n>c\nNNNN.\n")   # lower case, duplicate, empty line, unknown letters -> gap
+    X, raw = _lib.read_msa(str(p2), 2, 5)
+    assert raw == 3 and X.tolist() == [[0, 1, 2, 3, 4], [4, 4, 4, 4, 4]]
+
+
+@pytest.mark.parametrize("tag,fname,bio", [("toy_rna", "toy_rna.fa", "rna"), ("toy_protein", "toy_protein.fa", "protein"),
+                                            ("rf00167", "MSA_RF00167.fa", "RNA")])
+def test_python_reader_matches_reference_reader(tag, fname, bio):
+    """fasta_reader.get_alignment_int_form == the reference's Biopython-based reader (golden X)."""
+    from pydca_amd.fasta_reader import fasta_reader
+    G = golden("mf_" + tag)
+    X = np.array(fasta_reader.get_alignment_int_form(data_file(fname), bio), dtype=np.int32)
+    assert np.array_equal(X, G["X"])
+
+
+def test_shard_bounds_partition_and_halo():
+    from pydca_amd import parallel
+    for n in (1, 7, 64, 1000, 50000):
+        for world in (1, 2, 3, 8):
+            if world > n:
+                continue
+            cover = []
+            for r in range(world):
+                a, b = parallel.shard_bounds(n, world, r)
+                assert 0 <= a <= b <= n
+                cover += list(range(a, b))
+                first, stop, halo = parallel.shard_with_halo(n, world, r, 40)
+                assert stop == b and first == a - halo and 0 <= halo <= 40 and first >= 0
+                if r == 0:
+                    assert halo == 0
+            assert cover == list(range(n))
+            sizes = [parallel.shard_bounds(n, world, r)[1] - parallel.shard_bounds(n, world, r)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_initial_x_host_matches_oracle(oracle_plm):
+    from pydca_amd import parallel
+    G = golden("plm_toy_protein")
+    x = parallel.initial_x(G["X"], G["w"], int(G["q"]), np.float32)
+    ref = oracle_plm.init_x(G["X"], G["w"], int(G["q"]))
+    np.testing.assert_allclose(x, ref, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(x, G["x0"], rtol=2e-6, atol=2e-6)
+
+
+def test_score_file_format(tmp_path):
+    """dca_utilities.write_sorted_dca_scores: header rule, metadata, 1-based sites, column widths
+    (pydca/dca_utilities/dca_utilities.py:236-266)."""
+    from pydca_amd.dca_utilities import dca_utilities
+
+    class Inst:
+        biomolecule, num_sequences, sequences_len = "RNA", 10, 7
+        sequence_identity, lambda_h, lambda_J, max_iterations = 0.8, 1.0, 20.0, 100
+
+    path = dca_utilities.get_dca_output_file_path(str(tmp_path), "/x/y/MSA_abc.fa", prefix="PLMDCA_apc_fn_scores_", postfix=".txt")
+    assert os.path.basename(path) == "PLMDCA_apc_fn_scores_MSA_abc.txt"
+    dca_utilities.write_sorted_dca_scores(path, [((0, 5), 1.25), ((2, 3), 0.5)], metadata=dca_utilities.plmdca_param_metadata(Inst()),
+                                          score_type="PLMDCA Frobenius norm, average product corrected (APC)")
+    lines = open(path).read().splitlines()
+    assert lines[0] == "#" + "=" * 70
+    assert lines[1] == "# PARAMETERS USED FOR THIS COMPUTATION: "
+    assert "#\tlambda_J: 20.0" in lines
+    assert lines[-2] == "{0:<7} {1:<14} {2:<35}".format(1, 6, 1.25)
+    assert lines[-1] == "{0:<7} {1:<14} {2:<35}".format(3, 4, 0.5)
+
+
+def test_cli_surface():
+    """Sub-commands and flags of the reference CLIs (plmdca_main.py:262-328, mfdca_main.py:310-394)."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-m", "pydca_amd.plmdca_main", "compute_fn", "--help"], env=env, capture_output=True, text=True)
+    assert out.returncode == 0
+    for flag in ("--seqid", "--lambda_h", "--lambda_J", "--max_iterations", "--num_threads", "--refseq_file", "--verbose", "--apc", "--output_dir"):
+        assert flag in out.stdout
+    out = subprocess.run([sys.executable, "-m", "pydca_amd.mfdca_main", "compute_fn", "--help"], env=env, capture_output=True, text=True)
+    assert out.returncode == 0
+    for flag in ("--seqid", "--pseudocount", "--refseq_file", "--output_dir", "--verbose", "--apc"):
+        assert flag in out.stdout
+    out = subprocess.run([sys.executable, "-m", "pydca_amd.plmdca_main"], env=env, capture_output=True, text=True)
+    assert "compute_fn" in out.stdout and "compute_di" in out.stdout and "compute_params" in out.stdout
+
+
+def test_class_validation_matches_reference():
+    """Argument validation happens before any GPU work (plmdca.py:53-71, meanfield_dca.py:76-95)."""
+    from pydca_amd.meanfield_dca.meanfield_dca import MeanFieldDCA
+    from pydca_amd.plmdca.plmdca import PlmDCA, PlmDCAException
+    f = data_file("toy_rna.fa")
+    with pytest.raises(PlmDCAException):
+        PlmDCA(f, "dna")
+    with pytest.raises(PlmDCAException):
+        PlmDCA(f, "rna", seqid=1.5)
+    with pytest.raises(PlmDCAException):
+        PlmDCA(f, "rna", lambda_J=-1.0)
+    p = PlmDCA(f, "rna")
+    assert (p.sequences_len, p.num_sequences, p.max_iterations) == (10, 48, 100)
+    assert abs(p.lambda_h - 0.2 * 9) < 1e-12 and p.sequence_identity == 0.8
+    assert p.map_index_couplings(0, 1, 0, 0) == 10 * 5
+    with pytest.raises(NotImplementedError):
+        p.effective_num_sequences
+    with pytest.raises(ValueError):
+        MeanFieldDCA(f, "rna", pseudocount=1.0)
+    with pytest.raises(ValueError):
+        MeanFieldDCA(f, "rna", seqid=0.0)
+    with pytest.raises(ValueError):
+        MeanFieldDCA(f, "lipid")
