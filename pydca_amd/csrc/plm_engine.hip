@@ -46,9 +46,12 @@ struct PairIJ { uint16_t i, j; };
 // W[(j,b)][(i,a)] = W[(i,a)][(j,b)] = J_ij(a,b); diagonal blocks and padding stay 0.
 // One workgroup per site pair; the q x q block goes through LDS so that both
 // writes are runs of q contiguous elements.
+// Rows of W are stored permuted within each site, row (j, perm[j][b]): the logits kernel reads W
+// rows with 16-byte LDS reads, where rows 16 apart share a bank slot (q = 21 rows > 16 slots), and
+// perm puts the rarest states of every site on the colliding rows (see PlmEngine::configure).
 template <typename T>
 __global__ void plm_expand_kernel(const T* __restrict__ x, T* __restrict__ W, const PairIJ* __restrict__ pairs,
-                                  int L, int q, int Cs)
+                                  const uint8_t* __restrict__ perm, int L, int q, int Cs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
     T* tile = reinterpret_cast<T*>(dca_smem);
@@ -61,9 +64,9 @@ __global__ void plm_expand_kernel(const T* __restrict__ x, T* __restrict__ W, co
     for (int t = threadIdx.x; t < q2; t += blockDim.x) {
         const int r = t / q, c = t % q;
         // row (i,a=r), columns (j,b=c): contiguous in b
-        W[(size_t)(i * q + r) * Cs + j * q + c] = tile[r * q + c];
+        W[(size_t)(i * q + perm[i * q + r]) * Cs + j * q + c] = tile[r * q + c];
         // row (j,b=r), columns (i,a=c): contiguous in a
-        W[(size_t)(j * q + r) * Cs + i * q + c] = tile[c * q + r];
+        W[(size_t)(j * q + perm[j * q + r]) * Cs + i * q + c] = tile[c * q + r];
     }
 }
 
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 2)
 void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ lists, const int* __restrict__ offs,
                         const uint8_t* __restrict__ dom, const unsigned char* __restrict__ zeros, T* __restrict__ G,
                         int N, int L, int Cs, int halo, int numChunks, int numColTiles, int numJG,
-                        int chunksPerSplit, size_t slabElems, int ablate)
+                        int chunksPerSplit, size_t slabElems, int groups, int ablate)
 {
     constexpr int EPL = 8 / sizeof(T);     // elements per lane
     constexpr int CW = 64 * EPL;           // columns per tile
@@ -280,17 +283,26 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ li
     struct alignas(8) Acc { T v[EPL]; };
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
 
+    // Column tiles are walked persistently: the grid holds `groups` x numJG workgroups per XCD;
+    // the numJG workgroups of a group walk the same sequence of column tiles
+    // (ct = group*8 + xcd, += groups*8) and all chunks of each in the same order, so they read
+    // the same 64 KB tile of R at about the same time and most of those reads can hit L2.
+    // groups = number of column tiles per XCD gives the one-tile-per-workgroup launch.
     const int id = blockIdx.x;
     const int xcd = id % kNumXcd, k = id / kNumXcd;
-    const int ct = (k / numJG) * kNumXcd + xcd;
+    const int group = k / numJG;
     const int jg = k % numJG;
-    if (ct >= numColTiles) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jbase = jg * JG + wave * JW;
+    T* const Gslab = G + (size_t)blockIdx.y * slabElems;
 
+    for (int t = tid; t < kRowBytes / 4; t += WAVES * 64)
+        reinterpret_cast<uint32_t*>(dca_smem + kNC * kRowBytes)[t] = 0u;
+
+  for (int ct = group * kNumXcd + xcd; ct < numColTiles; ct += groups * kNumXcd) {
     Acc acc[JW][Q];
     Acc colsum;
 #pragma unroll
@@ -302,14 +314,10 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ li
 #pragma unroll
             for (int e = 0; e < EPL; ++e) acc[jj][b].v[e] = 0;
 
-    for (int t = tid; t < kRowBytes / 4; t += WAVES * 64)
-        reinterpret_cast<uint32_t*>(dca_smem + kNC * kRowBytes)[t] = 0u;
-
     // blockIdx.y splits the chunk range; every split writes its own slab of G (summed by
     // plm_sum_slabs_kernel in a fixed order), so small L*q shapes still fill the chip.
     const int cBegin = blockIdx.y * chunksPerSplit;
     const int cEnd = min(numChunks, cBegin + chunksPerSplit);
-    G += (size_t)blockIdx.y * slabElems;
 
     const unsigned char* laneBase = dca_smem + lane * 8;
     const unsigned char* Rtile = reinterpret_cast<const unsigned char*>(R + (size_t)ct * CW) + (lane & 31) * 16;
@@ -413,10 +421,12 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ li
             for (int b = 0; b < Q; ++b) {
                 Acc out = acc[jj][b];
                 if (b == dj) out = rest;
-                *reinterpret_cast<Acc*>(reinterpret_cast<unsigned char*>(G + (size_t)(j * Q + b) * Cs + (size_t)ct * CW) + lane * 8) = out;
+                *reinterpret_cast<Acc*>(reinterpret_cast<unsigned char*>(Gslab + (size_t)(j * Q + b) * Cs + (size_t)ct * CW) + lane * 8) = out;
             }
         }
     }
+    __syncthreads();   // the column-sum scratch rows are tile rows of the next iteration
+  }
 }
 
 // G[0] += G[1] + ... + G[nsplit-1], fixed order (deterministic)
@@ -609,13 +619,20 @@ __global__ void cast_weights_kernel(const double* __restrict__ wd, T* __restrict
 }
 
 // X4[u][n] = bytes X[n][4u..4u+3]
-__global__ void pack_x4_kernel(const uint8_t* __restrict__ X, uint32_t* __restrict__ X4, int N, int Npad, int Ls, int Ls4)
+// (states already mapped through the per-site row permutation of W)
+__global__ void pack_x4_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ perm, uint32_t* __restrict__ X4,
+                               int N, int Npad, int L, int Ls, int Ls4, int q)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int u = blockIdx.y;
     if (n >= Npad || u >= Ls4) return;
     uint32_t v = 0;
-    if (n < N && u * 4 < Ls) v = *reinterpret_cast<const uint32_t*>(X + (size_t)n * Ls + u * 4);
+    if (n < N) {
+        for (int k = 0; k < 4; ++k) {
+            const int j = u * 4 + k;
+            if (j < L) v |= (uint32_t)perm[j * q + X[(size_t)n * Ls + j]] << (8 * k);
+        }
+    }
     X4[(size_t)u * Npad + n] = v;
 }
 
@@ -739,6 +756,7 @@ struct PlmEngine : PlmEngineBase {
     T *dWt = nullptr, *dSR = nullptr, *dG = nullptr, *dw = nullptr;
     uint32_t *dX4 = nullptr, *dLists = nullptr;
     uint8_t* dDom = nullptr;
+    uint8_t* dPerm = nullptr;
     unsigned char* dZeros = nullptr;
     int* dOffs = nullptr;
     PairIJ* dPairs = nullptr;
@@ -766,7 +784,7 @@ struct PlmEngine : PlmEngineBase {
         hipFree(dx); hipFree(dg); hipFree(dxp); hipFree(dgp); hipFree(dd);
         for (int i = 0; i < 5; ++i) { hipFree(dS[i]); hipFree(dY[i]); }
         hipFree(dWt); hipFree(dSR); hipFree(dG); hipFree(dw); hipFree(dX4); hipFree(dLists); hipFree(dOffs);
-        hipFree(dPairs); hipFree(dDom); hipFree(dZeros); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
+        hipFree(dPairs); hipFree(dDom); hipFree(dPerm); hipFree(dZeros); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
     }
     ~PlmEngine() override { freeall(); }
 
@@ -790,7 +808,7 @@ struct PlmEngine : PlmEngineBase {
         freeall();
         dx = dg = dxp = dgp = dd = nullptr;
         for (int i = 0; i < 5; ++i) dS[i] = dY[i] = nullptr;
-        dWt = dSR = dG = dw = nullptr; dX4 = dLists = nullptr; dDom = nullptr; dZeros = nullptr; dOffs = nullptr; dPairs = nullptr;
+        dWt = dSR = dG = dw = nullptr; dX4 = dLists = nullptr; dDom = nullptr; dPerm = nullptr; dZeros = nullptr; dOffs = nullptr; dPairs = nullptr;
         dFxPart = dRegPart = dVecPart = nullptr;
         lbfgs_alloc = false;
         o = decltype(o)();
@@ -818,6 +836,7 @@ struct PlmEngine : PlmEngineBase {
         }
         DCA_TRY(dalloc(&dG, (size_t)scatSplit * Grows * Cs));
         DCA_TRY(dalloc(&dDom, L));
+        DCA_TRY(dalloc(&dPerm, (size_t)L * q));
         DCA_TRY(dalloc(&dZeros, kRowBytes));
         HIP_TRY(hipMemsetAsync(dZeros, 0, kRowBytes, ctx->stream));
         DCA_TRY(dalloc(&dw, N));
@@ -844,7 +863,7 @@ struct PlmEngine : PlmEngineBase {
         }
         HIP_TRY(hipMemcpyAsync(dPairs, hp.data(), npairs * sizeof(PairIJ), hipMemcpyHostToDevice, ctx->stream));
         // most frequent state of every site among the owned sequences (ties -> lowest code)
-        std::vector<uint8_t> hdom(L);
+        std::vector<uint8_t> hdom(L), hperm;
         {
             std::vector<int> cnt((size_t)L * q, 0);
             const uint8_t* X = ctx->hX.data();
@@ -855,8 +874,28 @@ struct PlmEngine : PlmEngineBase {
                 for (int a = 1; a < q; ++a) if (cnt[(size_t)i * q + a] > cnt[(size_t)i * q + best]) best = a;
                 hdom[i] = (uint8_t)best;
             }
+            // row permutation of W within each site: physical rows r and r+16 share an LDS bank slot
+            // for the 16-byte reads of the logits kernel, so the 2(q-16) rarest states take rows
+            // 0..q-17 and 16..q-1 (rarest last) and the frequent states the collision-free rows between
+            hperm.assign((size_t)L * q, 0);
+            std::vector<int> order(q);
+            for (int i = 0; i < L; ++i) {
+                for (int a = 0; a < q; ++a) order[a] = a;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cnt[(size_t)i * q + a] < cnt[(size_t)i * q + b]; });
+                const int extra = q > 16 ? q - 16 : 0;       // rows that have a colliding partner
+                // order[] ascending by count: order[0..extra) -> rows 16.., order[extra..2*extra) -> rows 0..extra,
+                // the rest -> rows extra..16
+                for (int k = 0; k < q; ++k) {
+                    int row;
+                    if (k < extra) row = 16 + k;
+                    else if (k < 2 * extra) row = k - extra;
+                    else row = k - extra;
+                    hperm[(size_t)i * q + order[k]] = (uint8_t)row;
+                }
+            }
         }
         HIP_TRY(hipMemcpyAsync(dDom, hdom.data(), L, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dPerm, hperm.data(), hperm.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
 
         // weights in T.  1/count is formed in T exactly as the reference does
@@ -877,7 +916,7 @@ struct PlmEngine : PlmEngineBase {
 
         {
             dim3 grid(ceil_div(Npad, 256), Ls4);
-            hipLaunchKernelGGL(pack_x4_kernel, grid, dim3(256), 0, ctx->stream, ctx->dX, dX4, N, Npad, Ls, Ls4);
+            hipLaunchKernelGGL(pack_x4_kernel, grid, dim3(256), 0, ctx->stream, ctx->dX, dPerm, dX4, N, Npad, L, Ls, Ls4, q);
             const int nt = numScatChunks * L;
             hipLaunchKernelGGL(plm_build_lists_kernel, dim3(ceil_div(nt, 128)), dim3(128), 0, ctx->stream,
                                ctx->dX, dDom, dLists, dOffs, N, L, Ls, q, halo, numScatChunks);
@@ -961,7 +1000,7 @@ struct PlmEngine : PlmEngineBase {
         {
             ScopedKernelClock kc(ctx, "plm_expand");
             hipLaunchKernelGGL(plm_expand_kernel<T>, dim3((unsigned)npairs), dim3(256), (size_t)q * q * sizeof(T), st,
-                               dx, dWt, dPairs, L, q, Cs);
+                               dx, dWt, dPairs, dPerm, L, q, Cs);
         }
         {
             constexpr int CT = Geo<T>::CT;
@@ -988,13 +1027,18 @@ struct PlmEngine : PlmEngineBase {
             constexpr int CW = 64 * (8 / (int)sizeof(T));
             const int numCT = Cs / CW;
             const int numJG = ceil_div(L, W * JW);
-            const int blocks = kNumXcd * ceil_div(numCT, kNumXcd) * numJG;
+            // groups per XCD: all column tiles (one tile per workgroup) by default;
+            // DCA_SCATTER_GROUPS=n makes the grid persistent with n groups per XCD
+            const int maxGroups = ceil_div(numCT, kNumXcd);
+            int groups = maxGroups;
+            if (const char* e = getenv("DCA_SCATTER_GROUPS")) groups = std::max(1, std::min(maxGroups, atoi(e)));
+            const int blocks = kNumXcd * groups * numJG;
             const size_t lds = (size_t)(kNC + 1) * kRowBytes;
             auto kern = plm_scatter_kernel<T, Q, JW, W>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ScopedKernelClock kc(ctx, "plm_scatter");
             hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(W * 64), lds, st, dSR, dLists, dOffs, dDom, dZeros, dG, N, L, Cs, halo,
-                               numScatChunks, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs,
+                               numScatChunks, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs, groups,
                                getenv("DCA_SCATTER_ABLATE") ? atoi(getenv("DCA_SCATTER_ABLATE")) : 0);
             if (scatSplit > 1)
                 hipLaunchKernelGGL(plm_sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, st, dG, (size_t)Grows * Cs, scatSplit);
