@@ -92,8 +92,8 @@ int dca_create(dca_ctx** out, int device, int precision)
     ctx->device = device;
     ctx->precision = precision;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dScal), 16 * sizeof(double)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->hScal), 16 * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dScal), 64 * sizeof(double)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->hScal), 64 * sizeof(double), hipHostMallocDefault));
     *out = ctx;
     return DCA_OK;
 }
