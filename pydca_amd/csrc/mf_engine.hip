@@ -19,36 +19,94 @@ __host__ __device__ __forceinline__ size_t pair_index(int L, int i, int j)
     return (size_t)L * (L - 1) / 2 - (size_t)(L - i) * (L - i - 1) / 2 + (size_t)(j - i - 1);
 }
 
-// thread = site: stable counting sort of the sequences by their state at that site
-__global__ void mf_site_sort_kernel(const uint8_t* __restrict__ X, uint32_t* __restrict__ perm, int* __restrict__ off,
-                                    int N, int L, int Ls, int q)
+// XT[i][n] = X[n][i]  (64x64 byte tiles through LDS; makes per-site passes coalesced)
+__global__ __launch_bounds__(256)
+void mf_transpose_kernel(const uint8_t* __restrict__ X, uint8_t* __restrict__ XT, int N, int L, int Ls, int Nt)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L) return;
-    int cnt[32], pos[32];
-    for (int b = 0; b < q; ++b) cnt[b] = 0;
-    for (int n = 0; n < N; ++n) cnt[X[(size_t)n * Ls + i]]++;
-    int run = 0;
-    for (int b = 0; b < q; ++b) { off[i * (q + 1) + b] = run; pos[b] = run; run += cnt[b]; }
-    off[i * (q + 1) + q] = run;
+    __shared__ uint8_t tile[64][65];
+    const int n0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int r = e / 64, c = e % 64;                 // r: sequence, c: site
+        const int n = n0 + r, i = i0 + c;
+        tile[r][c] = (n < N && i < L) ? X[(size_t)n * Ls + i] : (uint8_t)0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int c = e / 64, r = e % 64;
+        const int n = n0 + r, i = i0 + c;
+        if (i < L && n < Nt) XT[(size_t)i * Nt + n] = tile[r][c];
+    }
+}
+
+// One workgroup per site: stable counting sort of the sequences by their state at that site
+// (ascending n inside a state), dominant state, and the weighted single-site counts
+// cnt1[i][b] = sum_{n : x_ni = b} w_n summed in ascending n (deterministic).
+// Thread t owns the contiguous segment of sequences [t*seg, (t+1)*seg).
+constexpr int kSortThreads = 256;
+
+__global__ __launch_bounds__(kSortThreads)
+void mf_site_sort_kernel(const uint8_t* __restrict__ XT, const double* __restrict__ w, uint32_t* __restrict__ perm,
+                         int* __restrict__ off, uint8_t* __restrict__ dom, double* __restrict__ cnt1,
+                         int N, int Nt, int q)
+{
+    __shared__ int cnts[32][kSortThreads + 1];
+    __shared__ int base[33];
+    const int i = blockIdx.x, t = threadIdx.x;
+    const int seg = (N + kSortThreads - 1) / kSortThreads;
+    const int nb = min(N, t * seg), ne = min(N, (t + 1) * seg);
+    const uint8_t* col = XT + (size_t)i * Nt;
+    int local[32];
+    for (int b = 0; b < q; ++b) local[b] = 0;
+    for (int n = nb; n < ne; ++n) local[col[n]]++;
+    for (int b = 0; b < q; ++b) cnts[b][t] = local[b];
+    __syncthreads();
+    if (t < q) {              // exclusive scan over the threads for state t
+        int run = 0;
+        for (int k = 0; k < kSortThreads; ++k) { const int c = cnts[t][k]; cnts[t][k] = run; run += c; }
+        cnts[t][kSortThreads] = run;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int run = 0, best = 0;
+        for (int b = 0; b < q; ++b) {
+            base[b] = run; run += cnts[b][kSortThreads];
+            if (cnts[b][kSortThreads] > cnts[best][kSortThreads]) best = b;
+        }
+        base[q] = run;
+        for (int b = 0; b <= q; ++b) off[i * (q + 1) + b] = base[b];
+        dom[i] = (uint8_t)best;
+    }
+    __syncthreads();
     uint32_t* p = perm + (size_t)i * N;
-    for (int n = 0; n < N; ++n) { const int b = X[(size_t)n * Ls + i]; p[pos[b]++] = (uint32_t)n; }
+    for (int b = 0; b < q; ++b) local[b] = base[b] + cnts[b][t];
+    for (int n = nb; n < ne; ++n) p[local[col[n]]++] = (uint32_t)n;
+    __syncthreads();
+    if (t < q) {              // weighted count of state t, ascending n
+        double s = 0.0;
+        for (int k = base[t]; k < base[t + 1]; ++k) s += w[p[k]];
+        cnt1[i * q + t] = s;
+    }
 }
 
 constexpr int kCountThreads = 256;
 
-// one workgroup per (site i, state a) row of Craw
+// One workgroup per (site i, state a): the upper-triangle part of row (i,a) of Craw,
+// Craw[(i,a)][(j,b)] for j > i.  Rows of the site's dominant state are skipped here and
+// completed by mf_complete_kernel from the single-site counts:
+// sum_a Craw[(i,a)][(j,b)] = cnt1[j][b].
 __global__ __launch_bounds__(kCountThreads)
 void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ w, const uint32_t* __restrict__ perm,
-                      const int* __restrict__ off, double* __restrict__ Craw, int N, int L, int Ls, int q, int ldc)
+                      const int* __restrict__ off, const uint8_t* __restrict__ dom, double* __restrict__ Craw,
+                      int N, int L, int Ls, int q, int ldc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
     double* hist = reinterpret_cast<double*>(dca_smem);       // [q][kCountThreads]
     const int i = blockIdx.x / q, a = blockIdx.x % q;
+    if (a == dom[i] || i == L - 1) return;
     const int k0 = off[i * (q + 1) + a], k1 = off[i * (q + 1) + a + 1];
     const uint32_t* p = perm + (size_t)i * N;
     const int t = threadIdx.x;
-    for (int j0 = 0; j0 < L; j0 += kCountThreads) {
+    for (int j0 = i + 1; j0 < L; j0 += kCountThreads) {
         const int j = j0 + t;
         for (int b = 0; b < q; ++b) hist[b * kCountThreads + t] = 0.0;
         if (j < L) {
@@ -60,6 +118,36 @@ void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ 
             double* dst = Craw + (size_t)(i * q + a) * ldc + (size_t)j * q;
             for (int b = 0; b < q; ++b) dst[b] = hist[b * kCountThreads + t];
         }
+    }
+}
+
+// Completes Craw: dominant-state rows by complement, diagonal blocks from the single-site
+// counts, lower triangle by mirroring.  One workgroup per site pair (i <= j).
+__global__ __launch_bounds__(64)
+void mf_complete_kernel(double* __restrict__ Craw, const double* __restrict__ cnt1, const uint8_t* __restrict__ dom,
+                        int L, int q, int ldc)
+{
+    const int i = blockIdx.y, j = blockIdx.x;
+    if (j < i) return;
+    const int t = threadIdx.x;
+    if (i == j) {
+        for (int e = t; e < q * q; e += 64) {
+            const int a = e / q, b = e % q;
+            Craw[(size_t)(i * q + a) * ldc + i * q + b] = (a == b) ? cnt1[i * q + a] : 0.0;
+        }
+        return;
+    }
+    const int da = dom[i];
+    if (t < q) {              // column b = t of the block: dominant row = cnt1[j][b] - sum of the others
+        double s = 0.0;
+        for (int a = 0; a < q; ++a)
+            if (a != da) s += Craw[(size_t)(i * q + a) * ldc + (size_t)j * q + t];
+        Craw[(size_t)(i * q + da) * ldc + (size_t)j * q + t] = cnt1[j * q + t] - s;
+    }
+    __syncthreads();
+    for (int e = t; e < q * q; e += 64) {
+        const int a = e / q, b = e % q;
+        Craw[(size_t)(j * q + b) * ldc + (size_t)i * q + a] = Craw[(size_t)(i * q + a) * ldc + (size_t)j * q + b];
     }
 }
 
@@ -147,9 +235,11 @@ struct MfEngine {
     int N, L, q, Ls, Lq, n, np;
     uint32_t* dPerm = nullptr;
     int* dOff = nullptr;
+    uint8_t *dXT = nullptr, *dDom = nullptr;
+    double* dCnt1 = nullptr;
     double *dCraw = nullptr, *dFi = nullptr, *dC = nullptr, *dJ = nullptr, *dWork = nullptr;
     bool have_counts = false, have_corr = false, have_J = false;
-    ~MfEngine() { hipFree(dPerm); hipFree(dOff); hipFree(dCraw); hipFree(dFi); hipFree(dC); hipFree(dJ); hipFree(dWork); }
+    ~MfEngine() { hipFree(dPerm); hipFree(dOff); hipFree(dXT); hipFree(dDom); hipFree(dCnt1); hipFree(dCraw); hipFree(dFi); hipFree(dC); hipFree(dJ); hipFree(dWork); }
 };
 
 MfEngine* dca_make_mf_engine(dca_ctx* ctx)
@@ -168,19 +258,30 @@ static int mf_counts(MfEngine* m)
     if (m->have_counts) return DCA_OK;
     dca_ctx* ctx = m->ctx;
     if (m->q > 32) { dca_set_error("q too large"); return DCA_ERR_ARG; }
+    const int Nt = (int)round_up((size_t)m->N, 64);
     if (!m->dPerm) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dPerm), (size_t)m->L * m->N * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dOff), (size_t)m->L * (m->q + 1) * sizeof(int)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dCraw), (size_t)m->Lq * m->Lq * sizeof(double)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dFi), (size_t)m->Lq * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dXT), (size_t)m->L * Nt));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dDom), (size_t)m->L));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dCnt1), (size_t)m->Lq * sizeof(double)));
     }
-    hipLaunchKernelGGL(mf_site_sort_kernel, dim3(ceil_div(m->L, 64)), dim3(64), 0, ctx->stream, ctx->dX, m->dPerm, m->dOff,
-                       m->N, m->L, m->Ls, m->q);
+    {
+        ScopedKernelClock kc(ctx, "mf_sort");
+        hipLaunchKernelGGL(mf_transpose_kernel, dim3(ceil_div(m->N, 64), ceil_div(m->L, 64)), dim3(256), 0, ctx->stream,
+                           ctx->dX, m->dXT, m->N, m->L, m->Ls, Nt);
+        hipLaunchKernelGGL(mf_site_sort_kernel, dim3(m->L), dim3(kSortThreads), 0, ctx->stream, m->dXT, ctx->dWd, m->dPerm,
+                           m->dOff, m->dDom, m->dCnt1, m->N, Nt, m->q);
+    }
     {
         ScopedKernelClock kc(ctx, "mf_counts");
         const size_t lds = (size_t)m->q * kCountThreads * sizeof(double);
         hipLaunchKernelGGL(mf_counts_kernel, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, ctx->dX, ctx->dWd,
-                           m->dPerm, m->dOff, m->dCraw, m->N, m->L, m->Ls, m->q, m->Lq);
+                           m->dPerm, m->dOff, m->dDom, m->dCraw, m->N, m->L, m->Ls, m->q, m->Lq);
+        hipLaunchKernelGGL(mf_complete_kernel, dim3(m->L, m->L), dim3(64), 0, ctx->stream, m->dCraw, m->dCnt1, m->dDom,
+                           m->L, m->q, m->Lq);
     }
     hipLaunchKernelGGL(mf_fi_kernel, dim3(ceil_div(m->Lq, 256)), dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->Lq, m->Lq, ctx->meff);
     HIP_TRY(hipGetLastError());

@@ -6,8 +6,8 @@
 // ident = 0..L and turned into an integer threshold T: the kernel is integer-exact.
 //
 // Integer/byte work, VALU-bound (N^2 L byte compares against N L bytes of input):
-// 64x64 sequence tiles, rows staged in LDS as dwords (4 sites), a 4x4 register block per
-// thread, mismatches counted with xor / add 0x7f7f7f7f / and 0x80808080 / popcount
+// 64x64 sequence tiles (upper triangle of tile pairs only), rows staged in LDS as dwords
+// (4 sites), a 4x4 register block per thread, mismatches counted with xor / add 0x7f7f7f7f / and 0x80808080 / popcount
 // (states are < 32 so bytes never carry).
 #include "dca_internal.h"
 
@@ -22,8 +22,14 @@ void weights_count_kernel(const uint8_t* __restrict__ X, uint32_t* __restrict__ 
 {
     __shared__ uint32_t sA[kTile * kLdsStride];
     __shared__ uint32_t sB[kTile * kLdsStride];
+    __shared__ unsigned sCol[kTile];
+    // identity is symmetric: only tile pairs with column tile >= row tile are computed; an
+    // off-diagonal tile also credits its columns' sequences (rows of the mirrored tile)
+    if (blockIdx.x < blockIdx.y) return;
+    const bool offDiag = blockIdx.x > blockIdx.y;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int rowBase = blockIdx.y * kTile, colBase = blockIdx.x * kTile;
+    if (threadIdx.x < kTile) sCol[threadIdx.x] = 0;
     const int dwords = Ls / 4;
     unsigned mism[4][4];
 #pragma unroll
@@ -71,6 +77,21 @@ void weights_count_kernel(const uint8_t* __restrict__ X, uint32_t* __restrict__ 
         for (int off = 8; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
         const int n = rowBase + ty + 16 * r;
         if (tx == 0 && n < N && cnt) atomicAdd(&counts[n], cnt);
+    }
+    if (offDiag) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned cnt = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = rowBase + ty + 16 * r;
+                if (n < N && (int)(L - mism[r][c]) >= thresh) cnt++;
+            }
+            if (cnt) atomicAdd(&sCol[tx + 16 * c], cnt);     // integer LDS atomics: order-independent
+        }
+        __syncthreads();
+        const int m = colBase + threadIdx.x;
+        if (threadIdx.x < kTile && m < N && sCol[threadIdx.x]) atomicAdd(&counts[m], sCol[threadIdx.x]);
     }
 }
 

@@ -278,7 +278,7 @@ def test_mf_stages_vs_reference(L_, tag):
     ctx = _mf_ctx(L_, X1, q, seqid)
     np.testing.assert_array_equal(ctx.weights(), G["w"])
     np.testing.assert_allclose(ctx.mf_single_site_freqs(), G["fi"], rtol=1e-13, atol=1e-16)
-    np.testing.assert_allclose(ctx.mf_pair_site_freqs(), G["fij"], rtol=1e-12, atol=1e-16)
+    np.testing.assert_allclose(ctx.mf_pair_site_freqs(), G["fij"], rtol=1e-12, atol=1e-15)   # dominant-state rows come from a complement (rounding ~1e-16 of the column total)
     np.testing.assert_allclose(ctx.mf_corr_mat(theta), G["corr_mat"], rtol=1e-11, atol=1e-15)
     np.testing.assert_allclose(ctx.mf_couplings(), G["couplings"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(ctx.mf_corr_from_freqs(G["reg_fi"], G["reg_fij"], X1.shape[1], q), G["corr_mat"],
