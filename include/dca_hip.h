@@ -131,6 +131,12 @@ int dca_plm_lbfgs_iterate(dca_ctx* ctx, int iterations, dca_plm_stats* stats_out
  * order (0,1),(0,2)...; sorting is left to the host. */
 int dca_plm_scores(dca_ctx* ctx, int apc, double* scores_out);
 
+/* Direct-information scores of the current x (PlmDCA.compute_direct_info_unsorted_DI /
+ * compute_sorted_DI[_APC], plmdca.py:683-790, numerics plmdca/msa_numerics.py:156-311) in pair
+ * order.  reg_fi: L*q regularised single-site frequencies (the reference computes them from
+ * its Python reader's alignment with pseudocount 0.5, plmdca.py:622-648). */
+int dca_plm_di_scores(dca_ctx* ctx, const double* reg_fi, int apc, double* scores_out);
+
 /* ------------------------------------------------------------------ mfDCA
  * Stage functions mirror pydca/meanfield_dca/msa_numerics.py; all float64. */
 int dca_mf_single_site_freqs(dca_ctx* ctx, double* fi_out /* L*q, gap last (:53-89) */);
@@ -141,6 +147,9 @@ int dca_mf_corr_mat(dca_ctx* ctx, double pseudocount, double* corr_out /* may be
 int dca_mf_couplings(dca_ctx* ctx, double* couplings_out /* may be NULL */);
 /* FN / FN_APC of the couplings (meanfield_dca.py:902-988), pair order */
 int dca_mf_scores(dca_ctx* ctx, int apc, double* scores_out);
+/* DI / DI_APC of the couplings (meanfield_dca.py:793-899; msa_numerics.py:378-533), pair order;
+ * needs dca_mf_corr_mat + dca_mf_couplings (or dca_mf_run) first */
+int dca_mf_di_scores(dca_ctx* ctx, int apc, double* scores_out);
 /* whole chain on the device: counts -> C -> -inv -> scores */
 int dca_mf_run(dca_ctx* ctx, double pseudocount, int apc, double* scores_out, double* couplings_out /* may be NULL */);
 /* stage API on caller-provided arrays: construct_corr_mat (:270-318) from regularised

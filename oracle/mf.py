@@ -4,7 +4,9 @@ and of the FN / APC scoring shared by both paths.
 Reference (relative to /root/reference/pydca/):
   meanfield_dca/msa_numerics.py  (weights :13-50, f_i :53-125, f_ij :182-267,
                                   corr mat :270-318, couplings :321-342)
-  meanfield_dca/meanfield_dca.py (FN :902-943, APC :946-988)
+  meanfield_dca/msa_numerics.py  (two-site fields :378-470, DI :473-533; plmDCA twin
+                                  plmdca/msa_numerics.py :156-311)
+  meanfield_dca/meanfield_dca.py (FN :902-943, APC :946-988, DI :793-899)
   plmdca/plmdca.py               (gap stripping :246-268, FN :437-481, APC :484-524)
   fasta_reader/fasta_reader.py   (letter->int :34-45,:122-163)
 
@@ -195,3 +197,67 @@ def mfdca_fn(alignment_data, num_site_states, pseudocount, seqid, weights=None, 
 def plm_fn(x, L, q, apc_correct=True, dtype=np.float64):
     fn = frobenius_from_blocks(plm_blocks(np.asarray(x, dtype=dtype), L, q))
     return apc(fn, L) if apc_correct else fn
+
+
+def two_site_model_fields(blocks, reg_fi, L, q, tol=1.0e-4):
+    """compute_two_site_model_fields (meanfield_dca/msa_numerics.py:378-470, plmdca twin
+    :156-246): per pair, E = exp(J_ij) with the gap row/column of J zero; iterate
+    h_i <- f_i / (E h_j), h_j <- f_j / (E^T h_i) (both from the OLD fields), normalise,
+    until the largest absolute change is <= tol.  blocks: [pairs, q-1, q-1] (i<j order).
+    Vectorised over pairs with a per-pair 'still iterating' mask so every pair stops at
+    its own iteration exactly as the reference's per-pair while loop does."""
+    iu, ju = np.triu_indices(L, k=1)
+    P = len(iu)
+    E = np.ones((P, q, q), dtype=np.float64)
+    E[:, :q - 1, :q - 1] = np.exp(np.asarray(blocks, dtype=np.float64))
+    fi, fj = reg_fi[iu], reg_fi[ju]
+    hi = np.full((P, q), 1.0 / q)
+    hj = np.full((P, q), 1.0 / q)
+    active = np.arange(P)
+    while active.size:
+        Ea, hia, hja = E[active], hi[active], hj[active]
+        xi = np.einsum("pab,pb->pa", Ea, hja)
+        xj = np.einsum("pab,pa->pb", Ea, hia)
+        ni = fi[active] / xi
+        ni /= ni.sum(axis=1, keepdims=True)
+        nj = fj[active] / xj
+        nj /= nj.sum(axis=1, keepdims=True)
+        change = np.maximum(np.abs(ni - hia).max(axis=1), np.abs(nj - hja).max(axis=1))
+        hi[active], hj[active] = ni, nj
+        active = active[change > tol]
+    return E, hi, hj
+
+
+def direct_info(blocks, reg_fi, L, q):
+    """compute_direct_info (meanfield_dca/msa_numerics.py:473-533; plmdca twin :249-311):
+    P_dir = E * h_i h_j^T / sum; DI = sum_{a,b<q-1} (P+eps) log((P+eps)/(f_i f_j+eps))."""
+    eps = 1.0e-20
+    iu, ju = np.triu_indices(L, k=1)
+    E, hi, hj = two_site_model_fields(blocks, reg_fi, L, q)
+    pdir = E * hi[:, :, None] * hj[:, None, :]
+    pdir /= pdir.sum(axis=(1, 2), keepdims=True)
+    pdir += eps
+    fifj = reg_fi[iu][:, :, None] * reg_fi[ju][:, None, :] + eps
+    val = pdir * np.log(pdir / fifj)
+    return val[:, :q - 1, :q - 1].sum(axis=(1, 2))
+
+
+def mfdca_di(alignment_data, num_site_states, pseudocount, seqid, weights=None, apc_correct=False):
+    """MeanFieldDCA.compute_sorted_DI[_APC] chain (meanfield_dca.py:793-899), pair order."""
+    X = np.asarray(alignment_data)
+    N, L = X.shape
+    q = num_site_states
+    if weights is None:
+        weights = compute_sequences_weight(X, seqid) if seqid < 1.0 else np.ones(N)
+    fi = get_reg_single_site_freqs(compute_single_site_freqs(X, q, weights), L, q, pseudocount)
+    fij = get_reg_pair_site_freqs(compute_pair_site_freqs(X, q, weights), L, q, pseudocount)
+    J = compute_couplings(construct_corr_mat(fi, fij, L, q))
+    di = direct_info(mf_blocks(J, L, q), fi, L, q)
+    return apc(di, L) if apc_correct else di
+
+
+def plm_di(x, reg_fi, L, q, apc_correct=False):
+    """PlmDCA.compute_sorted_DI[_APC] (plmdca.py:683-790) on a packed vector; the reference
+    widens the float32 couplings to float64 before exp."""
+    di = direct_info(plm_blocks(np.asarray(x), L, q).astype(np.float64), reg_fi, L, q)
+    return apc(di, L) if apc_correct else di

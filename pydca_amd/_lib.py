@@ -79,6 +79,8 @@ def lib():
         "dca_plm_lbfgs_begin": (i, [vp, i, i]),
         "dca_plm_lbfgs_iterate": (i, [vp, i, C.POINTER(PlmStats)]),
         "dca_plm_scores": (i, [vp, i, vp]),
+        "dca_plm_di_scores": (i, [vp, vp, i, vp]),
+        "dca_mf_di_scores": (i, [vp, i, vp]),
         "dca_mf_single_site_freqs": (i, [vp, vp]),
         "dca_mf_pair_site_freqs": (i, [vp, vp]),
         "dca_mf_corr_mat": (i, [vp, d, vp]),
@@ -106,7 +108,8 @@ EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_read_msa", 
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_num_params", "dca_plm_init_x",
            "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook",
-           "dca_plm_lbfgs_begin", "dca_plm_lbfgs_iterate", "dca_plm_scores", "dca_mf_single_site_freqs",
+           "dca_plm_lbfgs_begin", "dca_plm_lbfgs_iterate", "dca_plm_scores", "dca_plm_di_scores",
+           "dca_mf_di_scores", "dca_mf_single_site_freqs",
            "dca_mf_pair_site_freqs", "dca_mf_corr_mat", "dca_mf_couplings", "dca_mf_scores", "dca_mf_run",
            "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_set_profiling", "dca_get_kernel_time",
            "dca_reset_kernel_times", "plmdcaBackend", "freeFieldsAndCouplings"]
@@ -245,7 +248,20 @@ class Context:
         check(self._l.dca_plm_scores(self._h, int(bool(apc)), _ptr(out)))
         return out
 
+    def plm_di_scores(self, reg_fi, apc=False):
+        reg_fi = np.ascontiguousarray(reg_fi, dtype=np.float64)
+        if reg_fi.shape != (self.L, self.q):
+            raise ValueError("reg_fi must be L x q")
+        out = np.zeros(self.L * (self.L - 1) // 2, dtype=np.float64)
+        check(self._l.dca_plm_di_scores(self._h, _ptr(reg_fi), int(bool(apc)), _ptr(out)))
+        return out
+
     # ---- mfDCA
+    def mf_di_scores(self, apc=False):
+        out = np.zeros(self.L * (self.L - 1) // 2, dtype=np.float64)
+        check(self._l.dca_mf_di_scores(self._h, int(bool(apc)), _ptr(out)))
+        return out
+
     def mf_single_site_freqs(self):
         out = np.zeros((self.L, self.q), dtype=np.float64)
         check(self._l.dca_mf_single_site_freqs(self._h, _ptr(out)))

@@ -215,6 +215,13 @@ int dca_plm_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user)
 int dca_plm_lbfgs_begin(dca_ctx* ctx, int max_iterations, int verbose) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->lbfgs_begin(max_iterations, verbose); }
 int dca_plm_lbfgs_iterate(dca_ctx* ctx, int iterations, dca_plm_stats* st) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->lbfgs_iterate(iterations, st); }
 int dca_plm_scores(dca_ctx* ctx, int apc, double* out) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->scores(apc, out); }
+int dca_plm_di_scores(dca_ctx* ctx, const double* reg_fi, int apc, double* out)
+{
+    CHECK_CTX(ctx);
+    DCA_TRY(need_plm(ctx));
+    if (!reg_fi || !out) return DCA_ERR_ARG;
+    return ctx->plm->di_scores(reg_fi, apc, out);
+}
 
 // ------------------------------------------------------------------ mfDCA
 static int need_mf(dca_ctx* ctx)
@@ -229,6 +236,7 @@ int dca_mf_pair_site_freqs(dca_ctx* ctx, double* fij_out) { CHECK_CTX(ctx); DCA_
 int dca_mf_corr_mat(dca_ctx* ctx, double pseudocount, double* corr_out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_corr(ctx->mf, pseudocount, corr_out); }
 int dca_mf_couplings(dca_ctx* ctx, double* out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_couplings(ctx->mf, out); }
 int dca_mf_scores(dca_ctx* ctx, int apc, double* out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_scores(ctx->mf, apc, out); }
+int dca_mf_di_scores(dca_ctx* ctx, int apc, double* out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_di(ctx->mf, apc, out); }
 int dca_mf_run(dca_ctx* ctx, double pseudocount, int apc, double* scores_out, double* couplings_out)
 {
     CHECK_CTX(ctx);

@@ -115,6 +115,7 @@ struct PlmEngineBase {
     virtual int lbfgs_begin(int max_iterations, int verbose) = 0;
     virtual int lbfgs_iterate(int iterations, dca_plm_stats* st) = 0;
     virtual int scores(int apc, double* out) = 0;
+    virtual int di_scores(const double* reg_fi, int apc, double* out) = 0;
     dca_reduce_hook hook = nullptr;
     void* hook_user = nullptr;
 };
@@ -126,6 +127,9 @@ PlmEngineBase* dca_make_plm_engine(dca_ctx* ctx);
 int dca_fn_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L, int q, int ld,
                   int apc, double* dScoresOut /* device, pairs */);
 
+int dca_di_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, const double* dRegFi, int L, int q, int ld,
+                  int apc, double* dScoresOut /* device, pairs */);
+
 // ---- mf engine
 struct MfEngine;
 MfEngine* dca_make_mf_engine(dca_ctx* ctx);
@@ -135,6 +139,7 @@ int dca_mf_engine_pair_freqs(MfEngine*, double* fij_out);
 int dca_mf_engine_corr(MfEngine*, double theta, double* corr_out);
 int dca_mf_engine_couplings(MfEngine*, double* out);
 int dca_mf_engine_scores(MfEngine*, int apc, double* out);
+int dca_mf_engine_di(MfEngine*, int apc, double* out);
 
 // ---- cholinv.hip : in-place inverse of an SPD matrix on the device (f64 MFMA)
 // dA: n x n row-major (ld = n), n multiple of 64.  On return dA holds inv(A) (full, symmetric).

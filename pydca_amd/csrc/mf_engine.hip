@@ -239,7 +239,9 @@ struct MfEngine {
     double* dCnt1 = nullptr;
     double *dCraw = nullptr, *dFi = nullptr, *dC = nullptr, *dJ = nullptr, *dWork = nullptr;
     bool have_counts = false, have_corr = false, have_J = false;
-    ~MfEngine() { hipFree(dPerm); hipFree(dOff); hipFree(dXT); hipFree(dDom); hipFree(dCnt1); hipFree(dCraw); hipFree(dFi); hipFree(dC); hipFree(dJ); hipFree(dWork); }
+    double theta = 0.0;
+    double* dRegFi = nullptr;
+    ~MfEngine() { hipFree(dRegFi); hipFree(dPerm); hipFree(dOff); hipFree(dXT); hipFree(dDom); hipFree(dCnt1); hipFree(dCraw); hipFree(dFi); hipFree(dC); hipFree(dJ); hipFree(dWork); }
 };
 
 MfEngine* dca_make_mf_engine(dca_ctx* ctx)
@@ -331,6 +333,7 @@ int dca_mf_engine_corr(MfEngine* m, double theta, double* corr_out)
     HIP_TRY(hipGetLastError());
     m->have_corr = true;
     m->have_J = false;
+    m->theta = theta;
     if (corr_out) return copy_out_square(m, m->dC, corr_out);
     return DCA_OK;
 }
@@ -399,5 +402,34 @@ extern "C" int dca_mf_corr_from_freqs(dca_ctx* ctx, const double* reg_fi, const 
         if (e != hipSuccess) { dca_set_error("corr_from_freqs: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
     }
     hipFree(dFi); hipFree(dFij); hipFree(dC);
+    return rc;
+}
+
+namespace {
+// (1 - theta) f + theta / q   (get_reg_single_site_freqs, msa_numerics.py:92-125)
+__global__ void mf_regfi_kernel(const double* __restrict__ fi, double* __restrict__ reg, int Lq, int q, double theta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < Lq) reg[c] = theta / (double)q + (1.0 - theta) * fi[c];
+}
+}  // namespace
+
+// DI / DI_APC of the mean-field couplings (meanfield_dca.py:793-899)
+int dca_mf_engine_di(MfEngine* m, int apc, double* out)
+{
+    if (!m->have_J) { dca_set_error("dca_mf_couplings first"); return DCA_ERR_STATE; }
+    dca_ctx* ctx = m->ctx;
+    if (!m->dRegFi) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dRegFi), (size_t)m->Lq * sizeof(double)));
+    hipLaunchKernelGGL(mf_regfi_kernel, dim3(ceil_div(m->Lq, 256)), dim3(256), 0, ctx->stream, m->dFi, m->dRegFi, m->Lq, m->q, m->theta);
+    const size_t npairs = (size_t)m->L * (m->L - 1) / 2;
+    double* dOut = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
+    int rc = dca_di_scores(ctx, m->dJ, 1, DCA_F64, m->dRegFi, m->L, m->q, m->np, apc, dOut);
+    if (rc == DCA_OK) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, dOut, npairs * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { dca_set_error("DI scores: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
+    }
+    hipFree(dOut);
     return rc;
 }

@@ -1373,6 +1373,25 @@ struct PlmEngine : PlmEngineBase {
         hipFree(dOut);
         return rc;
     }
+    // DI of the current x (plmdca.py:683-790); reg_fi: host, L*q regularised single-site frequencies
+    int di_scores(const double* reg_fi, int apc, double* out) override
+    {
+        if (!configured) return DCA_ERR_STATE;
+        const size_t npairs = (size_t)L * (L - 1) / 2;
+        double *dOut = nullptr, *dFi = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
+        if (hipMalloc(reinterpret_cast<void**>(&dFi), (size_t)L * q * sizeof(double)) != hipSuccess) { hipFree(dOut); return DCA_ERR_NOMEM; }
+        int rc = DCA_OK;
+        if (hipMemcpy(dFi, reg_fi, (size_t)L * q * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = DCA_ERR_HIP;
+        if (rc == DCA_OK) rc = dca_di_scores(ctx, dx, 0, (int)sizeof(T) * 8, dFi, L, q, 0, apc, dOut);
+        if (rc == DCA_OK) {
+            hipError_t e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = hipMemcpy(out, dOut, npairs * sizeof(double), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { dca_set_error("copy DI scores: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
+        }
+        hipFree(dOut); hipFree(dFi);
+        return rc;
+    }
 };
 
 }  // namespace

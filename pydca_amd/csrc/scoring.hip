@@ -116,6 +116,85 @@ __global__ void apc_apply_kernel(double* __restrict__ fn, const double* __restri
     }
 }
 
+// Direct information of one site pair (meanfield_dca/msa_numerics.py:378-533 and the plmDCA twin
+// plmdca/msa_numerics.py:156-311): two-site model fields by the reference's fixed-point iteration
+// (both fields updated from the old ones, stop when the largest change is <= 1e-4), direct
+// probability P_dir = exp(J_ij) h_i h_j / Z with the gap row/column of J set to 0, and
+// DI = sum over non-gap (a,b) of (P_dir + eps) log((P_dir + eps) / (f_i f_j + eps)), eps = 1e-20.
+template <typename S>
+__global__ __launch_bounds__(64)
+void di_kernel(const S* __restrict__ src, int kind, const double* __restrict__ regfi, int L, int q, int ld,
+               double* __restrict__ di)
+{
+    __shared__ double E[21 * 21];
+    __shared__ double fi[21], fj[21], hi[21], hj[21], ni[21], nj[21];
+    __shared__ double change;
+    const int qm = q - 1;
+    const size_t p = blockIdx.x;
+    int i = 0;
+    {
+        const double Ld = (double)L;
+        double t = (2.0 * Ld - 1.0 - sqrt((2.0 * Ld - 1.0) * (2.0 * Ld - 1.0) - 8.0 * (double)p)) / 2.0;
+        i = (int)t;
+        if (i < 0) i = 0;
+        if (i > L - 2) i = L - 2;
+        while (i > 0 && pair_index(L, i, i + 1) > p) --i;
+        while (i < L - 2 && pair_index(L, i + 1, i + 2) <= p) ++i;
+    }
+    const int j = (int)(p - pair_index(L, i, i + 1)) + i + 1;
+    const int t = threadIdx.x;
+    for (int e = t; e < q * q; e += 64) {
+        const int a = e / q, b = e % q;
+        double v = 0.0;
+        if (a < qm && b < qm) {
+            if (kind == 0) v = (double)src[(size_t)L * q + p * (size_t)q * q + (size_t)a * q + b];
+            else v = (double)src[(size_t)(i * qm + a) * ld + (size_t)j * qm + b];
+        }
+        E[e] = exp(v);
+    }
+    if (t < q) { fi[t] = regfi[i * q + t]; fj[t] = regfi[j * q + t]; hi[t] = hj[t] = 1.0 / (double)q; }
+    __syncthreads();
+    for (int iter = 0; iter < 100000; ++iter) {
+        if (t < q) {
+            double x = 0.0;
+            for (int b = 0; b < q; ++b) x += E[t * q + b] * hj[b];
+            ni[t] = fi[t] / x;
+        } else if (t >= 32 && t < 32 + q) {
+            const int b = t - 32;
+            double x = 0.0;
+            for (int a = 0; a < q; ++a) x += E[a * q + b] * hi[a];
+            nj[b] = fj[b] / x;
+        }
+        __syncthreads();
+        if (t == 0) {
+            double si = 0.0, sj = 0.0;
+            for (int a = 0; a < q; ++a) { si += ni[a]; sj += nj[a]; }
+            double mx = 0.0;
+            for (int a = 0; a < q; ++a) {
+                const double vi = ni[a] / si, vj = nj[a] / sj;
+                mx = fmax(mx, fmax(fabs(vi - hi[a]), fabs(vj - hj[a])));
+                hi[a] = vi; hj[a] = vj;
+            }
+            change = mx;
+        }
+        __syncthreads();
+        if (!(change > 1.0e-4)) break;
+    }
+    // direct probability and DI
+    double zpart = 0.0;
+    for (int e = t; e < q * q; e += 64) zpart += E[e] * hi[e / q] * hj[e % q];
+    for (int off = 32; off > 0; off >>= 1) zpart += __shfl_down(zpart, off);
+    const double Z = __shfl(zpart, 0);
+    double acc = 0.0;
+    for (int e = t; e < qm * qm; e += 64) {
+        const int a = e / qm, b = e % qm;
+        const double pd = E[a * q + b] * hi[a] * hj[b] / Z + 1.0e-20;
+        acc += pd * log(pd / (fi[a] * fj[b] + 1.0e-20));
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (t == 0) di[p] = acc;
+}
+
 }  // namespace
 
 int dca_fn_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L, int q, int ld, int apc, double* dOut)
@@ -127,6 +206,31 @@ int dca_fn_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L,
         hipLaunchKernelGGL(fn_kernel<float>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const float*>(src), src_kind, L, q, ld, dOut);
     else
         hipLaunchKernelGGL(fn_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const double*>(src), src_kind, L, q, ld, dOut);
+    if (apc) {
+        double* dAv = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dAv), (size_t)(L + 1) * sizeof(double)));
+        hipLaunchKernelGGL(apc_site_kernel, dim3(L), dim3(256), 0, ctx->stream, dOut, L, dAv);
+        hipLaunchKernelGGL(apc_mean_kernel, dim3(1), dim3(256), 0, ctx->stream, dAv, L, dAv + L);
+        hipLaunchKernelGGL(apc_apply_kernel, dim3(L - 1), dim3(256), 0, ctx->stream, dOut, dAv, dAv + L, L);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        hipFree(dAv);
+        if (e != hipSuccess) { dca_set_error("apc: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
+    }
+    HIP_TRY(hipGetLastError());
+    return DCA_OK;
+}
+
+// DI / DI_APC of coupling blocks; same source conventions as dca_fn_scores.  dRegFi: device, L*q.
+int dca_di_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, const double* dRegFi, int L, int q, int ld,
+                  int apc, double* dOut)
+{
+    if (q > 21) { dca_set_error("q too large for the DI kernel"); return DCA_ERR_ARG; }
+    const size_t npairs = (size_t)L * (L - 1) / 2;
+    ScopedKernelClock kc(ctx, "scores");
+    if (dtype == DCA_F32)
+        hipLaunchKernelGGL(di_kernel<float>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const float*>(src), src_kind, dRegFi, L, q, ld, dOut);
+    else
+        hipLaunchKernelGGL(di_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const double*>(src), src_kind, dRegFi, L, q, ld, dOut);
     if (apc) {
         double* dAv = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dAv), (size_t)(L + 1) * sizeof(double)));

@@ -193,7 +193,18 @@ class MeanFieldDCA:
         return self.__couplings
 
     def compute_sorted_DI(self, seqbackmapper=None):
-        raise NotImplementedError('DI scoring is the next row of the scope table (SURVEY 8f1); compute_fn is accelerated')
+        """meanfield_dca.py:793-845 (two-site model fields + direct information, msa_numerics.py:378-533,
+        one workgroup per site pair on the device)."""
+        if seqbackmapper is not None:
+            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
+        self._device_scores(False)
+        logger.info('\n\tComputing direct information')
+        return _ranked(self.__ctx.mf_di_scores(False), self.__sequences_len)
 
     def compute_sorted_DI_APC(self, seqbackmapper=None):
-        raise NotImplementedError('DI scoring is the next row of the scope table (SURVEY 8f1); compute_fn is accelerated')
+        """meanfield_dca.py:848-899."""
+        if seqbackmapper is not None:
+            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
+        self._device_scores(False)
+        logger.info('\n\tPerforming average product correction (APC) of DI scores')
+        return _ranked(self.__ctx.mf_di_scores(True), self.__sequences_len)

@@ -1,5 +1,5 @@
-"""`mfdca` command line (mirror of pydca/mfdca_main.py:310-394).  compute_fn runs on the GPU;
-the other sub-commands exist with the same flags and report that they are not accelerated yet."""
+"""`mfdca` command line (mirror of pydca/mfdca_main.py:310-394).  compute_fn and compute_di run on
+the GPU; the other sub-commands exist with the same flags and report that they are not accelerated yet."""
 import logging
 import os
 import sys
@@ -23,7 +23,7 @@ def execute_from_command_line(msa_file=None, biomolecule=None, seqid=None, pseud
         configure_logging()
     if refseq_file:
         raise NotImplementedError('--refseq_file (reference-sequence back-mapping) is outside the accelerated path')
-    if the_command.strip() != 'compute_fn':
+    if the_command.strip() not in ('compute_fn', 'compute_di'):
         raise NotImplementedError('{} is not part of the accelerated compute_fn path yet'.format(the_command))
     mfdca_instance = meanfield_dca.MeanFieldDCA(msa_file, biomolecule, pseudocount=pseudocount, seqid=seqid, device=device)
     param_metadata = dca_utilities.mfdca_param_metadata(mfdca_instance)
@@ -31,6 +31,17 @@ def execute_from_command_line(msa_file=None, biomolecule=None, seqid=None, pseud
         msa_file_base_name, _ext = os.path.splitext(os.path.basename(msa_file))
         output_dir = 'MFDCA_output_' + msa_file_base_name
     dca_utilities.create_directories(output_dir)
+    if the_command.strip() == 'compute_di':
+        if apc:
+            sorted_DI = mfdca_instance.compute_sorted_DI_APC()
+            score_type = ' MF DI average product corrected (APC)'
+            di_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='MFDCA_apc_di_scores_', postfix='.txt')
+        else:
+            sorted_DI = mfdca_instance.compute_sorted_DI()
+            score_type = 'raw DI'
+            di_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='MFDCA_raw_di_scores_', postfix='.txt')
+        dca_utilities.write_sorted_dca_scores(di_file_path, sorted_DI, metadata=param_metadata, score_type=score_type)
+        return di_file_path
     if apc:
         score_type = 'MFDCA Frobenius norm, average product corrected (APC)'
         sorted_FN = mfdca_instance.compute_sorted_FN_APC()

@@ -183,8 +183,42 @@ class PlmDCA:
         logger.info('\n\tPerforming average product correction (APC) of FN  of DCA scores')
         return _ranked(ctx.plm_scores(True), self.__seqs_len)
 
+    def get_single_site_freqs(self):
+        """plmdca.py:590-621: frequencies of the PYTHON reader's alignment (unknown letters -> gap,
+        duplicates dropped, fasta_reader.py:122-163) with float64 weights, on the device."""
+        from ..fasta_reader import fasta_reader
+        aln = np.array(fasta_reader.get_alignment_int_form(self.__msa_file, biomolecule=self.__biomolecule))
+        ctx = _lib.Context(self.__device, _lib.DCA_F64)
+        try:
+            ctx.set_msa((aln - 1).astype(np.uint8), self.__num_site_states)
+            ctx.compute_weights(self.__seqid, _lib.DCA_F64)
+            return ctx.mf_single_site_freqs()
+        finally:
+            ctx.close()
+
+    def get_reg_single_site_freqs(self):
+        """plmdca.py:624-648 (pseudocount fixed at 0.5 as in the reference)."""
+        from ..meanfield_dca import msa_numerics
+        return msa_numerics.get_reg_single_site_freqs(
+            single_site_freqs=self.get_single_site_freqs(), seqs_len=self.__seqs_len,
+            num_site_states=self.__num_site_states, pseudocount=0.5)
+
+    def compute_direct_info_unsorted_DI(self, apc=False):
+        """plmdca.py:683-720: DI in pair order from the optimised parameters left on the device."""
+        ctx = self._run_backend()
+        reg_fi = self.get_reg_single_site_freqs()
+        logger.info('\n\tComputing direct information')
+        return ctx.plm_di_scores(reg_fi, apc)
+
     def compute_sorted_DI(self, seqbackmapper=None):
-        raise NotImplementedError('DI scoring is the next row of the scope table (SURVEY 8f1); compute_fn is accelerated')
+        """plmdca.py:723-750."""
+        if seqbackmapper is not None:
+            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
+        return _ranked(self.compute_direct_info_unsorted_DI(False), self.__seqs_len)
 
     def compute_sorted_DI_APC(self, seqbackmapper=None):
-        raise NotImplementedError('DI scoring is the next row of the scope table (SURVEY 8f1); compute_fn is accelerated')
+        """plmdca.py:753-790."""
+        if seqbackmapper is not None:
+            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
+        logger.info('\n\tPerforming average product correction (APC) of DI scores')
+        return _ranked(self.compute_direct_info_unsorted_DI(True), self.__seqs_len)

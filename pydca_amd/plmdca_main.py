@@ -1,6 +1,6 @@
 """`plmdca` command line (mirror of pydca/plmdca_main.py:262-330): same sub-commands, flags,
-output directory and file names.  compute_fn runs on the GPU; compute_di / compute_params
-are the next rows of the scope table and say so."""
+output directory and file names.  compute_fn and compute_di run on the GPU; compute_params
+is the next row of the scope table and says so."""
 import logging
 import os
 import sys
@@ -45,6 +45,17 @@ def execute_from_command_line(biomolecule, msa_file, the_command=None, refseq_fi
                 fn_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='PLMDCA_raw_fn_scores_', postfix='.txt')
             dca_utilities.write_sorted_dca_scores(fn_file_path, sorted_FN, metadata=param_metadata, score_type=score_type)
             return fn_file_path
+        if the_command == 'compute_di':
+            if apc:
+                score_type = 'PLMDCA  DI scores, average product corrected (APC)'
+                sorted_DI = plmdca_instance.compute_sorted_DI_APC()
+                di_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='PLMDCA_apc_di_scores_', postfix='.txt')
+            else:
+                score_type = 'PLMDCA DI scores, non-APC (not average product corrected)'
+                sorted_DI = plmdca_instance.compute_sorted_DI()
+                di_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='PLMDCA_raw_di_scores_', postfix='.txt')
+            dca_utilities.write_sorted_dca_scores(di_file_path, sorted_DI, metadata=param_metadata, score_type=score_type)
+            return di_file_path
         raise NotImplementedError('{} is not part of the accelerated compute_fn path yet'.format(the_command))
     return None
 

@@ -175,10 +175,56 @@ def mf_golden(tag, path, bio, pseudocount, seqid, stages):
     return apc
 
 
+def pair_order(sorted_list, L):
+    """(pair, score) list -> scores in (0,1),(0,2),... order."""
+    d = {tuple(p): s for p, s in sorted_list}
+    return np.array([d[(i, j)] for i in range(L - 1) for j in range(i + 1, L)])
+
+
+def di_golden(tag, path, bio, pseudocount, seqid, plm_seqid=None):
+    """Direct-information goldens.  mfDCA: MeanFieldDCA.compute_sorted_DI[_APC] through the stubbed
+    import.  plmDCA: PlmDCA.compute_direct_info_unsorted_DI's body (plmdca.py:683-720) replayed with
+    the reference's own plmdca/msa_numerics functions on the couplings of the stored reference run
+    (plm_<tag>.npz run_a); the class itself cannot be imported without its compiled backend."""
+    from pydca.meanfield_dca import meanfield_dca
+    from pydca.plmdca import msa_numerics as plm_num
+    from pydca.fasta_reader.fasta_reader import get_alignment_int_form
+    inst = meanfield_dca.MeanFieldDCA(path, bio, pseudocount=pseudocount, seqid=seqid)
+    L, q = inst.sequences_len, inst.num_site_states
+    out = dict(L=L, q=q, pseudocount=pseudocount, seqid=seqid,
+               mf_di=pair_order(inst.compute_sorted_DI(), L), mf_di_apc=pair_order(inst.compute_sorted_DI_APC(), L))
+    g = np.load(os.path.join(HERE, "plm_%s.npz" % tag))
+    x = g["run_a"]
+    sid = float(g["seqid"]) if plm_seqid is None else plm_seqid
+    blocks = x[L * q:].reshape(L * (L - 1) // 2, q, q)[:, :q - 1, :q - 1]
+    couplings = np.array(blocks.reshape(-1))           # get_couplings_no_gap_state, plmdca.py:246-268
+    aln = np.array(get_alignment_int_form(path, biomolecule=bio))
+    w = plm_num.compute_sequences_weight(alignment_data=aln, sequence_identity=sid)
+    fi = plm_num.compute_single_site_freqs(alignment_data=aln, num_site_states=q, seqs_weight=w)
+    reg_fi = plm_num.get_reg_single_site_freqs(single_site_freqs=fi, seqs_len=L, num_site_states=q, pseudocount=0.5)
+    fields = plm_num.compute_two_site_model_fields(couplings=couplings, reg_fi=reg_fi, seqs_len=L, num_site_states=q)
+    di = plm_num.compute_direct_info(couplings=couplings, fields_ij=fields, reg_fi=reg_fi, seqs_len=L,
+                                     num_site_states=q)
+    out.update(plm_reg_fi=np.array(reg_fi), plm_fields=np.array(fields), plm_di=np.array(di), plm_seqid=sid)
+    np.savez_compressed(os.path.join(HERE, "di_%s.npz" % tag), **out)
+    print("di_%s: mf top %.6g  plm top %.6g" % (tag, out["mf_di"].max(), out["plm_di"].max()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-slow", action="store_true")
+    ap.add_argument("--only-di", action="store_true", help="regenerate only di_*.npz (needs plm_*.npz present)")
     args = ap.parse_args()
+    if args.only_di:
+        tmp = tempfile.mkdtemp(prefix="pydca_stubs_")
+        try:
+            install_stubs(tmp)
+            di_golden("toy_rna", os.path.join(DATA, "toy_rna.fa"), "rna", 0.5, 0.8)
+            di_golden("toy_protein", os.path.join(DATA, "toy_protein.fa"), "protein", 0.5, 0.8)
+            di_golden("rf71", os.path.join(DATA, "MSA_RF00167_trimmed71.fa"), "rna", 0.5, 0.8)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return
     os.makedirs(DATA, exist_ok=True)
     oplm.build(ref=True)
 
@@ -221,6 +267,9 @@ def main():
         mf_golden("toy_protein", toy_prot, "protein", 0.5, 0.8, stages=True)
         mf_golden("toy_rna_theta02_seqid1", toy_rna, "rna", 0.2, 1.0, stages=True)
         mf_golden("rf00167", rf, "rna", 0.5, 0.8, stages=False)
+        di_golden("toy_rna", toy_rna, "rna", 0.5, 0.8)
+        di_golden("toy_protein", toy_prot, "protein", 0.5, 0.8)
+        di_golden("rf71", rf71, "rna", 0.5, 0.8)
         if not args.skip_slow:
             mf_golden("pf02826", pf, "protein", 0.5, 0.8, stages=False)
     finally:

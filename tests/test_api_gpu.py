@@ -161,3 +161,35 @@ def test_reduce_hook_through_torch_distributed():
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_direct_information_through_the_classes(tmp_path):
+    """compute_sorted_DI[_APC] of both classes and the compute_di sub-commands."""
+    from pydca_amd import mfdca_main, plmdca_main
+    from pydca_amd.meanfield_dca.meanfield_dca import MeanFieldDCA
+    from pydca_amd.plmdca.plmdca import PlmDCA
+    G = golden("di_rf71")
+    L = int(G["L"])
+    f = data_file("MSA_RF00167_trimmed71.fa")
+    di = MeanFieldDCA(f, "rna", pseudocount=0.5, seqid=0.8).compute_sorted_DI()
+    order = np.argsort(-G["mf_di"], kind="stable")
+    iu, ju = np.triu_indices(L, k=1)
+    assert [p for p, _ in di[:L]] == [(int(iu[k]), int(ju[k])) for k in order[:L]]
+    np.testing.assert_allclose([s for _, s in di[:L]], G["mf_di"][order[:L]], rtol=1e-7)
+    # plmDCA: the regularised frequencies (python-reader alignment, pseudocount 0.5) are exact;
+    # the scores inherit the optimiser's float32 trajectory (P4 regime, like compute_fn)
+    T = golden("di_toy_rna")
+    inst = PlmDCA(data_file("toy_rna.fa"), "rna", seqid=0.8, lambda_h=1.8, lambda_J=1.8, max_iterations=100)
+    np.testing.assert_allclose(inst.get_reg_single_site_freqs(), T["plm_reg_fi"], rtol=1e-13)
+    pdi = inst.compute_sorted_DI()
+    ref_order = np.argsort(-T["plm_di"], kind="stable")
+    iu, ju = np.triu_indices(int(T["L"]), k=1)
+    assert [p for p, _ in pdi[:3]] == [(int(iu[k]), int(ju[k])) for k in ref_order[:3]]
+    assert abs(pdi[0][1] - T["plm_di"][ref_order[0]]) < 2e-2 * T["plm_di"][ref_order[0]]
+    assert len(inst.compute_sorted_DI_APC()) == 45
+    out = mfdca_main.run_meanfield_dca(["compute_di", "rna", data_file("toy_rna.fa"), "--apc", "--output_dir",
+                                        str(tmp_path / "m")])
+    assert os.path.basename(out) == "MFDCA_apc_di_scores_toy_rna.txt"
+    out = plmdca_main.run_plm_dca(["compute_di", "rna", data_file("toy_rna.fa"), "--max_iterations", "5",
+                                   "--output_dir", str(tmp_path / "p")])
+    assert os.path.basename(out) == "PLMDCA_raw_di_scores_toy_rna.txt"

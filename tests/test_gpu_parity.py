@@ -328,3 +328,57 @@ def test_spd_inverse_f64_mfma(L_, n):
     assert rel_err(inv, ref) < 1e-11
     assert np.array_equal(inv, inv.T)
     ctx.close()
+
+
+# ----------------------------------------------------------------------------- DI
+DI_TAGS = ["toy_rna", "toy_protein", "rf71"]
+
+
+@pytest.mark.parametrize("tag", DI_TAGS)
+def test_mf_direct_information_vs_reference(L_, oracle_mf, tag):
+    """mfdca compute_di: DI and DI_APC vs MeanFieldDCA.compute_sorted_DI[_APC] of the real reference
+    (golden).  The couplings differ from LAPACK's at ~1e-10, the fixed point stops at the same
+    iteration; tolerance 1e-7 relative per score (rtol) with identical top-L ranking."""
+    G, M = golden("di_" + tag), golden("mf_" + tag)
+    X1, q = M["X"], int(G["q"])
+    L = X1.shape[1]
+    ctx = _mf_ctx(L_, X1, q, float(G["seqid"]))
+    ctx.mf_run(float(G["pseudocount"]), False)
+    di = ctx.mf_di_scores(False)
+    np.testing.assert_allclose(di, G["mf_di"], rtol=1e-7, atol=1e-12)
+    assert np.array_equal(np.argsort(-di, kind="stable")[:L], np.argsort(-G["mf_di"], kind="stable")[:L])
+    np.testing.assert_allclose(ctx.mf_di_scores(True), G["mf_di_apc"], rtol=1e-6, atol=1e-10)
+    ctx.close()
+
+
+@pytest.mark.parametrize("tag", DI_TAGS)
+def test_plm_direct_information_vs_reference(L_, tag):
+    """plmdca compute_di numerics: DI of the reference's own optimised parameters (plm_<tag>.npz
+    run_a, float32) with the reference's regularised frequencies -> plmdca/msa_numerics.py's output
+    to 1e-9 relative (float64 arithmetic on both sides; only summation order differs)."""
+    G, P = golden("di_" + tag), golden("plm_" + tag)
+    L, q = int(G["L"]), int(G["q"])
+    ctx = make_ctx(L_, P["X"], q, L_.DCA_F32)
+    ctx.plm_configure(1.0, 1.0)
+    ctx.plm_set_x(P["run_a"])
+    di = ctx.plm_di_scores(G["plm_reg_fi"], False)
+    np.testing.assert_allclose(di, G["plm_di"], rtol=1e-9, atol=1e-14)
+    assert np.array_equal(np.argsort(-di, kind="stable"), np.argsort(-G["plm_di"], kind="stable"))
+    ctx.close()
+
+
+def test_di_kernel_random_blocks_vs_oracle(L_, oracle_mf):
+    """DI / DI_APC kernel on random parameters, float64 storage, protein and RNA sizes."""
+    rng = np.random.default_rng(5)
+    for (L, q) in ((9, 5), (12, 21)):
+        X = rng.integers(0, q, size=(30, L), dtype=np.uint8)
+        ctx = make_ctx(L_, X, q, L_.DCA_F64, 0.8, L_.DCA_F64)
+        ctx.plm_configure(1.0, 1.0)
+        x = 0.7 * rng.standard_normal(ctx.num_params())
+        ctx.plm_set_x(x)
+        fi = rng.random((L, q)) + 0.05
+        fi /= fi.sum(axis=1, keepdims=True)
+        for apc in (False, True):
+            np.testing.assert_allclose(ctx.plm_di_scores(fi, apc), oracle_mf.plm_di(x, fi, L, q, apc_correct=apc),
+                                       rtol=1e-10, atol=1e-13)
+        ctx.close()

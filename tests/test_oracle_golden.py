@@ -153,3 +153,41 @@ def test_reader_codes(oracle_plm):
     assert L.oracle_residue_code(2, ord("u")) == 3 and L.oracle_residue_code(2, ord("N")) == 4
     assert L.oracle_residue_code(1, ord("X")) == 20 and L.oracle_residue_code(1, ord("y")) == 19
     assert L.oracle_residue_code(1, ord("*")) == -1
+
+
+DI_CASES = [("toy_rna", "toy_rna.fa", "RNA"), ("toy_protein", "toy_protein.fa", "PROTEIN"),
+            ("rf71", "MSA_RF00167_trimmed71.fa", "RNA")]
+
+
+@pytest.mark.parametrize("tag,fname,bio", DI_CASES)
+def test_mf_direct_information_matches_reference(oracle_mf, tag, fname, bio):
+    """DI / DI_APC of the numpy restatement against MeanFieldDCA.compute_sorted_DI[_APC]
+    (meanfield_dca.py:793-899).  Tolerance 1e-9 relative on the score vector; the
+    fixed point stops at the same iteration as the reference (tolerance 1e-4 on the
+    change), so only summation order differs; the full ranking must be identical."""
+    g = golden("di_" + tag)
+    X = oracle_mf.letter2int(oracle_mf.read_fasta(data_file(fname)), bio)
+    L, q = int(g["L"]), int(g["q"])
+    di = oracle_mf.mfdca_di(X, q, float(g["pseudocount"]), float(g["seqid"]))
+    assert rel_err(di, g["mf_di"]) <= 1e-9
+    assert np.array_equal(np.argsort(-di, kind="stable"), np.argsort(-g["mf_di"], kind="stable"))
+    di_apc = oracle_mf.apc(di, L)
+    assert rel_err(di_apc, g["mf_di_apc"]) <= 1e-9
+
+
+@pytest.mark.parametrize("tag,fname,bio", DI_CASES)
+def test_plm_direct_information_matches_reference(oracle_mf, tag, fname, bio):
+    """plmDCA DI (plmdca.py:683-720; plmdca/msa_numerics.py:156-311) on the stored reference run."""
+    g = golden("di_" + tag)
+    x = golden("plm_" + tag)["run_a"]
+    L, q = int(g["L"]), int(g["q"])
+    X = oracle_mf.letter2int(oracle_mf.read_fasta(data_file(fname)), bio)
+    w = oracle_mf.compute_sequences_weight(X, float(g["plm_seqid"]))
+    reg_fi = oracle_mf.get_reg_single_site_freqs(oracle_mf.compute_single_site_freqs(X, q, w), L, q, 0.5)
+    assert np.max(np.abs(reg_fi - g["plm_reg_fi"])) <= 1e-13
+    E, hi, hj = oracle_mf.two_site_model_fields(oracle_mf.plm_blocks(x, L, q).astype(np.float64), reg_fi, L, q)
+    assert np.max(np.abs(hi - g["plm_fields"][:, 0, :])) <= 1e-12
+    assert np.max(np.abs(hj - g["plm_fields"][:, 1, :])) <= 1e-12
+    di = oracle_mf.plm_di(x, reg_fi, L, q)
+    assert rel_err(di, g["plm_di"]) <= 1e-9
+    assert np.array_equal(np.argsort(-di, kind="stable"), np.argsort(-g["plm_di"], kind="stable"))
