@@ -210,223 +210,163 @@ void plm_softmax_kernel(T* __restrict__ SR, const T* __restrict__ x, const uint8
     if (lane == 0) fxPart[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv] = facc;
 }
 
-// ------------------------------------------------------------------ per-chunk sorted lists
-// For every chunk of NC owned sequences and every site j: the chunk-local rows grouped
-// by state x_nj (counting sort, ascending n inside a group), stored as LDS byte offsets
-// (row * 512).  Groups are padded to a multiple of 4 with the offset of an all-zero row
-// so that the scatter kernel's inner loop needs no remainder handling.  The group of the
-// site's most frequent state is left empty: its sum is recovered as (column sum of R) -
-// (sum of the other groups), which removes the largest group -- typically about half of
-// the entries -- from the gather.
-constexpr int kNC = 128;           // sequences per scatter chunk
+// ------------------------------------------------------------------ scatter (as a gather)
+// G[(j,b)][c] = sum_{n : x_nj = b} R[n][c].  A workgroup owns 32 sites (two per wave) and one
+// 512-byte column strip of R (lane = 8 bytes of a row) and walks the owned sequences in
+// 128-row tiles that are double-buffered in LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+// wave instruction, no staging registers): tile c+1 streams in while tile c is gathered, one
+// barrier per tile.  The q accumulators of a site sit in fixed VGPRs and the one that a row adds
+// to is selected with the gfx9 VGPR index mode (s_set_gpr_idx_*; M0 = 2 x state), so the rows
+// are visited in sequence order with immediate LDS offsets: one ds_read_b64 per row shared by the
+// wave's two sites and one packed add per (row, site).  The inner block is generated assembly
+// (tools/gen_scatter_asm.py -> scatter_gather_asm.inc): 84 accumulator + 16 data-ring registers
+// are pinned, which is why the kernel is built for 128 VGPRs (16 waves = one workgroup per CU).
+// The sums of a (site, state) run over n in ascending order: deterministic.
+constexpr int kNC = 128;           // sequences per scatter tile
 constexpr int kRowBytes = 512;     // bytes of one staged row (64 lanes x 8 B)
+constexpr int kScatWavesC = 16;
+constexpr int kScatJG = 32;        // sites per workgroup (2 per wave)
 
-__host__ __device__ constexpr int list_len(int q) { return (kNC + 3 * q + 3) / 4 * 4; }
-
-__global__ void plm_build_lists_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ dom,
-                                       uint32_t* __restrict__ lists, int* __restrict__ offs, int N, int L, int Ls,
-                                       int q, int halo, int numChunks)
+// XT2[j][k] = 2 * x_{halo+k, j} (the accumulator register-pair offset), zero past N; row stride NT
+__global__ void plm_build_states_kernel(const uint8_t* __restrict__ X, uint8_t* __restrict__ XT2, int N, int L, int Ls,
+                                        int halo, int NT)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= numChunks * L) return;
-    const int c = t / L, j = t % L;
-    const int LP = list_len(q);
-    const int n0 = halo + c * kNC;
-    int cnt[32], pos[32];
-    for (int b = 0; b < q; ++b) cnt[b] = 0;
-    const int skip = dom[j];   // rows in the site's dominant state are not listed (complement trick)
-    for (int r = 0; r < kNC; ++r) {
-        const int n = n0 + r;
-        if (n < N) { const int b = X[(size_t)n * Ls + j]; if (b != skip) cnt[b]++; }
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (k >= NT) return;
+    const int n = halo + k;
+    XT2[(size_t)j * NT + k] = (n < N) ? (uint8_t)(2 * X[(size_t)n * Ls + j]) : (uint8_t)0;
+}
+
+typedef float dca_v32f __attribute__((ext_vector_type(32)));
+typedef float dca_v8f __attribute__((ext_vector_type(8)));
+typedef float dca_v2f __attribute__((ext_vector_type(2)));
+
+#include "scatter_gather_asm.inc"
+
+// accumulators of one site as the register tuples the generated assembly pins
+template <int Q> struct SiteAcc;
+template <> struct SiteAcc<21> {
+    dca_v32f a; dca_v8f b; dca_v2f c;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = 0.f;
+        c[0] = c[1] = 0.f;
     }
-    int* of = offs + (size_t)t * (q + 1);
-    int run = 0;
-    for (int b = 0; b < q; ++b) { of[b] = run; pos[b] = run; run += (cnt[b] + 3) / 4 * 4; }
-    of[q] = run;
-    uint32_t* lst = lists + (size_t)t * LP;
-    for (int k = 0; k < LP; ++k) lst[k] = kNC * kRowBytes;   // zero row
-    for (int r = 0; r < kNC; ++r) {
-        const int n = n0 + r;
-        if (n < N) { const int b = X[(size_t)n * Ls + j]; if (b != skip) lst[pos[b]++] = r * kRowBytes; }
+    template <int S> __device__ __forceinline__ dca_v2f get() const {
+        if constexpr (S < 16) return dca_v2f{a[2 * S], a[2 * S + 1]};
+        else if constexpr (S < 20) return dca_v2f{b[2 * (S - 16)], b[2 * (S - 16) + 1]};
+        else return c;
+    }
+};
+template <> struct SiteAcc<5> {
+    dca_v8f a; dca_v2f b;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = 0.f;
+        b[0] = b[1] = 0.f;
+    }
+    template <int S> __device__ __forceinline__ dca_v2f get() const {
+        if constexpr (S < 4) return dca_v2f{a[2 * S], a[2 * S + 1]};
+        else return b;
+    }
+};
+
+template <int Q, int S = 0>
+__device__ __forceinline__ void scatter_store_site(const SiteAcc<Q>& acc, unsigned char* rowBase, size_t rowStrideBytes)
+{
+    if constexpr (S < Q) {
+        *reinterpret_cast<dca_v2f*>(rowBase + (size_t)S * rowStrideBytes) = acc.template get<S>();
+        scatter_store_site<Q, S + 1>(acc, rowBase, rowStrideBytes);
     }
 }
 
-// ------------------------------------------------------------------ scatter (as a gather)
-// G[(j,b)][c] = sum_{n : x_nj = b} R[n][c].  Lanes = columns (8 bytes per lane), the
-// q running sums of a site sit in registers because the groups are visited in state
-// order with a compile-time unrolled loop over b; the rows of R come from an LDS tile.
-// The sorted list of a (chunk, site) is fetched with coalesced vector loads before the
-// staging barrier (lane l holds entries l, 64+l, 128+l) and its entries are broadcast
-// with v_readlane, so the inner loop touches no memory but LDS:
-// readlane -> address add -> ds_read_b64 -> add, four entries per trip.
-// 16-wave workgroups, JW sites per wave, <= 64 VGPRs => two workgroups (32 waves) per CU:
-// the kernel is bound by per-wave issue latency, so resident waves are what matters.
-// The dominant state's group of every site is not gathered (see plm_build_lists_kernel);
-// each wave also sums an 8-row slice of every tile, the slices combine to the column sum
-// at the end, and G[(j,dom)] = colsum - sum of the other groups.
-template <typename T, int Q, int JW, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 2)
-void plm_scatter_kernel(const T* __restrict__ R, const uint32_t* __restrict__ lists, const int* __restrict__ offs,
-                        const uint8_t* __restrict__ dom, const unsigned char* __restrict__ zeros, T* __restrict__ G,
-                        int N, int L, int Cs, int halo, int numChunks, int numColTiles, int numJG,
-                        int chunksPerSplit, size_t slabElems, int groups, int ablate)
+template <typename T, int Q>
+__global__ __launch_bounds__(kScatWavesC * 64)
+void plm_scatter_kernel(const T* __restrict__ R, const uint8_t* __restrict__ XT2, const unsigned char* __restrict__ zeros,
+                        T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int NT, int numColTiles,
+                        int numJG, int chunksPerSplit, size_t slabElems)
 {
-    constexpr int EPL = 8 / sizeof(T);     // elements per lane
-    constexpr int CW = 64 * EPL;           // columns per tile
-    constexpr int JG = WAVES * JW;         // sites per workgroup
-    constexpr int LP = list_len(Q);
-    constexpr int NB = (LP + 63) / 64;     // 64-entry list blocks per (chunk, site)
-    constexpr int SLICE = kNC / WAVES;     // tile rows each wave adds to the column sum
-    constexpr int DMA_PER_WAVE = kNC / 2 / WAVES;   // LDS-DMA instructions per wave and tile
-    static_assert(NB <= 3, "list longer than three lane blocks");
-    static_assert(kNC % WAVES == 0, "tile rows must divide over the waves");
-    struct alignas(8) Acc { T v[EPL]; };
+    constexpr int WAVES = kScatWavesC;
+    constexpr int CW = kRowBytes / (int)sizeof(T);     // columns per strip
+    constexpr int DMA_PER_WAVE = kNC / 2 / WAVES;      // LDS-DMA instructions per wave and tile
+    constexpr int TILE = kNC * kRowBytes;
+    static_assert(kNC % (2 * WAVES) == 0, "tile rows must divide over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
 
-    // Column tiles are walked persistently: the grid holds `groups` x numJG workgroups per XCD;
-    // the numJG workgroups of a group walk the same sequence of column tiles
-    // (ct = group*8 + xcd, += groups*8) and all chunks of each in the same order, so they read
-    // the same 64 KB tile of R at about the same time and most of those reads can hit L2.
-    // groups = number of column tiles per XCD gives the one-tile-per-workgroup launch.
+    // workgroup id -> (XCD, column strip, site group): the numJG site groups of a strip run on the
+    // same XCD (id % 8) so that their reads of the strip can meet in that XCD's L2
     const int id = blockIdx.x;
     const int xcd = id % kNumXcd, k = id / kNumXcd;
-    const int group = k / numJG;
+    const int ct = (k / numJG) * kNumXcd + xcd;
     const int jg = k % numJG;
+    if (ct >= numColTiles) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int jbase = jg * JG + wave * JW;
-    T* const Gslab = G + (size_t)blockIdx.y * slabElems;
+    const int j0 = jg * kScatJG + wave * 2;
+    const int jc0 = min(j0, L - 1), jc1 = min(j0 + 1, L - 1);
 
-    for (int t = tid; t < kRowBytes / 4; t += WAVES * 64)
-        reinterpret_cast<uint32_t*>(dca_smem + kNC * kRowBytes)[t] = 0u;
-
-  for (int ct = group * kNumXcd + xcd; ct < numColTiles; ct += groups * kNumXcd) {
-    Acc acc[JW][Q];
-    Acc colsum;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) colsum.v[e] = 0;
-#pragma unroll
-    for (int jj = 0; jj < JW; ++jj)
-#pragma unroll
-        for (int b = 0; b < Q; ++b)
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[jj][b].v[e] = 0;
-
-    // blockIdx.y splits the chunk range; every split writes its own slab of G (summed by
+    // blockIdx.y splits the tile range; every split writes its own slab of G (summed by
     // plm_sum_slabs_kernel in a fixed order), so small L*q shapes still fill the chip.
     const int cBegin = blockIdx.y * chunksPerSplit;
     const int cEnd = min(numChunks, cBegin + chunksPerSplit);
 
-    const unsigned char* laneBase = dca_smem + lane * 8;
-    const unsigned char* Rtile = reinterpret_cast<const unsigned char*>(R + (size_t)ct * CW) + (lane & 31) * 16;
+    SiteAcc<Q> acc0, acc1;
+    acc0.zero();
+    acc1.zero();
+
+    const unsigned char* Rstrip = reinterpret_cast<const unsigned char*>(R + (size_t)ct * CW) + (lane & 31) * 16;
     const size_t rowStrideBytes = (size_t)Cs * sizeof(T);
+    const uint32_t* x0 = reinterpret_cast<const uint32_t*>(XT2 + (size_t)jc0 * NT);
+    const uint32_t* x1 = reinterpret_cast<const uint32_t*>(XT2 + (size_t)jc1 * NT);
+
+    // rows past N come from a zero row in global memory
+    auto stage = [&](int c, int buf) {
+        const int n0 = halo + c * kNC;
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            const int pairIdx = wave * DMA_PER_WAVE + i;              // wave-uniform
+            const int n = n0 + pairIdx * 2 + (lane >> 5);
+            const unsigned char* g = (n < N) ? Rstrip + (size_t)n * rowStrideBytes : zeros + (lane & 31) * 16;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)g,
+                (__attribute__((address_space(3))) void*)(dca_smem + buf * TILE + pairIdx * 1024), 16, 0, 0);
+        }
+    };
+
+    uint32_t st0 = 0, st1 = 0;
+    if (cBegin < cEnd) {
+        stage(cBegin, 0);
+        if (lane < 32) { st0 = x0[cBegin * (kNC / 4) + lane]; st1 = x1[cBegin * (kNC / 4) + lane]; }
+    }
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)dca_smem + lane * 8;
     for (int c = cBegin; c < cEnd; ++c) {
-        // this wave's sorted lists and group offsets for the chunk (in flight across the barrier).
-        // Separate statically indexed arrays per field: an aggregate lets the compiler turn the
-        // block select below into a scratch lookup.
-        uint32_t la[JW], lb[JW], lc[JW];
-        int lo[JW];
-#pragma unroll
-        for (int jj = 0; jj < JW; ++jj) {
-            const int jc = min(jbase + jj, L - 1);
-            const uint32_t* lst = lists + ((size_t)c * L + jc) * LP;
-            const uint32_t zrow = (uint32_t)(kNC * kRowBytes);
-            la[jj] = (lane < LP && !(ablate & 4)) ? lst[lane] : zrow;
-            lb[jj] = (NB > 1 && 64 + lane < LP && !(ablate & 4)) ? lst[64 + lane] : zrow;
-            lc[jj] = (NB > 2 && 128 + lane < LP && !(ablate & 4)) ? lst[128 + lane] : zrow;
-            lo[jj] = (lane <= Q && !(ablate & 4)) ? offs[((size_t)c * L + jc) * (Q + 1) + lane] : 0;
+        const int buf = (c - cBegin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile c have landed
+        __syncthreads();                                    // ... everyone's; and tile c-1 is no longer read
+        uint32_t st0n = 0, st1n = 0;
+        if (c + 1 < cEnd) {
+            stage(c + 1, buf ^ 1);
+            if (lane < 32) { st0n = x0[(c + 1) * (kNC / 4) + lane]; st1n = x1[(c + 1) * (kNC / 4) + lane]; }
         }
-        __syncthreads();   // every wave is done with the previous tile
-        // stage the tile by LDS-DMA (global_load_lds_dwordx4: 1 KiB = two 512-byte rows per wave
-        // instruction, no staging VGPRs -- the kernel runs at the 64-VGPR budget, where register
-        // staging spills).  Rows past N come from a zero row in global memory.
-        {
-            const int n0 = halo + c * kNC;
-#pragma unroll
-            for (int i = 0; i < DMA_PER_WAVE && !(ablate & 8); ++i) {
-                const int pairIdx = wave * DMA_PER_WAVE + i;              // wave-uniform
-                const int n = n0 + pairIdx * 2 + (lane >> 5);
-                const unsigned char* g = (n < N) ? Rtile + (size_t)n * rowStrideBytes : zeros + (lane & 31) * 16;
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)g,
-                    (__attribute__((address_space(3))) void*)(dca_smem + pairIdx * 1024), 16, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        // column-sum slice of this wave
-#pragma unroll
-        for (int r = 0; r < SLICE && !(ablate & 16); ++r) {
-            const Acc v = *reinterpret_cast<const Acc*>(laneBase + (wave * SLICE + r) * kRowBytes);
-#pragma unroll
-            for (int u = 0; u < EPL; ++u) colsum.v[u] += v.v[u];
-        }
-#pragma unroll
-        for (int jj = 0; jj < JW; ++jj) {
-            if (jbase + jj < L && !(ablate & 2)) {
-#pragma unroll
-                for (int b = 0; b < Q; ++b) {
-                    int k0 = __builtin_amdgcn_readlane(lo[jj], b);
-                    const int k1 = __builtin_amdgcn_readlane(lo[jj], b + 1);
-                    while (k0 < k1) {
-                        const int blk = k0 >> 6;
-                        const int segEnd = min(k1, (blk + 1) << 6);
-                        uint32_t vsel = la[jj];
-                        if (blk == 1) vsel = lb[jj];
-                        if (blk == 2) vsel = lc[jj];
-                        for (; k0 < segEnd; k0 += 4) {
-                            const int t = k0 & 63;
-                            const Acc v0 = *reinterpret_cast<const Acc*>(laneBase + __builtin_amdgcn_readlane(vsel, t));
-                            const Acc v1 = *reinterpret_cast<const Acc*>(laneBase + __builtin_amdgcn_readlane(vsel, t + 1));
-                            const Acc v2 = *reinterpret_cast<const Acc*>(laneBase + __builtin_amdgcn_readlane(vsel, t + 2));
-                            const Acc v3 = *reinterpret_cast<const Acc*>(laneBase + __builtin_amdgcn_readlane(vsel, t + 3));
-#pragma unroll
-                            for (int u = 0; u < EPL; ++u) {
-                                T a = acc[jj][b].v[u];
-                                a += v0.v[u]; a += v1.v[u]; a += v2.v[u]; a += v3.v[u];
-                                acc[jj][b].v[u] = a;
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        const uint32_t vbase = ldsBase + buf * TILE;
+        if constexpr (Q == 21 && sizeof(T) == 4) DCA_GATHER_Q21_F32(vbase, st0, st1, acc0.a, acc0.b, acc0.c, acc1.a, acc1.b, acc1.c);
+        else if constexpr (Q == 21) DCA_GATHER_Q21_F64(vbase, st0, st1, acc0.a, acc0.b, acc0.c, acc1.a, acc1.b, acc1.c);
+        else if constexpr (sizeof(T) == 4) DCA_GATHER_Q5_F32(vbase, st0, st1, acc0.a, acc0.b, acc1.a, acc1.b);
+        else DCA_GATHER_Q5_F64(vbase, st0, st1, acc0.a, acc0.b, acc1.a, acc1.b);
+        st0 = st0n;
+        st1 = st1n;
     }
 
-    // total column sum of the tile = sum of the waves' slices (fixed order)
-    __syncthreads();
-    *reinterpret_cast<Acc*>(dca_smem + wave * kRowBytes + lane * 8) = colsum;
-    __syncthreads();
-    Acc total;
-#pragma unroll
-    for (int u = 0; u < EPL; ++u) total.v[u] = 0;
-    for (int w = 0; w < WAVES; ++w) {
-        const Acc v = *reinterpret_cast<const Acc*>(laneBase + w * kRowBytes);
-#pragma unroll
-        for (int u = 0; u < EPL; ++u) total.v[u] += v.v[u];
-    }
-#pragma unroll
-    for (int jj = 0; jj < JW; ++jj) {
-        const int j = jbase + jj;
-        if (j < L) {
-            const int dj = dom[j];
-            Acc rest = total;   // becomes colsum - sum of the listed groups = the dominant group
-#pragma unroll
-            for (int b = 0; b < Q; ++b)
-#pragma unroll
-                for (int u = 0; u < EPL; ++u) rest.v[u] -= acc[jj][b].v[u];
-#pragma unroll
-            for (int b = 0; b < Q; ++b) {
-                Acc out = acc[jj][b];
-                if (b == dj) out = rest;
-                *reinterpret_cast<Acc*>(reinterpret_cast<unsigned char*>(Gslab + (size_t)(j * Q + b) * Cs + (size_t)ct * CW) + lane * 8) = out;
-            }
-        }
-    }
-    __syncthreads();   // the column-sum scratch rows are tile rows of the next iteration
-  }
+    T* const Gslab = G + (size_t)blockIdx.y * slabElems;
+    if (j0 < L)
+        scatter_store_site<Q>(acc0, reinterpret_cast<unsigned char*>(Gslab + (size_t)j0 * Q * Cs + (size_t)ct * CW) + lane * 8, rowStrideBytes);
+    if (j0 + 1 < L)
+        scatter_store_site<Q>(acc1, reinterpret_cast<unsigned char*>(Gslab + (size_t)(j0 + 1) * Q * Cs + (size_t)ct * CW) + lane * 8, rowStrideBytes);
 }
 
 // G[0] += G[1] + ... + G[nsplit-1], fixed order (deterministic)
@@ -813,11 +753,11 @@ struct PlmEngine : PlmEngineBase {
     T* dS[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     T* dY[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     T *dWt = nullptr, *dSR = nullptr, *dG = nullptr, *dw = nullptr;
-    uint32_t *dX4 = nullptr, *dLists = nullptr;
-    uint8_t* dDom = nullptr;
+    uint32_t* dX4 = nullptr;
+    uint8_t* dXT2 = nullptr;
+    int NT = 0;
     uint8_t* dPerm = nullptr;
     unsigned char* dZeros = nullptr;
-    int* dOffs = nullptr;
     PairIJ* dPairs = nullptr;
     double *dFxPart = nullptr, *dRegPart = nullptr, *dVecPart = nullptr;
     int nFxPart = 0, nRegPart = 0;
@@ -844,13 +784,12 @@ struct PlmEngine : PlmEngineBase {
     {
         hipFree(dx); hipFree(dg); hipFree(dxp); hipFree(dgp); hipFree(dd);
         for (int i = 0; i < 5; ++i) { hipFree(dS[i]); hipFree(dY[i]); }
-        hipFree(dWt); hipFree(dSR); hipFree(dG); hipFree(dw); hipFree(dX4); hipFree(dLists); hipFree(dOffs);
-        hipFree(dPairs); hipFree(dDom); hipFree(dPerm); hipFree(dZeros); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
+        hipFree(dWt); hipFree(dSR); hipFree(dG); hipFree(dw); hipFree(dX4); hipFree(dXT2);
+        hipFree(dPairs); hipFree(dPerm); hipFree(dZeros); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
     }
     ~PlmEngine() override { freeall(); }
 
     int jt() const { return q <= 8 ? 32 : 8; }
-    int jw() const { return q <= 8 ? 2 : 1; }
 
     int configure(double lh, double lJ, int cmode, int chunk_, int warm_, int halo_, int add_reg_) override
     {
@@ -869,7 +808,7 @@ struct PlmEngine : PlmEngineBase {
         freeall();
         dx = dg = dxp = dgp = dd = nullptr;
         for (int i = 0; i < 5; ++i) dS[i] = dY[i] = nullptr;
-        dWt = dSR = dG = dw = nullptr; dX4 = dLists = nullptr; dDom = nullptr; dPerm = nullptr; dZeros = nullptr; dOffs = nullptr; dPairs = nullptr;
+        dWt = dSR = dG = dw = nullptr; dX4 = nullptr; dXT2 = nullptr; dPerm = nullptr; dZeros = nullptr; dPairs = nullptr;
         dFxPart = dRegPart = dVecPart = nullptr;
         lbfgs_alloc = false;
         o = decltype(o)();
@@ -879,7 +818,7 @@ struct PlmEngine : PlmEngineBase {
         Cs = (int)round_up(Lq, 128);
         const int JT = jt();
         Wrows = ceil_div(L, JT) * JT * q;
-        const int JG = kScatWaves * jw();
+        const int JG = kScatJG;
         Grows = ceil_div(L, JG) * JG * q;
         Npad = (int)round_up(N, 64 * kLogitWaves);
         Ls4 = ceil_div(L, JT) * JT / 4;
@@ -888,22 +827,21 @@ struct PlmEngine : PlmEngineBase {
         DCA_TRY(dalloc(&dWt, (size_t)Wrows * Cs));
         DCA_TRY(dalloc(&dSR, (size_t)N * Cs));
         {
-            // split the chunk range until the scatter grid has ~2048 workgroups
-            const int cw = 64 * (8 / (int)sizeof(T));
-            const int wgs = kNumXcd * ceil_div(Cs / cw, kNumXcd) * ceil_div(L, JG);
+            // split the tile range until the scatter grid has ~2048 workgroups (one per CU at a time)
+            const int cw = kRowBytes / (int)sizeof(T);
+            const int wgs = ceil_div(Cs, cw) * ceil_div(L, JG);
             scatSplit = std::max(1, std::min(numScatChunks, ceil_div(2048, wgs)));
             scatChunksPerSplit = ceil_div(numScatChunks, scatSplit);
             scatSplit = ceil_div(numScatChunks, scatChunksPerSplit);
         }
         DCA_TRY(dalloc(&dG, (size_t)scatSplit * Grows * Cs));
-        DCA_TRY(dalloc(&dDom, L));
         DCA_TRY(dalloc(&dPerm, (size_t)L * q));
         DCA_TRY(dalloc(&dZeros, kRowBytes));
         HIP_TRY(hipMemsetAsync(dZeros, 0, kRowBytes, ctx->stream));
         DCA_TRY(dalloc(&dw, N));
         DCA_TRY(dalloc(&dX4, (size_t)Ls4 * Npad));
-        DCA_TRY(dalloc(&dLists, (size_t)numScatChunks * L * list_len(q)));
-        DCA_TRY(dalloc(&dOffs, (size_t)numScatChunks * L * (q + 1)));
+        NT = numScatChunks * kNC;
+        DCA_TRY(dalloc(&dXT2, (size_t)L * NT));
         const size_t npairs = (size_t)L * (L - 1) / 2;
         DCA_TRY(dalloc(&dPairs, npairs));
         nFxPart = ceil_div(L, 64) * ceil_div(numScanChunks, 4) * 4;
@@ -923,18 +861,12 @@ struct PlmEngine : PlmEngineBase {
             for (int i = 0; i < L - 1; ++i) for (int j = i + 1; j < L; ++j) hp[k++] = PairIJ{(uint16_t)i, (uint16_t)j};
         }
         HIP_TRY(hipMemcpyAsync(dPairs, hp.data(), npairs * sizeof(PairIJ), hipMemcpyHostToDevice, ctx->stream));
-        // most frequent state of every site among the owned sequences (ties -> lowest code)
-        std::vector<uint8_t> hdom(L), hperm;
+        std::vector<uint8_t> hperm;
         {
             std::vector<int> cnt((size_t)L * q, 0);
             const uint8_t* X = ctx->hX.data();
             for (int n = halo; n < N; ++n)
                 for (int i = 0; i < L; ++i) cnt[(size_t)i * q + X[(size_t)n * L + i]]++;
-            for (int i = 0; i < L; ++i) {
-                int best = 0;
-                for (int a = 1; a < q; ++a) if (cnt[(size_t)i * q + a] > cnt[(size_t)i * q + best]) best = a;
-                hdom[i] = (uint8_t)best;
-            }
             // row permutation of W within each site: physical rows r and r+16 share an LDS bank slot
             // for the 16-byte reads of the logits kernel, so the 2(q-16) rarest states take rows
             // 0..q-17 and 16..q-1 (rarest last) and the frequent states the collision-free rows between
@@ -955,7 +887,6 @@ struct PlmEngine : PlmEngineBase {
                 }
             }
         }
-        HIP_TRY(hipMemcpyAsync(dDom, hdom.data(), L, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(dPerm, hperm.data(), hperm.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
 
@@ -978,9 +909,8 @@ struct PlmEngine : PlmEngineBase {
         {
             dim3 grid(ceil_div(Npad, 256), Ls4);
             hipLaunchKernelGGL(pack_x4_kernel, grid, dim3(256), 0, ctx->stream, ctx->dX, dPerm, dX4, N, Npad, L, Ls, Ls4, q);
-            const int nt = numScatChunks * L;
-            hipLaunchKernelGGL(plm_build_lists_kernel, dim3(ceil_div(nt, 128)), dim3(128), 0, ctx->stream,
-                               ctx->dX, dDom, dLists, dOffs, N, L, Ls, q, halo, numScatChunks);
+            hipLaunchKernelGGL(plm_build_states_kernel, dim3(ceil_div(NT, 256), L), dim3(256), 0, ctx->stream,
+                               ctx->dX, dXT2, N, L, Ls, halo, NT);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
@@ -1083,24 +1013,16 @@ struct PlmEngine : PlmEngineBase {
                                N, L, Ls, Cs, halo, chunk, warm, carry_mode != DCA_CARRY_EXACT ? 1 : 0, numScanChunks);
         }
         {
-            constexpr int JW = (Q <= 8) ? 2 : 1;
-            constexpr int W = kScatWaves;
-            constexpr int CW = 64 * (8 / (int)sizeof(T));
-            const int numCT = Cs / CW;
-            const int numJG = ceil_div(L, W * JW);
-            // groups per XCD: all column tiles (one tile per workgroup) by default;
-            // DCA_SCATTER_GROUPS=n makes the grid persistent with n groups per XCD
-            const int maxGroups = ceil_div(numCT, kNumXcd);
-            int groups = maxGroups;
-            if (const char* e = getenv("DCA_SCATTER_GROUPS")) groups = std::max(1, std::min(maxGroups, atoi(e)));
-            const int blocks = kNumXcd * groups * numJG;
-            const size_t lds = (size_t)(kNC + 1) * kRowBytes;
-            auto kern = plm_scatter_kernel<T, Q, JW, W>;
+            constexpr int CW = kRowBytes / (int)sizeof(T);
+            const int numCT = ceil_div(Cs, CW);
+            const int numJG = ceil_div(L, kScatJG);
+            const int blocks = kNumXcd * ceil_div(numCT, kNumXcd) * numJG;
+            const size_t lds = (size_t)2 * kNC * kRowBytes;
+            auto kern = plm_scatter_kernel<T, Q>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ScopedKernelClock kc(ctx, "plm_scatter");
-            hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(W * 64), lds, st, dSR, dLists, dOffs, dDom, dZeros, dG, N, L, Cs, halo,
-                               numScatChunks, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs, groups,
-                               getenv("DCA_SCATTER_ABLATE") ? atoi(getenv("DCA_SCATTER_ABLATE")) : 0);
+            hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(kScatWavesC * 64), lds, st, dSR, dXT2, dZeros, dG, N, L, Cs, halo,
+                               numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
             if (scatSplit > 1)
                 hipLaunchKernelGGL(plm_sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, st, dG, (size_t)Grows * Cs, scatSplit);
         }
