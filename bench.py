@@ -168,7 +168,7 @@ def main():
     # algorithmic HBM bytes per launch: compulsory reads + writes of each kernel
     alg_bytes = {
         "plm_logits": Lq * Lq * esz + n_local * L + n_local * Lq * esz,          # W once, alignment bytes, write S
-        "plm_scatter": n_local * Lq * esz + Lq * Lq * esz + n_local * L * 4,     # read R, write G, sorted lists (4 B/entry)
+        "plm_scatter": n_local * Lq * esz + Lq * Lq * esz + n_local * L * 2,     # read R, write G, 16-bit state images
     }
     lds_bytes = {k: esz * n_local * L * Lq for k in alg_bytes}                     # gathered operand bytes (N L^2 q)
     dom = max(alg_bytes, key=lambda k: ktimes[k][0])
@@ -184,7 +184,7 @@ def main():
     roofline = {"kernel": dom, "bound": "hbm", "achieved": alg_bytes[dom] / avg_s / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": alg_bytes[dom] / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_kernel_ms": ms / max(launches, 1), "launches": launches,
-                "note": "kernel is bound by LDS gather bandwidth, not HBM (DESIGN.md section 4); see onchip",
+                "note": "gather kernels: bound on chip (LDS reads + VALU/SALU issue), not by HBM (DESIGN.md section 4); see onchip",
                 "onchip": {"bound": "lds", "achieved": lds_bytes[dom] / avg_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                            "frac": lds_bytes[dom] / avg_s / 1e9 / LDS_PEAK_GBS}}
     kernels_ms = {k: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in ktimes.items()}

@@ -216,7 +216,7 @@ void plm_softmax_kernel(T* __restrict__ SR, const T* __restrict__ x, const uint8
 // 128-row tiles that are double-buffered in LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
 // wave instruction, no staging registers): tile c+1 streams in while tile c is gathered, one
 // barrier per tile.  The q accumulators of a site sit in fixed VGPRs and the one that a row adds
-// to is selected with the gfx9 VGPR index mode (s_set_gpr_idx_*; M0 = 2 x state), so the rows
+// to is selected with the gfx9 VGPR index mode (s_set_gpr_idx_on; M0 = 0x9000 | 2 x state), so the rows
 // are visited in sequence order with immediate LDS offsets: one ds_read_b64 per row shared by the
 // wave's two sites and one packed add per (row, site).  The inner block is generated assembly
 // (tools/gen_scatter_asm.py -> scatter_gather_asm.inc): 84 accumulator + 16 data-ring registers
@@ -227,15 +227,16 @@ constexpr int kRowBytes = 512;     // bytes of one staged row (64 lanes x 8 B)
 constexpr int kScatWavesC = 16;
 constexpr int kScatJG = 32;        // sites per workgroup (2 per wave)
 
-// XT2[j][k] = 2 * x_{halo+k, j} (the accumulator register-pair offset), zero past N; row stride NT
-__global__ void plm_build_states_kernel(const uint8_t* __restrict__ X, uint8_t* __restrict__ XT2, int N, int L, int Ls,
+// XT2[j][k] = 0x9000 | 2 * x_{halo+k, j}: the M0 image that selects the accumulator of the state
+// (index-enable bits for src0 and dst + register-pair offset); state 0 past N (zero rows); row stride NT
+__global__ void plm_build_states_kernel(const uint8_t* __restrict__ X, uint16_t* __restrict__ XT2, int N, int L, int Ls,
                                         int halo, int NT)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
     if (k >= NT) return;
     const int n = halo + k;
-    XT2[(size_t)j * NT + k] = (n < N) ? (uint8_t)(2 * X[(size_t)n * Ls + j]) : (uint8_t)0;
+    XT2[(size_t)j * NT + k] = (uint16_t)(0x9000u | ((n < N) ? 2u * X[(size_t)n * Ls + j] : 0u));
 }
 
 typedef float dca_v32f __attribute__((ext_vector_type(32)));
@@ -285,9 +286,9 @@ __device__ __forceinline__ void scatter_store_site(const SiteAcc<Q>& acc, unsign
 
 template <typename T, int Q>
 __global__ __launch_bounds__(kScatWavesC * 64)
-void plm_scatter_kernel(const T* __restrict__ R, const uint8_t* __restrict__ XT2, const unsigned char* __restrict__ zeros,
+void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT2, const unsigned char* __restrict__ zeros,
                         T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int NT, int numColTiles,
-                        int numJG, int chunksPerSplit, size_t slabElems)
+                        int numJG, int chunksPerSplit, size_t slabElems, int ablate)
 {
     constexpr int WAVES = kScatWavesC;
     constexpr int CW = kRowBytes / (int)sizeof(T);     // columns per strip
@@ -328,7 +329,7 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint8_t* __restrict__ XT2
     auto stage = [&](int c, int buf) {
         const int n0 = halo + c * kNC;
 #pragma unroll
-        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        for (int i = 0; i < DMA_PER_WAVE && !(ablate & 8); ++i) {
             const int pairIdx = wave * DMA_PER_WAVE + i;              // wave-uniform
             const int n = n0 + pairIdx * 2 + (lane >> 5);
             const unsigned char* g = (n < N) ? Rstrip + (size_t)n * rowStrideBytes : zeros + (lane & 31) * 16;
@@ -341,7 +342,8 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint8_t* __restrict__ XT2
     uint32_t st0 = 0, st1 = 0;
     if (cBegin < cEnd) {
         stage(cBegin, 0);
-        if (lane < 32) { st0 = x0[cBegin * (kNC / 4) + lane]; st1 = x1[cBegin * (kNC / 4) + lane]; }
+        st0 = x0[cBegin * (kNC / 2) + lane];
+        st1 = x1[cBegin * (kNC / 2) + lane];
     }
     const uint32_t ldsBase = (uint32_t)(uintptr_t)dca_smem + lane * 8;
     for (int c = cBegin; c < cEnd; ++c) {
@@ -351,9 +353,11 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint8_t* __restrict__ XT2
         uint32_t st0n = 0, st1n = 0;
         if (c + 1 < cEnd) {
             stage(c + 1, buf ^ 1);
-            if (lane < 32) { st0n = x0[(c + 1) * (kNC / 4) + lane]; st1n = x1[(c + 1) * (kNC / 4) + lane]; }
+            st0n = x0[(c + 1) * (kNC / 2) + lane];
+            st1n = x1[(c + 1) * (kNC / 2) + lane];
         }
         const uint32_t vbase = ldsBase + buf * TILE;
+        if (ablate & 2) { st0 = st0n; st1 = st1n; continue; }   // timing knob (DCA_SCATTER_ABLATE): staging only
         if constexpr (Q == 21 && sizeof(T) == 4) DCA_GATHER_Q21_F32(vbase, st0, st1, acc0.a, acc0.b, acc0.c, acc1.a, acc1.b, acc1.c);
         else if constexpr (Q == 21) DCA_GATHER_Q21_F64(vbase, st0, st1, acc0.a, acc0.b, acc0.c, acc1.a, acc1.b, acc1.c);
         else if constexpr (sizeof(T) == 4) DCA_GATHER_Q5_F32(vbase, st0, st1, acc0.a, acc0.b, acc1.a, acc1.b);
@@ -754,7 +758,7 @@ struct PlmEngine : PlmEngineBase {
     T* dY[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     T *dWt = nullptr, *dSR = nullptr, *dG = nullptr, *dw = nullptr;
     uint32_t* dX4 = nullptr;
-    uint8_t* dXT2 = nullptr;
+    uint16_t* dXT2 = nullptr;
     int NT = 0;
     uint8_t* dPerm = nullptr;
     unsigned char* dZeros = nullptr;
@@ -1022,7 +1026,8 @@ struct PlmEngine : PlmEngineBase {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ScopedKernelClock kc(ctx, "plm_scatter");
             hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(kScatWavesC * 64), lds, st, dSR, dXT2, dZeros, dG, N, L, Cs, halo,
-                               numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
+                               numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs,
+                               getenv("DCA_SCATTER_ABLATE") ? atoi(getenv("DCA_SCATTER_ABLATE")) : 0);
             if (scatSplit > 1)
                 hipLaunchKernelGGL(plm_sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, st, dG, (size_t)Grows * Cs, scatSplit);
         }
