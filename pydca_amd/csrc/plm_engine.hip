@@ -46,12 +46,9 @@ struct PairIJ { uint16_t i, j; };
 // W[(j,b)][(i,a)] = W[(i,a)][(j,b)] = J_ij(a,b); diagonal blocks and padding stay 0.
 // One workgroup per site pair; the q x q block goes through LDS so that both
 // writes are runs of q contiguous elements.
-// Rows of W are stored permuted within each site, row (j, perm[j][b]): the logits kernel reads W
-// rows with 16-byte LDS reads, where rows 16 apart share a bank slot (q = 21 rows > 16 slots), and
-// perm puts the rarest states of every site on the colliding rows (see PlmEngine::configure).
 template <typename T>
 __global__ void plm_expand_kernel(const T* __restrict__ x, T* __restrict__ W, const PairIJ* __restrict__ pairs,
-                                  const uint8_t* __restrict__ perm, int L, int q, int Cs)
+                                  int L, int q, int Cs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
     T* tile = reinterpret_cast<T*>(dca_smem);
@@ -64,32 +61,73 @@ __global__ void plm_expand_kernel(const T* __restrict__ x, T* __restrict__ W, co
     for (int t = threadIdx.x; t < q2; t += blockDim.x) {
         const int r = t / q, c = t % q;
         // row (i,a=r), columns (j,b=c): contiguous in b
-        W[(size_t)(i * q + perm[i * q + r]) * Cs + j * q + c] = tile[r * q + c];
+        W[(size_t)(i * q + r) * Cs + j * q + c] = tile[r * q + c];
         // row (j,b=r), columns (i,a=c): contiguous in a
-        W[(size_t)(j * q + perm[j * q + r]) * Cs + i * q + c] = tile[c * q + r];
+        W[(size_t)(j * q + r) * Cs + i * q + c] = tile[c * q + r];
     }
 }
 
 // ------------------------------------------------------------------ logits
-// S[n][c] = sum_j W[j*q + x_nj][c] for a tile of CT columns.  Lanes = sequences, so
-// the data-dependent row index lives in the LDS *address* and the CT running sums
-// live in registers.  The (JT*Q) x CT slice of W for JT sites is staged in LDS and
-// shared by the workgroup's WAVES*64 sequences.  Row stride CT+16B keeps 16-byte
-// alignment and spreads rows over banks.
-template <typename T, int Q, int CT, int JT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64)
-void plm_logits_kernel(const T* __restrict__ W, const uint32_t* __restrict__ X4, T* __restrict__ S,
+// S[n][c] = sum_j W[j*q + x_nj][c].  The transpose of the scatter kernel: a workgroup owns 512
+// sequences (32 per wave) and one 512-byte column strip (lane = 8 bytes of a row) and walks the
+// sites in tiles of JT = 128/q sites whose q rows each are double-buffered in LDS by LDS-DMA.
+// For one site a wave pulls the q rows into q register pairs (ds_read_b64, immediate offsets) and
+// then adds, for each of its 32 sequences, the row of that sequence's state: the SOURCE register
+// is selected with the VGPR index mode (M0 = 0x2000 | 2 x state, src1 relative), so a
+// (sequence, site) pair costs one SALU write of M0 and one packed add; the 32 running sums are
+// fixed registers.  No per-lane LDS addresses, hence no bank conflicts and no row permutation.
+// Inner block: generated assembly (tools/gen_plm_asm.py -> logits_gather_asm.inc), 64 accumulator
+// + 2q row registers pinned, 128 VGPRs, one 16-wave workgroup per CU.
+constexpr int kLogitSeqPerWave = 32;
+constexpr int kLogitWavesC = 16;
+constexpr int kLogitSeqPerWG = kLogitSeqPerWave * kLogitWavesC;
+__host__ __device__ constexpr int logits_jt(int q) { return q == 21 ? 6 : 24; }   // sites per LDS tile (<= 128 rows)
+
+// XL[j][n] = 0x2000 | 2 * x_nj (M0 image: src1-relative + register-pair offset); state 0 past N and for
+// the padding sites j >= L of the last tile (their rows of W are zero)
+__global__ void plm_build_logit_states_kernel(const uint8_t* __restrict__ X, uint16_t* __restrict__ XL, int N, int Npad,
+                                              int L, int Ls)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (n >= Npad) return;
+    XL[(size_t)j * Npad + n] = (uint16_t)(0x2000u | ((n < N && j < L) ? 2u * X[(size_t)n * Ls + j] : 0u));
+}
+
+typedef float dca_v32f __attribute__((ext_vector_type(32)));
+typedef float dca_v8f __attribute__((ext_vector_type(8)));
+typedef float dca_v2f __attribute__((ext_vector_type(2)));
+
+#include "logits_gather_asm.inc"
+
+template <int S = 0>
+__device__ __forceinline__ void logits_store(const dca_v32f& a, const dca_v32f& b, unsigned char* rowBase, size_t rowStrideBytes,
+                                             int rowsLeft)
+{
+    if constexpr (S < kLogitSeqPerWave) {
+        if (S < rowsLeft) {
+            dca_v2f v;
+            if constexpr (S < 16) v = dca_v2f{a[2 * S], a[2 * S + 1]};
+            else v = dca_v2f{b[2 * (S - 16)], b[2 * (S - 16) + 1]};
+            *reinterpret_cast<dca_v2f*>(rowBase + (size_t)S * rowStrideBytes) = v;
+        }
+        logits_store<S + 1>(a, b, rowBase, rowStrideBytes, rowsLeft);
+    }
+}
+
+template <typename T, int Q>
+__global__ __launch_bounds__(kLogitWavesC * 64)
+void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL, T* __restrict__ S,
                        int N, int Npad, int L, int Cs, int numColTiles, int numNBlocks)
 {
-    using V = typename V16<T>::type;
-    constexpr int VEC = V16<T>::n;
-    constexpr int VPR = CT / VEC;          // 16-byte vectors per tile row
-    constexpr int ROWS = JT * Q;
-    constexpr int STRIDE = CT + VEC;       // elements
+    constexpr int WAVES = kLogitWavesC;
+    constexpr int JT = logits_jt(Q);
+    constexpr int CW = 512 / (int)sizeof(T);
+    constexpr int TILE = 128 * 512;                 // bytes of one LDS buffer (JT*Q <= 128 rows)
+    constexpr int DMA_PER_WAVE = 128 / 2 / WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
-    T* tile = reinterpret_cast<T*>(dca_smem);
 
-    // XCD-aware decode: all sequence blocks of one column tile run on one XCD so that
+    // XCD-aware decode: all sequence blocks of one column strip run on one XCD so that
     // its slice of W is served by that XCD's L2.
     const int id = blockIdx.x;
     const int xcd = id % kNumXcd, k = id / kNumXcd;
@@ -98,39 +136,47 @@ void plm_logits_kernel(const T* __restrict__ W, const uint32_t* __restrict__ X4,
     if (ct >= numColTiles) return;
 
     const int tid = threadIdx.x;
-    const int n = nb * (WAVES * 64) + tid;
-    const int c0 = ct * CT;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = nb * kLogitSeqPerWG + wave * kLogitSeqPerWave;
 
-    T z[CT];
+    dca_v32f accA, accB;
 #pragma unroll
-    for (int c = 0; c < CT; ++c) z[c] = 0;
+    for (int i = 0; i < 32; ++i) { accA[i] = 0.f; accB[i] = 0.f; }
+
+    const unsigned char* Wstrip = reinterpret_cast<const unsigned char*>(W + (size_t)ct * CW) + (lane & 31) * 16;
+    const size_t rowStrideBytes = (size_t)Cs * sizeof(T);
+    // tile jt = rows [jt*JT*Q, +128) of W (the allocation is padded so that the last tile can over-read)
+    auto stage = [&](int jt, int buf) {
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            const int pairIdx = wave * DMA_PER_WAVE + i;              // wave-uniform
+            const int r = jt * (JT * Q) + pairIdx * 2 + (lane >> 5);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(Wstrip + (size_t)r * rowStrideBytes),
+                (__attribute__((address_space(3))) void*)(dca_smem + buf * TILE + pairIdx * 1024), 16, 0, 0);
+        }
+    };
 
     const int numJT = (L + JT - 1) / JT;
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)dca_smem + lane * 8;
+    stage(0, 0);
     for (int jt = 0; jt < numJT; ++jt) {
-        __syncthreads();
-        const T* src = W + (size_t)jt * ROWS * Cs + c0;
-        for (int v = tid; v < ROWS * VPR; v += WAVES * 64) {
-            const int r = v / VPR, cv = v % VPR;
-            *reinterpret_cast<V*>(tile + r * STRIDE + cv * VEC) =
-                *reinterpret_cast<const V*>(src + (size_t)r * Cs + cv * VEC);
-        }
-        uint32_t xw[JT / 4];
-#pragma unroll
-        for (int u = 0; u < JT / 4; ++u) xw[u] = X4[(size_t)(jt * (JT / 4) + u) * Npad + n];
-        __syncthreads();
-#pragma unroll
-        for (int jj = 0; jj < JT; ++jj) {
-            const int b = (xw[jj >> 2] >> (8 * (jj & 3))) & 0xFF;
-            const T* row = tile + (jj * Q + b) * STRIDE;
-#pragma unroll
-            for (int cv = 0; cv < VPR; ++cv) vadd(z + cv * VEC, *reinterpret_cast<const V*>(row + cv * VEC));
-        }
+        const int buf = jt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile jt have landed
+        __syncthreads();                                    // ... everyone's; and tile jt-1 is no longer read
+        if (jt + 1 < numJT) stage(jt + 1, buf ^ 1);
+        const uint16_t* sp = XL + (size_t)jt * JT * Npad + n0;     // wave-uniform
+        const uint32_t vbase = ldsBase + buf * TILE;
+        const uint32_t strideBytes = (uint32_t)Npad * 2u;
+        if constexpr (Q == 21 && sizeof(T) == 4) DCA_LOGITS_Q21_F32(vbase, sp, strideBytes, accA, accB);
+        else if constexpr (Q == 21) DCA_LOGITS_Q21_F64(vbase, sp, strideBytes, accA, accB);
+        else if constexpr (sizeof(T) == 4) DCA_LOGITS_Q5_F32(vbase, sp, strideBytes, accA, accB);
+        else DCA_LOGITS_Q5_F64(vbase, sp, strideBytes, accA, accB);
     }
-    if (n < N) {
-        T* dst = S + (size_t)n * Cs + c0;
-#pragma unroll
-        for (int cv = 0; cv < VPR; ++cv) *reinterpret_cast<V*>(dst + cv * VEC) = vpack(z + cv * VEC);
-    }
+    if (n0 < N)
+        logits_store(accA, accB, reinterpret_cast<unsigned char*>(S + (size_t)n0 * Cs + (size_t)ct * CW) + lane * 8,
+                     rowStrideBytes, N - n0);
 }
 
 // ------------------------------------------------------------------ softmax scan
@@ -238,10 +284,6 @@ __global__ void plm_build_states_kernel(const uint8_t* __restrict__ X, uint16_t*
     const int n = halo + k;
     XT2[(size_t)j * NT + k] = (uint16_t)(0x9000u | ((n < N) ? 2u * X[(size_t)n * Ls + j] : 0u));
 }
-
-typedef float dca_v32f __attribute__((ext_vector_type(32)));
-typedef float dca_v8f __attribute__((ext_vector_type(8)));
-typedef float dca_v2f __attribute__((ext_vector_type(2)));
 
 #include "scatter_gather_asm.inc"
 
@@ -621,24 +663,6 @@ __global__ void cast_weights_kernel(const double* __restrict__ wd, T* __restrict
     if (n < N) w[n] = (T)wd[n];
 }
 
-// X4[u][n] = bytes X[n][4u..4u+3]
-// (states already mapped through the per-site row permutation of W)
-__global__ void pack_x4_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ perm, uint32_t* __restrict__ X4,
-                               int N, int Npad, int L, int Ls, int Ls4, int q)
-{
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    const int u = blockIdx.y;
-    if (n >= Npad || u >= Ls4) return;
-    uint32_t v = 0;
-    if (n < N) {
-        for (int k = 0; k < 4; ++k) {
-            const int j = u * 4 + k;
-            if (j < L) v |= (uint32_t)perm[j * q + X[(size_t)n * Ls + j]] << (8 * k);
-        }
-    }
-    X4[(size_t)u * Npad + n] = v;
-}
-
 // ======================================================================
 // More-Thuente trial-interval update, restated from More & Thuente (1994) with the
 // safeguards the reference's library applies (lbfgs.cpp:1128-1295).  Scalars are double.
@@ -744,12 +768,11 @@ struct PlmEngine : PlmEngineBase {
     size_t P = 0;
     int Cs = 0;                  // row stride (elements) of W, SR, G
     int Wrows = 0, Grows = 0;
-    int Npad = 0, Ls4 = 0;
+    int Npad = 0;
     double lambda_h = 0, lambda_J = 0;
     int carry_mode = DCA_CARRY_CHUNKED, chunk = 128, warm = 40, halo = 0, add_reg = 1;
     bool configured = false;
     int numScanChunks = 0, numScatChunks = 0;
-    static constexpr int kLogitWaves = 8;
     static constexpr int kScatWaves = 16;
     int scatSplit = 1, scatChunksPerSplit = 0;
 
@@ -757,10 +780,9 @@ struct PlmEngine : PlmEngineBase {
     T* dS[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     T* dY[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     T *dWt = nullptr, *dSR = nullptr, *dG = nullptr, *dw = nullptr;
-    uint32_t* dX4 = nullptr;
+    uint16_t* dXL = nullptr;
     uint16_t* dXT2 = nullptr;
     int NT = 0;
-    uint8_t* dPerm = nullptr;
     unsigned char* dZeros = nullptr;
     PairIJ* dPairs = nullptr;
     double *dFxPart = nullptr, *dRegPart = nullptr, *dVecPart = nullptr;
@@ -788,12 +810,12 @@ struct PlmEngine : PlmEngineBase {
     {
         hipFree(dx); hipFree(dg); hipFree(dxp); hipFree(dgp); hipFree(dd);
         for (int i = 0; i < 5; ++i) { hipFree(dS[i]); hipFree(dY[i]); }
-        hipFree(dWt); hipFree(dSR); hipFree(dG); hipFree(dw); hipFree(dX4); hipFree(dXT2);
-        hipFree(dPairs); hipFree(dPerm); hipFree(dZeros); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
+        hipFree(dWt); hipFree(dSR); hipFree(dG); hipFree(dw); hipFree(dXL); hipFree(dXT2);
+        hipFree(dPairs); hipFree(dZeros); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
     }
     ~PlmEngine() override { freeall(); }
 
-    int jt() const { return q <= 8 ? 32 : 8; }
+    int jt() const { return logits_jt(q); }
 
     int configure(double lh, double lJ, int cmode, int chunk_, int warm_, int halo_, int add_reg_) override
     {
@@ -812,7 +834,7 @@ struct PlmEngine : PlmEngineBase {
         freeall();
         dx = dg = dxp = dgp = dd = nullptr;
         for (int i = 0; i < 5; ++i) dS[i] = dY[i] = nullptr;
-        dWt = dSR = dG = dw = nullptr; dX4 = nullptr; dXT2 = nullptr; dPerm = nullptr; dZeros = nullptr; dPairs = nullptr;
+        dWt = dSR = dG = dw = nullptr; dXL = nullptr; dXT2 = nullptr; dZeros = nullptr; dPairs = nullptr;
         dFxPart = dRegPart = dVecPart = nullptr;
         lbfgs_alloc = false;
         o = decltype(o)();
@@ -821,11 +843,10 @@ struct PlmEngine : PlmEngineBase {
         const int Lq = L * q;
         Cs = (int)round_up(Lq, 128);
         const int JT = jt();
-        Wrows = ceil_div(L, JT) * JT * q;
+        Wrows = ceil_div(L, JT) * JT * q + 128;     // + over-read margin of the last LDS-DMA tile
         const int JG = kScatJG;
         Grows = ceil_div(L, JG) * JG * q;
-        Npad = (int)round_up(N, 64 * kLogitWaves);
-        Ls4 = ceil_div(L, JT) * JT / 4;
+        Npad = (int)round_up(N, kLogitSeqPerWG);
 
         DCA_TRY(dalloc(&dx, P)); DCA_TRY(dalloc(&dg, P));
         DCA_TRY(dalloc(&dWt, (size_t)Wrows * Cs));
@@ -839,11 +860,10 @@ struct PlmEngine : PlmEngineBase {
             scatSplit = ceil_div(numScatChunks, scatChunksPerSplit);
         }
         DCA_TRY(dalloc(&dG, (size_t)scatSplit * Grows * Cs));
-        DCA_TRY(dalloc(&dPerm, (size_t)L * q));
         DCA_TRY(dalloc(&dZeros, kRowBytes));
         HIP_TRY(hipMemsetAsync(dZeros, 0, kRowBytes, ctx->stream));
         DCA_TRY(dalloc(&dw, N));
-        DCA_TRY(dalloc(&dX4, (size_t)Ls4 * Npad));
+        DCA_TRY(dalloc(&dXL, (size_t)ceil_div(L, JT) * JT * Npad));
         NT = numScatChunks * kNC;
         DCA_TRY(dalloc(&dXT2, (size_t)L * NT));
         const size_t npairs = (size_t)L * (L - 1) / 2;
@@ -865,33 +885,6 @@ struct PlmEngine : PlmEngineBase {
             for (int i = 0; i < L - 1; ++i) for (int j = i + 1; j < L; ++j) hp[k++] = PairIJ{(uint16_t)i, (uint16_t)j};
         }
         HIP_TRY(hipMemcpyAsync(dPairs, hp.data(), npairs * sizeof(PairIJ), hipMemcpyHostToDevice, ctx->stream));
-        std::vector<uint8_t> hperm;
-        {
-            std::vector<int> cnt((size_t)L * q, 0);
-            const uint8_t* X = ctx->hX.data();
-            for (int n = halo; n < N; ++n)
-                for (int i = 0; i < L; ++i) cnt[(size_t)i * q + X[(size_t)n * L + i]]++;
-            // row permutation of W within each site: physical rows r and r+16 share an LDS bank slot
-            // for the 16-byte reads of the logits kernel, so the 2(q-16) rarest states take rows
-            // 0..q-17 and 16..q-1 (rarest last) and the frequent states the collision-free rows between
-            hperm.assign((size_t)L * q, 0);
-            std::vector<int> order(q);
-            for (int i = 0; i < L; ++i) {
-                for (int a = 0; a < q; ++a) order[a] = a;
-                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cnt[(size_t)i * q + a] < cnt[(size_t)i * q + b]; });
-                const int extra = q > 16 ? q - 16 : 0;       // rows that have a colliding partner
-                // order[] ascending by count: order[0..extra) -> rows 16.., order[extra..2*extra) -> rows 0..extra,
-                // the rest -> rows extra..16
-                for (int k = 0; k < q; ++k) {
-                    int row;
-                    if (k < extra) row = 16 + k;
-                    else if (k < 2 * extra) row = k - extra;
-                    else row = k - extra;
-                    hperm[(size_t)i * q + order[k]] = (uint8_t)row;
-                }
-            }
-        }
-        HIP_TRY(hipMemcpyAsync(dPerm, hperm.data(), hperm.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
 
         // weights in T.  1/count is formed in T exactly as the reference does
@@ -911,8 +904,8 @@ struct PlmEngine : PlmEngineBase {
         HIP_TRY(hipMemcpy(dw, hw.data(), (size_t)N * sizeof(T), hipMemcpyHostToDevice));
 
         {
-            dim3 grid(ceil_div(Npad, 256), Ls4);
-            hipLaunchKernelGGL(pack_x4_kernel, grid, dim3(256), 0, ctx->stream, ctx->dX, dPerm, dX4, N, Npad, L, Ls, Ls4, q);
+            hipLaunchKernelGGL(plm_build_logit_states_kernel, dim3(ceil_div(Npad, 256), ceil_div(L, JT) * JT), dim3(256), 0,
+                               ctx->stream, ctx->dX, dXL, N, Npad, L, Ls);
             hipLaunchKernelGGL(plm_build_states_kernel, dim3(ceil_div(NT, 256), L), dim3(256), 0, ctx->stream,
                                ctx->dX, dXT2, N, L, Ls, halo, NT);
             HIP_TRY(hipGetLastError());
@@ -995,20 +988,18 @@ struct PlmEngine : PlmEngineBase {
         {
             ScopedKernelClock kc(ctx, "plm_expand");
             hipLaunchKernelGGL(plm_expand_kernel<T>, dim3((unsigned)npairs), dim3(256), (size_t)q * q * sizeof(T), st,
-                               dx, dWt, dPairs, dPerm, L, q, Cs);
+                               dx, dWt, dPairs, L, q, Cs);
         }
         {
-            constexpr int CT = Geo<T>::CT;
-            constexpr int JT = (Q <= 8) ? 32 : 8;
-            constexpr int W = kLogitWaves;
-            const int numCT = Cs / CT;
-            const int numNB = Npad / (64 * W);
+            constexpr int CW = 512 / (int)sizeof(T);
+            const int numCT = ceil_div(Cs, CW);
+            const int numNB = Npad / kLogitSeqPerWG;
             const int blocks = kNumXcd * ceil_div(numCT, kNumXcd) * numNB;
-            const size_t lds = (size_t)JT * Q * (CT + V16<T>::n) * sizeof(T);
-            auto kern = plm_logits_kernel<T, Q, CT, JT, W>;
+            const size_t lds = (size_t)2 * 128 * 512;
+            auto kern = plm_logits_kernel<T, Q>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ScopedKernelClock kc(ctx, "plm_logits");
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(W * 64), lds, st, dWt, dX4, dSR, N, Npad, L, Cs, numCT, numNB);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(kLogitWavesC * 64), lds, st, dWt, dXL, dSR, N, Npad, L, Cs, numCT, numNB);
         }
         {
             dim3 grid(ceil_div(L, 64), ceil_div(numScanChunks, 4));

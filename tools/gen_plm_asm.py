@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Generates pydca_amd/csrc/scatter_gather_asm.inc: the inline-asm gather blocks of
-plm_scatter_kernel (plm_engine.hip), one macro per (q, element type).
+"""Generates the inline-asm inner blocks of the two gather kernels of plm_engine.hip, one macro per
+(q, element type): pydca_amd/csrc/scatter_gather_asm.inc (plm_scatter_kernel, described first) and
+pydca_amd/csrc/logits_gather_asm.inc (plm_logits_kernel, described at logits_body below).
 
 One block = one wave, one 128-row x 512-byte LDS tile of R, JW = 2 sites:
 
@@ -110,8 +111,89 @@ def macro(q, f64):
     return "\n".join(lines)
 
 
+# ------------------------------------------------------------------------------------------ logits
+# One block = one wave, one LDS tile of JT sites, NB = 32 sequences, one 512-byte column strip.
+# For every site j of the tile:
+#
+#     w[b] = Wtile[(j, b)][lane]  for b in 0..q-1      (q ds_read_b64 with immediate offsets)
+#     for s in 0..31:  acc[s] += w[state(n0 + s, j)]   (source register selected through M0)
+#
+# i.e. the transpose of the scatter block: there the destination is indexed, here the source
+# (src1 relative: M0 image 0x2000 | 2 x state).  The q rows of W of the site sit in q register
+# pairs, so a (sequence, site) pair costs one SALU write of M0 and one packed add and no LDS access
+# of its own; the LDS reads are q per 32 pairs.  The 32 M0 images of a site arrive with one
+# s_load_dwordx16 that is issued one site ahead (two SGPR sets, ping-pong), so only the LDS latency
+# of the q row reads is exposed per site -- the other three waves of the SIMD cover it.
+#
+# Register plan: accumulators v[64:127] (two 32-register tuples), w rows v[64-2q : 63],
+# state words s[40:55] / s[56:71], temporaries s72 (zero), s73 (saved M0), s[74:75] (state pointer).
+NBSEQ = 32
+
+
+def logits_jt(q):
+    return {21: 6, 5: 24}[q]
+
+
+def logits_body(q, f64):
+    w0 = 64 - 2 * q
+    jt = logits_jt(q)
+    add = "v_add_f64" if f64 else "v_pk_add_f32"
+    sets = (S0, S0 + 16)
+    o = ["s_mov_b32 s%d, m0" % (T0 + 1),
+         "s_mov_b64 s[74:75], %[sptr]",
+         "s_mov_b32 s%d, 0" % T0,
+         "s_load_dwordx16 s[%d:%d], s[74:75], 0x0" % (sets[0], sets[0] + 15)]
+    for jj in range(jt):
+        cur = sets[jj % 2]
+        nxt = sets[(jj + 1) % 2]
+        if jj + 1 < jt:
+            o.append("s_add_u32 s74, s74, %[stride]")
+            o.append("s_addc_u32 s75, s75, 0")
+        for b in range(q):
+            o.append("ds_read_b64 v[%d:%d], %%[vbase] offset:%d" % (w0 + 2 * b, w0 + 2 * b + 1, (jj * q + b) * ROWBYTES))
+        o.append("s_waitcnt lgkmcnt(0)")
+        if jj + 1 < jt:
+            o.append("s_load_dwordx16 s[%d:%d], s[74:75], 0x0" % (nxt, nxt + 15))
+        o.append("s_set_gpr_idx_on s%d, 0x2" % T0)
+        for sq in range(NBSEQ):
+            w = cur + sq // 2
+            if sq % 2 == 0:
+                o.append("s_pack_ll_b32_b16 m0, s%d, 0" % w)
+            else:
+                o.append("s_lshr_b32 m0, s%d, 16" % w)
+            a = 64 + 2 * sq
+            o.append("%s v[%d:%d], v[%d:%d], v[%d:%d]" % (add, a, a + 1, a, a + 1, w0, w0 + 1))
+        o.append("s_set_gpr_idx_off")
+    o.append("s_mov_b32 m0, s%d" % (T0 + 1))
+    return o
+
+
+def logits_macro(q, f64):
+    w0 = 64 - 2 * q
+    lines = ["#define DCA_LOGITS_Q%d_%s(VBASE, SPTR, STRIDE, ACCA, ACCB) \\" % (q, "F64" if f64 else "F32"), "    asm volatile( \\"]
+    for ln in logits_body(q, f64):
+        lines.append('        "%s\\n" \\' % ln)
+    lines.append('        : "+{v[64:95]}"(ACCA), "+{v[96:127]}"(ACCB) \\')
+    lines.append('        : [vbase] "v"(VBASE), [sptr] "s"(SPTR), [stride] "s"(STRIDE) \\')
+    clob = ['"memory"'] + ['"v%d"' % (w0 + i) for i in range(2 * q)] + ['"s%d"' % (S0 + i) for i in range(32)] + \
+           ['"s%d"' % (T0 + i) for i in range(4)]
+    lines.append("        : %s)" % ", ".join(clob))
+    return "\n".join(lines)
+
+
 def main():
-    out = ["// GENERATED by tools/gen_scatter_asm.py -- do not edit by hand.",
+    here = os.path.dirname(os.path.abspath(__file__))
+    lout = ["// GENERATED by tools/gen_plm_asm.py -- do not edit by hand.",
+            "// Inline-asm inner blocks of plm_logits_kernel; see the generator for the register plan.", ""]
+    for q in (21, 5):
+        for f64 in (0, 1):
+            lout.append(logits_macro(q, f64))
+            lout.append("")
+    lpath = os.path.join(here, "..", "pydca_amd", "csrc", "logits_gather_asm.inc")
+    with open(lpath, "w") as fh:
+        fh.write("\n".join(lout))
+    print("wrote", os.path.normpath(lpath))
+    out = ["// GENERATED by tools/gen_plm_asm.py -- do not edit by hand.",
            "// Inline-asm gather blocks of plm_scatter_kernel; see the generator for the register plan.", ""]
     for q in (21, 5):
         for f64 in (0, 1):
