@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+#ifndef THREADS
+#define THREADS 1024
+#endif
 #define R4(x) x x x x
 #define R16(x) R4(x) R4(x) R4(x) R4(x)
 #define R64(x) R16(x) R16(x) R16(x) R16(x)
@@ -20,8 +23,9 @@ __global__ __launch_bounds__(1024) void k(float* out, long long* cyc, int iters)
         if (V == 0) asm volatile(R64("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n") : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(inc));
         if (V == 1) asm volatile(R64("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a7));
         if (V == 2) asm volatile(R64("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n") : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(d3));
-        if (V == 3) asm volatile(R64("s_lshr_b32 %0, %0, 1\n s_lshr_b32 %0, %0, 1\n s_lshr_b32 %0, %0, 1\n s_lshr_b32 %0, %0, 1\n") : "+s"(s0));
-        if (V == 4) asm volatile(R64("s_lshr_b32 %5, %5, 1\n v_pk_add_f32 %0, %0, %4\n s_lshr_b32 %5, %5, 1\n v_pk_add_f32 %1, %1, %4\n s_lshr_b32 %5, %5, 1\n v_pk_add_f32 %2, %2, %4\n s_lshr_b32 %5, %5, 1\n v_pk_add_f32 %3, %3, %4\n") : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(inc), "s"(s0));
+        if (V == 3) asm volatile(R64("v_add_f32_e64 %0, %0, %4\n v_add_f32_e64 %1, %1, %4\n v_add_f32_e64 %2, %2, %4\n v_add_f32_e64 %3, %3, %4\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a7));
+        if (V == 4) asm volatile(R64("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"));
+        if (V == 5) asm volatile(R64("v_add_f32 %0, %0, %4\n s_nop 0\n v_add_f32 %2, %2, %4\n s_nop 0\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a7));
     }
     long long t1 = __builtin_readcyclecounter();
     out[blockIdx.x * 1024 + threadIdx.x] = a0 + a1 + a2 + a3 + p0[0] + p1[1] + p2[0] + p3[1] + (float)(d0 + d1 + d2 + d3) + s0;
@@ -34,12 +38,12 @@ template <int V> void run(const char* name, float* dO, long long* dC)
     float best = 1e9;
     for (int r = 0; r < 3; ++r) {
         CHECK(hipEventRecord(a));
-        hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(1024), 0, 0, dO, dC, iters);
+        hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(THREADS), 0, 0, dO, dC, iters);
         CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
         float ms; CHECK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
     }
     long long c; CHECK(hipMemcpy(&c, dC, 8, hipMemcpyDeviceToHost));
-    const double ops = (double)iters * 256 * 16;   // wave-instructions per CU (V=4: pairs)
+    const double ops = (double)iters * 256 * (THREADS / 64);   // wave-instructions per CU (V=4: pairs)
     printf("%-22s %.3f ms  %.2f ns per wave-instr per CU -> %.2f clk @2.4GHz; s_memtime ticks %lld (%.1f MHz)\n", name, best, best * 1e6 / ops, best * 1e-3 * 2.4e9 / ops, c, c / (best * 1e3));
 }
 int main(int argc, char** argv)
@@ -50,8 +54,9 @@ int main(int argc, char** argv)
     if (which == 0) run<0>("v_pk_add_f32", dO, dC);
     if (which == 1) run<1>("v_add_f32", dO, dC);
     if (which == 2) run<2>("v_add_f64", dO, dC);
-    if (which == 3) run<3>("s_lshr_b32 (dependent)", dO, dC);
-    if (which == 4) run<4>("salu+pk_add pair", dO, dC);
+    if (which == 3) run<3>("v_add_f32_e64 (8 B)", dO, dC);
+    if (which == 4) run<4>("s_nop 0 (4 B)", dO, dC);
+    if (which == 5) run<5>("v_add_f32 + s_nop", dO, dC);
     fflush(stdout);
     return 0;
 }
