@@ -496,29 +496,73 @@ __global__ void plm_fold_fields_kernel(const T* __restrict__ x, const T* __restr
 constexpr int kVecBlocks = 1024;
 constexpr int kVecThreads = 256;
 
+// All vector kernels stream 16 bytes per lane and load (4 floats / 2 doubles): with 4-byte loads a
+// wave has too few bytes in flight to approach HBM bandwidth.  Element k of a pack is element
+// iv*VEC + k; the n % VEC tail is handled by the first threads with scalar accesses.  The mapping
+// of elements to threads is fixed, so every reduction is deterministic.
+template <typename T> struct Pack { T v[16 / sizeof(T)]; };
+template <typename T> __device__ __forceinline__ Pack<T> ldp(const T* p, size_t iv)
+{
+    using V = typename V16<T>::type;
+    const V r = reinterpret_cast<const V*>(p)[iv];
+    Pack<T> o;
+    if constexpr (sizeof(T) == 4) { o.v[0] = r.x; o.v[1] = r.y; o.v[2] = r.z; o.v[3] = r.w; }
+    else { o.v[0] = r.x; o.v[1] = r.y; }
+    return o;
+}
+template <typename T> __device__ __forceinline__ void stp(T* p, size_t iv, const Pack<T>& o)
+{
+    using V = typename V16<T>::type;
+    V r;
+    if constexpr (sizeof(T) == 4) { r.x = o.v[0]; r.y = o.v[1]; r.z = o.v[2]; r.w = o.v[3]; }
+    else { r.x = o.v[0]; r.y = o.v[1]; }
+    reinterpret_cast<V*>(p)[iv] = r;
+}
+#define DCA_VEC_LOOP(n, BODY_PACK, BODY_TAIL)                                                             \
+    {                                                                                                      \
+        constexpr int VEC = 16 / (int)sizeof(T);                                                           \
+        const size_t nv_ = (n) / VEC, stride_ = (size_t)gridDim.x * blockDim.x;                            \
+        const size_t t0_ = blockIdx.x * (size_t)blockDim.x + threadIdx.x;                                  \
+        for (size_t iv = t0_; iv < nv_; iv += stride_) { BODY_PACK }                                       \
+        for (size_t i = nv_ * VEC + t0_; i < (n); i += stride_) { BODY_TAIL }                              \
+    }
+
 template <typename T>
 __global__ void vec_neg_kernel(T* __restrict__ d, const T* __restrict__ g, size_t n)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = -g[i];
+    DCA_VEC_LOOP(n,
+        Pack<T> a = ldp(g, iv);
+        _Pragma("unroll") for (int k = 0; k < VEC; ++k) a.v[k] = -a.v[k];
+        stp(d, iv, a);,
+        d[i] = -g[i];)
 }
 template <typename T>
 __global__ void vec_axpy_kernel(T* __restrict__ y, T a, const T* __restrict__ x, size_t n)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] += a * x[i];
+    DCA_VEC_LOOP(n,
+        Pack<T> yy = ldp(y, iv); const Pack<T> xx = ldp(x, iv);
+        _Pragma("unroll") for (int k = 0; k < VEC; ++k) yy.v[k] += a * xx.v[k];
+        stp(y, iv, yy);,
+        y[i] += a * x[i];)
 }
 template <typename T>
 __global__ void vec_scale_kernel(T* __restrict__ y, T a, size_t n)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] *= a;
+    DCA_VEC_LOOP(n,
+        Pack<T> yy = ldp(y, iv);
+        _Pragma("unroll") for (int k = 0; k < VEC; ++k) yy.v[k] *= a;
+        stp(y, iv, yy);,
+        y[i] *= a;)
 }
 // x = xp + stp*d, as lbfgs.cpp:902-903 (copy, then add the rounded product)
 template <typename T>
-__global__ void vec_step_kernel(T* __restrict__ x, const T* __restrict__ xp, T stp, const T* __restrict__ d, size_t n)
+__global__ void vec_step_kernel(T* __restrict__ x, const T* __restrict__ xp, T stpv, const T* __restrict__ d, size_t n)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        T v = stp * d[i];
-        x[i] = xp[i] + v;
-    }
+    DCA_VEC_LOOP(n,
+        const Pack<T> dd = ldp(d, iv); Pack<T> xx = ldp(xp, iv);
+        _Pragma("unroll") for (int k = 0; k < VEC; ++k) { const T v = stpv * dd.v[k]; xx.v[k] = xx.v[k] + v; }
+        stp(x, iv, xx);,
+        { const T v = stpv * d[i]; x[i] = xp[i] + v; })
 }
 
 __device__ __forceinline__ void block_reduce_store(double v, double* red, double* out)
@@ -540,10 +584,13 @@ __global__ void vec_dot3_kernel(const T* __restrict__ a, const T* __restrict__ b
 {
     __shared__ double red[kVecThreads];
     double s0 = 0, s1 = 0, s2 = 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double av = a[i], bv = b[i], cv = c[i];
-        s0 += av * bv; s1 += cv * cv; s2 += av * av;
-    }
+    DCA_VEC_LOOP(n,
+        const Pack<T> pa = ldp(a, iv); const Pack<T> pb = ldp(b, iv); const Pack<T> pc = ldp(c, iv);
+        _Pragma("unroll") for (int k = 0; k < VEC; ++k) {
+            const double av = pa.v[k]; const double bv = pb.v[k]; const double cv = pc.v[k];
+            s0 += av * bv; s1 += cv * cv; s2 += av * av;
+        },
+        { const double av = a[i]; const double bv = b[i]; const double cv = c[i]; s0 += av * bv; s1 += cv * cv; s2 += av * av; })
     block_reduce_store(s0, red, partials + blockIdx.x);
     block_reduce_store(s1, red, partials + gridDim.x + blockIdx.x);
     block_reduce_store(s2, red, partials + 2 * gridDim.x + blockIdx.x);
@@ -553,8 +600,10 @@ __global__ void vec_dot_kernel(const T* __restrict__ a, const T* __restrict__ b,
 {
     __shared__ double red[kVecThreads];
     double s0 = 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        s0 += (double)a[i] * (double)b[i];
+    DCA_VEC_LOOP(n,
+        const Pack<T> pa = ldp(a, iv); const Pack<T> pb = ldp(b, iv);
+        _Pragma("unroll") for (int k = 0; k < VEC; ++k) s0 += (double)pa.v[k] * (double)pb.v[k];,
+        s0 += (double)a[i] * (double)b[i];)
     block_reduce_store(s0, red, partials + blockIdx.x);
 }
 // s = x - xp, y = g - gp, partials: y.s, y.y   (lbfgs.cpp:546-558)
@@ -564,11 +613,17 @@ __global__ void vec_diff_kernel(T* __restrict__ s, T* __restrict__ y, const T* _
 {
     __shared__ double red[kVecThreads];
     double s0 = 0, s1 = 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const T sv = x[i] - xp[i], yv = g[i] - gp[i];
-        s[i] = sv; y[i] = yv;
-        s0 += (double)yv * (double)sv; s1 += (double)yv * (double)yv;
-    }
+    DCA_VEC_LOOP(n,
+        const Pack<T> px = ldp(x, iv); const Pack<T> pxp = ldp(xp, iv); const Pack<T> pg = ldp(g, iv); const Pack<T> pgp = ldp(gp, iv);
+        Pack<T> ps; Pack<T> py;
+        _Pragma("unroll") for (int k = 0; k < VEC; ++k) {
+            const T sv = px.v[k] - pxp.v[k]; const T yv = pg.v[k] - pgp.v[k];
+            ps.v[k] = sv; py.v[k] = yv;
+            s0 += (double)yv * (double)sv; s1 += (double)yv * (double)yv;
+        }
+        stp(s, iv, ps); stp(y, iv, py);,
+        { const T sv = x[i] - xp[i]; const T yv = g[i] - gp[i]; s[i] = sv; y[i] = yv;
+          s0 += (double)yv * (double)sv; s1 += (double)yv * (double)yv; })
     block_reduce_store(s0, red, partials + blockIdx.x);
     block_reduce_store(s1, red, partials + gridDim.x + blockIdx.x);
 }
@@ -591,18 +646,21 @@ void vec_gram_kernel(VecPtrs5 P, const T* __restrict__ g, int e, size_t n, doubl
     for (int v = 0; v < 25; ++v) acc[v] = 0.0;
     const T* se = static_cast<const T*>(P.s[e]);
     const T* ye = static_cast<const T*>(P.y[e]);
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double gv = g[i], sev = se[i], yev = ye[i];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const double sk = static_cast<const T*>(P.s[k])[i], yk = static_cast<const T*>(P.y[k])[i];
-            acc[k] += sk * gv;
-            acc[5 + k] += yk * gv;
-            acc[10 + k] += sev * yk;
-            acc[15 + k] += yev * sk;
-            acc[20 + k] += yev * yk;
-        }
-    }
+    DCA_VEC_LOOP(n,
+        const Pack<T> pg = ldp(g, iv); const Pack<T> pse = ldp(se, iv); const Pack<T> pye = ldp(ye, iv);
+        _Pragma("unroll") for (int k = 0; k < 5; ++k) {
+            const Pack<T> psk = ldp(static_cast<const T*>(P.s[k]), iv); const Pack<T> pyk = ldp(static_cast<const T*>(P.y[k]), iv);
+            _Pragma("unroll") for (int u = 0; u < VEC; ++u) {
+                const double gv = pg.v[u]; const double sev = pse.v[u]; const double yev = pye.v[u];
+                const double sk = psk.v[u]; const double yk = pyk.v[u];
+                acc[k] += sk * gv; acc[5 + k] += yk * gv; acc[10 + k] += sev * yk; acc[15 + k] += yev * sk; acc[20 + k] += yev * yk;
+            }
+        },
+        { const double gv = g[i]; const double sev = se[i]; const double yev = ye[i];
+          _Pragma("unroll") for (int k = 0; k < 5; ++k) {
+              const double sk = static_cast<const T*>(P.s[k])[i]; const double yk = static_cast<const T*>(P.y[k])[i];
+              acc[k] += sk * gv; acc[5 + k] += yk * gv; acc[10 + k] += sev * yk; acc[15 + k] += yev * sk; acc[20 + k] += yev * yk;
+          } })
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int v = 0; v < 25; ++v) {
@@ -622,13 +680,21 @@ void vec_gram_kernel(VecPtrs5 P, const T* __restrict__ g, int e, size_t n, doubl
 template <typename T>
 __global__ void vec_compose_kernel(T* __restrict__ d, const T* __restrict__ g, VecPtrs5 P, DirCoefs c, size_t n)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        double v = c.g * (double)g[i];
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-            v += c.s[k] * (double)static_cast<const T*>(P.s[k])[i] + c.y[k] * (double)static_cast<const T*>(P.y[k])[i];
-        d[i] = (T)v;
-    }
+    DCA_VEC_LOOP(n,
+        const Pack<T> pg = ldp(g, iv);
+        double v[VEC];
+        _Pragma("unroll") for (int u = 0; u < VEC; ++u) v[u] = c.g * (double)pg.v[u];
+        _Pragma("unroll") for (int k = 0; k < 5; ++k) {
+            const Pack<T> psk = ldp(static_cast<const T*>(P.s[k]), iv); const Pack<T> pyk = ldp(static_cast<const T*>(P.y[k]), iv);
+            _Pragma("unroll") for (int u = 0; u < VEC; ++u) v[u] += c.s[k] * (double)psk.v[u] + c.y[k] * (double)pyk.v[u];
+        }
+        Pack<T> o;
+        _Pragma("unroll") for (int u = 0; u < VEC; ++u) o.v[u] = (T)v[u];
+        stp(d, iv, o);,
+        { double v = c.g * (double)g[i];
+          _Pragma("unroll") for (int k = 0; k < 5; ++k)
+              v += c.s[k] * (double)static_cast<const T*>(P.s[k])[i] + c.y[k] * (double)static_cast<const T*>(P.y[k])[i];
+          d[i] = (T)v; })
 }
 
 // out[k] = sum_b partials[k*nb + b], k < nk; one block, fixed tree
