@@ -137,6 +137,11 @@ int dca_plm_scores(dca_ctx* ctx, int apc, double* scores_out);
  * its Python reader's alignment with pseudocount 0.5, plmdca.py:622-648). */
 int dca_plm_di_scores(dca_ctx* ctx, const double* reg_fi, int apc, double* scores_out);
 
+/* (q-1)x(q-1) coupling blocks of the current x for `npairs` site pairs (pairs[2k] < pairs[2k+1]),
+ * row-major a,b, as doubles; shift != 0 applies the zero-sum gauge of PlmDCA.shift_couplings
+ * (plmdca.py:320-342).  Feeds PlmDCA.compute_params (plmdca.py:345-434). */
+int dca_plm_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift, double* out);
+
 /* ------------------------------------------------------------------ mfDCA
  * Stage functions mirror pydca/meanfield_dca/msa_numerics.py; all float64. */
 int dca_mf_single_site_freqs(dca_ctx* ctx, double* fi_out /* L*q, gap last (:53-89) */);
@@ -150,6 +155,12 @@ int dca_mf_scores(dca_ctx* ctx, int apc, double* scores_out);
 /* DI / DI_APC of the couplings (meanfield_dca.py:793-899; msa_numerics.py:378-533), pair order;
  * needs dca_mf_corr_mat + dca_mf_couplings (or dca_mf_run) first */
 int dca_mf_di_scores(dca_ctx* ctx, int apc, double* scores_out);
+/* local fields of the global model, L*(q-1) doubles (MeanFieldDCA.compute_fields,
+ * meanfield_dca.py:588-633); needs the couplings */
+int dca_mf_fields(dca_ctx* ctx, double* fields_out);
+/* coupling blocks of selected pairs, optionally gauge shifted (MeanFieldDCA.compute_params,
+ * meanfield_dca.py:661-752; shift_couplings :636-658) */
+int dca_mf_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift, double* out);
 /* whole chain on the device: counts -> C -> -inv -> scores */
 int dca_mf_run(dca_ctx* ctx, double pseudocount, int apc, double* scores_out, double* couplings_out /* may be NULL */);
 /* stage API on caller-provided arrays: construct_corr_mat (:270-318) from regularised

@@ -6,7 +6,9 @@ Reference (relative to /root/reference/pydca/):
                                   corr mat :270-318, couplings :321-342)
   meanfield_dca/msa_numerics.py  (two-site fields :378-470, DI :473-533; plmDCA twin
                                   plmdca/msa_numerics.py :156-311)
-  meanfield_dca/meanfield_dca.py (FN :902-943, APC :946-988, DI :793-899)
+  meanfield_dca/meanfield_dca.py (FN :902-943, APC :946-988, DI :793-899, fields :588-633,
+                                  shift_couplings :636-658, compute_params :661-752)
+  plmdca/plmdca.py               (compute_params :345-434)
   plmdca/plmdca.py               (gap stripping :246-268, FN :437-481, APC :484-524)
   fasta_reader/fasta_reader.py   (letter->int :34-45,:122-163)
 
@@ -261,3 +263,57 @@ def plm_di(x, reg_fi, L, q, apc_correct=False):
     widens the float32 couplings to float64 before exp."""
     di = direct_info(plm_blocks(np.asarray(x), L, q).astype(np.float64), reg_fi, L, q)
     return apc(di, L) if apc_correct else di
+
+
+def compute_fields(couplings, reg_fi, L, q):
+    """MeanFieldDCA.compute_fields (meanfield_dca.py:588-633): per site
+    log(f_i(a)/f_i(q)) - sum_{j!=i} J_ij f_j (gap state dropped) -> [L, q-1]."""
+    qm1 = q - 1
+    f = reg_fi[:, :qm1]
+    J4 = couplings.reshape(L, qm1, L, qm1)
+    total = np.einsum("iajb,jb->ia", J4, f)
+    diag = np.einsum("iaib,ib->ia", J4, f)
+    return np.log(f / reg_fi[:, qm1:q]) - (total - diag)
+
+
+def shift_couplings(block):
+    """shift_couplings (meanfield_dca.py:636-658, plmdca.py:320-342) in the dtype of `block`."""
+    block = np.asarray(block)
+    return block - block.mean(axis=1, keepdims=True) - block.mean(axis=0, keepdims=True) + block.mean()
+
+
+def select_ranked_pairs(sorted_scores, L, linear_dist=4, num_site_pairs=None):
+    """Pair selection of compute_params (meanfield_dca.py:715-745, plmdca.py:398-428) without a
+    reference sequence: walk the ranked list, keep |i-j| > linear_dist, stop after num_site_pairs
+    (default: L)."""
+    if num_site_pairs is None:
+        num_site_pairs = L
+    out = []
+    for (i, j), _score in sorted_scores:
+        if abs(i - j) > linear_dist:
+            if len(out) >= num_site_pairs:
+                break
+            out.append((i, j))
+    return out
+
+
+def mf_compute_params(couplings, reg_fi, sorted_scores, L, q, linear_dist=4, num_site_pairs=None):
+    qm1 = q - 1
+    fields = compute_fields(couplings, reg_fi, L, q)
+    pairs = select_ranked_pairs(sorted_scores, L, linear_dist, num_site_pairs)
+    blocks = [(pr, shift_couplings(couplings[pr[0] * qm1:(pr[0] + 1) * qm1, pr[1] * qm1:(pr[1] + 1) * qm1]).reshape(-1))
+              for pr in pairs]
+    return tuple((i, fields[i]) for i in range(L)), tuple(blocks)
+
+
+def plm_compute_params(x, sorted_scores, L, q, linear_dist=4, num_site_pairs=None):
+    """PlmDCA.compute_params on a packed float32 vector (fields/couplings keep its dtype)."""
+    x = np.asarray(x)
+    qm1 = q - 1
+    h = x[:L * q].reshape(L, q)[:, :qm1]
+    J = plm_blocks(x, L, q)
+    iu, ju = np.triu_indices(L, k=1)
+    index = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(iu, ju))}
+    pairs = select_ranked_pairs(sorted_scores, L, linear_dist, num_site_pairs)
+    blocks = [(pr, shift_couplings(J[index[pr]]).reshape(-1)) for pr in pairs]
+    return tuple((i, h[i]) for i in range(L)), tuple(blocks)

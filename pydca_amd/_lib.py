@@ -81,6 +81,9 @@ def lib():
         "dca_plm_scores": (i, [vp, i, vp]),
         "dca_plm_di_scores": (i, [vp, vp, i, vp]),
         "dca_mf_di_scores": (i, [vp, i, vp]),
+        "dca_plm_pair_couplings": (i, [vp, vp, i, i, vp]),
+        "dca_mf_fields": (i, [vp, vp]),
+        "dca_mf_pair_couplings": (i, [vp, vp, i, i, vp]),
         "dca_mf_single_site_freqs": (i, [vp, vp]),
         "dca_mf_pair_site_freqs": (i, [vp, vp]),
         "dca_mf_corr_mat": (i, [vp, d, vp]),
@@ -109,7 +112,8 @@ EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_read_msa", 
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_num_params", "dca_plm_init_x",
            "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook",
            "dca_plm_lbfgs_begin", "dca_plm_lbfgs_iterate", "dca_plm_scores", "dca_plm_di_scores",
-           "dca_mf_di_scores", "dca_mf_single_site_freqs",
+           "dca_mf_di_scores", "dca_plm_pair_couplings", "dca_mf_fields", "dca_mf_pair_couplings",
+           "dca_mf_single_site_freqs",
            "dca_mf_pair_site_freqs", "dca_mf_corr_mat", "dca_mf_couplings", "dca_mf_scores", "dca_mf_run",
            "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_set_profiling", "dca_get_kernel_time",
            "dca_reset_kernel_times", "plmdcaBackend", "freeFieldsAndCouplings"]
@@ -256,7 +260,26 @@ class Context:
         check(self._l.dca_plm_di_scores(self._h, _ptr(reg_fi), int(bool(apc)), _ptr(out)))
         return out
 
+    def _pair_couplings(self, fn, pairs, shift):
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        qm = self.q - 1
+        out = np.zeros((pairs.shape[0], qm, qm), dtype=np.float64)
+        if pairs.shape[0]:
+            check(fn(self._h, _ptr(pairs), int(pairs.shape[0]), int(bool(shift)), _ptr(out)))
+        return out
+
+    def plm_pair_couplings(self, pairs, shift=True):
+        return self._pair_couplings(self._l.dca_plm_pair_couplings, pairs, shift)
+
     # ---- mfDCA
+    def mf_pair_couplings(self, pairs, shift=True):
+        return self._pair_couplings(self._l.dca_mf_pair_couplings, pairs, shift)
+
+    def mf_fields(self):
+        out = np.zeros((self.L, self.q - 1), dtype=np.float64)
+        check(self._l.dca_mf_fields(self._h, _ptr(out)))
+        return out
+
     def mf_di_scores(self, apc=False):
         out = np.zeros(self.L * (self.L - 1) // 2, dtype=np.float64)
         check(self._l.dca_mf_di_scores(self._h, int(bool(apc)), _ptr(out)))

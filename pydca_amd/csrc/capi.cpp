@@ -236,6 +236,21 @@ int dca_mf_pair_site_freqs(dca_ctx* ctx, double* fij_out) { CHECK_CTX(ctx); DCA_
 int dca_mf_corr_mat(dca_ctx* ctx, double pseudocount, double* corr_out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_corr(ctx->mf, pseudocount, corr_out); }
 int dca_mf_couplings(dca_ctx* ctx, double* out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_couplings(ctx->mf, out); }
 int dca_mf_scores(dca_ctx* ctx, int apc, double* out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_scores(ctx->mf, apc, out); }
+int dca_plm_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift, double* out)
+{
+    CHECK_CTX(ctx);
+    DCA_TRY(need_plm(ctx));
+    if (npairs < 0 || (npairs > 0 && (!pairs || !out))) return DCA_ERR_ARG;
+    return ctx->plm->pair_couplings(pairs, npairs, shift, out);
+}
+int dca_mf_fields(dca_ctx* ctx, double* out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); if (!out) return DCA_ERR_ARG; return dca_mf_engine_fields(ctx->mf, out); }
+int dca_mf_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift, double* out)
+{
+    CHECK_CTX(ctx);
+    DCA_TRY(need_mf(ctx));
+    if (npairs < 0 || (npairs > 0 && (!pairs || !out))) return DCA_ERR_ARG;
+    return dca_mf_engine_pair_couplings(ctx->mf, pairs, npairs, shift, out);
+}
 int dca_mf_di_scores(dca_ctx* ctx, int apc, double* out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_di(ctx->mf, apc, out); }
 int dca_mf_run(dca_ctx* ctx, double pseudocount, int apc, double* scores_out, double* couplings_out)
 {

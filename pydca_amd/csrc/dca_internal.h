@@ -116,6 +116,7 @@ struct PlmEngineBase {
     virtual int lbfgs_iterate(int iterations, dca_plm_stats* st) = 0;
     virtual int scores(int apc, double* out) = 0;
     virtual int di_scores(const double* reg_fi, int apc, double* out) = 0;
+    virtual int pair_couplings(const int* pairs, int npairs, int shift, double* out) = 0;
     dca_reduce_hook hook = nullptr;
     void* hook_user = nullptr;
 };
@@ -130,6 +131,9 @@ int dca_fn_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L,
 int dca_di_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, const double* dRegFi, int L, int q, int ld,
                   int apc, double* dScoresOut /* device, pairs */);
 
+int dca_pair_blocks(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L, int q, int ld, const int* pairs, int npairs,
+                    int shift, double* out /* host */);
+
 // ---- mf engine
 struct MfEngine;
 MfEngine* dca_make_mf_engine(dca_ctx* ctx);
@@ -140,6 +144,8 @@ int dca_mf_engine_corr(MfEngine*, double theta, double* corr_out);
 int dca_mf_engine_couplings(MfEngine*, double* out);
 int dca_mf_engine_scores(MfEngine*, int apc, double* out);
 int dca_mf_engine_di(MfEngine*, int apc, double* out);
+int dca_mf_engine_fields(MfEngine*, double* out);
+int dca_mf_engine_pair_couplings(MfEngine*, const int* pairs, int npairs, int shift, double* out);
 
 // ---- cholinv.hip : in-place inverse of an SPD matrix on the device (f64 MFMA)
 // dA: n x n row-major (ld = n), n multiple of 64.  On return dA holds inv(A) (full, symmetric).

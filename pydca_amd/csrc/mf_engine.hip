@@ -433,3 +433,50 @@ int dca_mf_engine_di(MfEngine* m, int apc, double* out)
     hipFree(dOut);
     return rc;
 }
+
+namespace {
+// fields_i[a] = log(f_i(a) / f_i(q)) - sum_{j != i} sum_b J[(i,a)][(j,b)] f_j(b)   (compute_fields,
+// meanfield_dca.py:588-633).  One workgroup per row (i,a) of J; the diagonal block is skipped.
+__global__ __launch_bounds__(256)
+void mf_fields_kernel(const double* __restrict__ J, const double* __restrict__ regfi, int L, int q, int ld, double* __restrict__ out)
+{
+    __shared__ double red[256];
+    const int qm = q - 1;
+    const int r = blockIdx.x, i = r / qm, a = r % qm;
+    double s = 0.0;
+    for (int c = threadIdx.x; c < L * qm; c += 256) {
+        const int j = c / qm, b = c % qm;
+        if (j != i) s += J[(size_t)r * ld + c] * regfi[j * q + b];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[r] = log(regfi[i * q + a] / regfi[i * q + qm]) - red[0];
+}
+}  // namespace
+
+int dca_mf_engine_fields(MfEngine* m, double* out)
+{
+    if (!m->have_J) { dca_set_error("dca_mf_couplings first"); return DCA_ERR_STATE; }
+    dca_ctx* ctx = m->ctx;
+    if (!m->dRegFi) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dRegFi), (size_t)m->Lq * sizeof(double)));
+    hipLaunchKernelGGL(mf_regfi_kernel, dim3(ceil_div(m->Lq, 256)), dim3(256), 0, ctx->stream, m->dFi, m->dRegFi, m->Lq, m->q, m->theta);
+    const int n = m->L * (m->q - 1);
+    double* dOut = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), (size_t)n * sizeof(double)));
+    hipLaunchKernelGGL(mf_fields_kernel, dim3(n), dim3(256), 0, ctx->stream, m->dJ, m->dRegFi, m->L, m->q, m->np, dOut);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dOut, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dOut);
+    if (e != hipSuccess) { dca_set_error("fields: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
+    return DCA_OK;
+}
+
+int dca_mf_engine_pair_couplings(MfEngine* m, const int* pairs, int npairs, int shift, double* out)
+{
+    if (!m->have_J) { dca_set_error("dca_mf_couplings first"); return DCA_ERR_STATE; }
+    return dca_pair_blocks(m->ctx, m->dJ, 1, DCA_F64, m->L, m->q, m->np, pairs, npairs, shift, out);
+}

@@ -1357,6 +1357,13 @@ struct PlmEngine : PlmEngineBase {
         hipFree(dOut);
         return rc;
     }
+    // (q-1)x(q-1) blocks of the current x for selected pairs (compute_params, plmdca.py:345-434)
+    int pair_couplings(const int* pairs, int npairs, int shift, double* out) override
+    {
+        if (!configured) return DCA_ERR_STATE;
+        return dca_pair_blocks(ctx, dx, 0, (int)sizeof(T) * 8, L, q, 0, pairs, npairs, shift, out);
+    }
+
     // DI of the current x (plmdca.py:683-790); reg_fi: host, L*q regularised single-site frequencies
     int di_scores(const double* reg_fi, int apc, double* out) override
     {

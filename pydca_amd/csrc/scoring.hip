@@ -195,6 +195,50 @@ void di_kernel(const S* __restrict__ src, int kind, const double* __restrict__ r
     if (t == 0) di[p] = acc;
 }
 
+// Coupling blocks of selected site pairs, optionally shifted to the zero-sum gauge
+// (shift_couplings, meanfield_dca.py:636-658 / plmdca.py:320-342): J - rowmean - colmean + mean.
+// One 64-lane workgroup per requested pair; out[p][(q-1)*(q-1)] doubles.
+template <typename S>
+__global__ __launch_bounds__(64)
+void pair_blocks_kernel(const S* __restrict__ src, int kind, const int* __restrict__ pairs, int L, int q, int ld, int shift,
+                        double* __restrict__ out)
+{
+    __shared__ double blk[20 * 20];
+    __shared__ double rowm[20], colm[20];
+    __shared__ double tot;
+    const int qm = q - 1;
+    const int i = pairs[2 * blockIdx.x], j = pairs[2 * blockIdx.x + 1];
+    const size_t p = pair_index(L, i, j);
+    const int t = threadIdx.x;
+    for (int e = t; e < qm * qm; e += 64) {
+        const int a = e / qm, b = e % qm;
+        double v;
+        if (kind == 0) v = (double)src[(size_t)L * q + p * (size_t)q * q + (size_t)a * q + b];
+        else v = (double)src[(size_t)(i * qm + a) * ld + (size_t)j * qm + b];
+        blk[e] = v;
+    }
+    __syncthreads();
+    if (shift) {
+        if (t < qm) {
+            double s = 0, c = 0;
+            for (int b = 0; b < qm; ++b) s += blk[t * qm + b];
+            for (int a = 0; a < qm; ++a) c += blk[a * qm + t];
+            rowm[t] = s / qm;
+            colm[t] = c / qm;
+        }
+        if (t == 63) {
+            double s = 0;
+            for (int e = 0; e < qm * qm; ++e) s += blk[e];
+            tot = s / (double)(qm * qm);
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < qm * qm; e += 64) {
+        const int a = e / qm, b = e % qm;
+        out[(size_t)blockIdx.x * qm * qm + e] = shift ? blk[e] - rowm[a] - colm[b] + tot : blk[e];
+    }
+}
+
 }  // namespace
 
 int dca_fn_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L, int q, int ld, int apc, double* dOut)
@@ -242,5 +286,32 @@ int dca_di_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, const 
         if (e != hipSuccess) { dca_set_error("apc: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     }
     HIP_TRY(hipGetLastError());
+    return DCA_OK;
+}
+
+// pairs: host array of 2*npairs ints (i < j); out: host, npairs*(q-1)^2 doubles
+int dca_pair_blocks(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L, int q, int ld, const int* pairs, int npairs,
+                    int shift, double* out)
+{
+    if (npairs <= 0) return DCA_OK;
+    if (q > 21) { dca_set_error("q too large"); return DCA_ERR_ARG; }
+    for (int k = 0; k < npairs; ++k)
+        if (pairs[2 * k] < 0 || pairs[2 * k] >= pairs[2 * k + 1] || pairs[2 * k + 1] >= L) { dca_set_error("site pair %d out of order or range", k); return DCA_ERR_ARG; }
+    const size_t per = (size_t)(q - 1) * (q - 1);
+    int* dPairs = nullptr;
+    double* dOut = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dPairs), (size_t)npairs * 2 * sizeof(int)));
+    if (hipMalloc(reinterpret_cast<void**>(&dOut), (size_t)npairs * per * sizeof(double)) != hipSuccess) { hipFree(dPairs); return DCA_ERR_NOMEM; }
+    hipError_t e = hipMemcpyAsync(dPairs, pairs, (size_t)npairs * 2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        if (dtype == DCA_F32)
+            hipLaunchKernelGGL(pair_blocks_kernel<float>, dim3(npairs), dim3(64), 0, ctx->stream, static_cast<const float*>(src), src_kind, dPairs, L, q, ld, shift, dOut);
+        else
+            hipLaunchKernelGGL(pair_blocks_kernel<double>, dim3(npairs), dim3(64), 0, ctx->stream, static_cast<const double*>(src), src_kind, dPairs, L, q, ld, shift, dOut);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dOut, (size_t)npairs * per * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dPairs); hipFree(dOut);
+    if (e != hipSuccess) { dca_set_error("pair blocks: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     return DCA_OK;
 }

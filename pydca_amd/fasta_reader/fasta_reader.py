@@ -23,6 +23,12 @@ class FastaReaderError(Exception):
     """Raised for problems while reading alignment data."""
 
 
+def res_to_char(biomolecule):
+    """fasta_reader.py:53-76: int -> letter ('.' and '~' excluded, so 21 / 5 maps to '-')."""
+    RES_TO_INT = RES_TO_INT_ALL[biomolecule.strip().upper()]
+    return {val: key for key, val in RES_TO_INT.items() if key not in ('.', '~')}
+
+
 def get_alignment_from_fasta_file(file_name):
     """-> list of upper-cased sequence strings (fasta_reader.py:81-119)."""
     alignment, name, cur = [], None, []

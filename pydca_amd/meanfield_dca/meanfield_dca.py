@@ -192,6 +192,72 @@ class MeanFieldDCA:
         self.__couplings = self.__ctx.mf_couplings()
         return self.__couplings
 
+    def compute_fields(self, couplings=None):
+        """meanfield_dca.py:588-633 -> {site: float64[q-1]}.  With couplings=None the couplings of
+        the current pseudocount are (re)computed on the device and the field sums run there too
+        (one workgroup per row of J); a caller-supplied matrix is used as given, on the host."""
+        q = self.__num_site_states
+        logger.info('\n\tComputing local fields of the global probability function')
+        if couplings is None:
+            self._device_scores(False)
+            f = self.__ctx.mf_fields()
+        else:
+            reg_fi = self.get_reg_single_site_freqs()
+            L, qm1 = self.__sequences_len, q - 1
+            J4 = np.asarray(couplings).reshape(L, qm1, L, qm1)
+            p = reg_fi[:, :qm1]
+            total = np.einsum('iajb,jb->ia', J4, p) - np.einsum('iaib,ib->ia', J4, p)
+            f = np.log(p / reg_fi[:, qm1:q]) - total
+        return {i: f[i] for i in range(self.__sequences_len)}
+
+    def shift_couplings(self, couplings_ij):
+        """meanfield_dca.py:636-658 (zero-sum gauge of one block)."""
+        qm1 = self.__num_site_states - 1
+        couplings_ij = np.reshape(couplings_ij, (qm1, qm1))
+        avx = np.reshape(np.mean(couplings_ij, axis=1), (qm1, 1))
+        avy = np.reshape(np.mean(couplings_ij, axis=0), (1, qm1))
+        return couplings_ij - avx - avy + np.mean(couplings_ij)
+
+    def compute_params(self, seqbackmapper=None, ranked_by=None, linear_dist=None, num_site_pairs=None):
+        """meanfield_dca.py:661-752: fields of every site and the gauge-shifted couplings of the top
+        site pairs of a ranking.  The blocks are cut and shifted on the device; only the selected
+        (q-1)^2 blocks travel to the host."""
+        if seqbackmapper is not None:
+            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
+        if ranked_by is None:
+            ranked_by = 'fn_apc'
+        if linear_dist is None:
+            linear_dist = 4
+        RANKING_METHODS = ('FN', 'FN_APC', 'DI', 'DI_APC')
+        ranked_by = ranked_by.strip().upper()
+        if ranked_by not in RANKING_METHODS:
+            logger.error('\n\tInvalid ranking criterion {}.\nChoose from {}'.format(ranked_by, RANKING_METHODS))
+            raise MeanFieldDCAException
+        dca_scores = {'FN': self.compute_sorted_FN, 'FN_APC': self.compute_sorted_FN_APC, 'DI': self.compute_sorted_DI,
+                      'DI_APC': self.compute_sorted_DI_APC}[ranked_by]()
+        f = self.__ctx.mf_fields()
+        L = self.__sequences_len
+        if num_site_pairs is None:
+            num_site_pairs = L
+        fields_mapped = [(i, f[i]) for i in range(L)]
+        logger.info('\n\tExtracting couplings for top {} site pairs (i, j) with |i - j| > {} and ranked by {}'.format(
+            num_site_pairs, linear_dist, ranked_by))
+        pairs = []
+        count_pairs = 0
+        for pair, _score in dca_scores:
+            if abs(pair[0] - pair[1]) > linear_dist:
+                count_pairs += 1
+                if count_pairs > num_site_pairs:
+                    break
+                pairs.append(pair)
+        if count_pairs < num_site_pairs:
+            logger.warning('\n\tObtained couplings for only {} ranked site pairs.'
+                           '\n\tThis is the maximum number of site paris we can obtain under '
+                           'the given criteria'.format(count_pairs))
+        blocks = self.__ctx.mf_pair_couplings(pairs, shift=True)
+        couplings_ranked = [(pair, blocks[k].reshape(-1)) for k, pair in enumerate(pairs)]
+        return tuple(fields_mapped), tuple(couplings_ranked)
+
     def compute_sorted_DI(self, seqbackmapper=None):
         """meanfield_dca.py:793-845 (two-site model fields + direct information, msa_numerics.py:378-533,
         one workgroup per site pair on the device)."""

@@ -1,5 +1,5 @@
-"""`mfdca` command line (mirror of pydca/mfdca_main.py:310-394).  compute_fn and compute_di run on
-the GPU; the other sub-commands exist with the same flags and report that they are not accelerated yet."""
+"""`mfdca` command line (mirror of pydca/mfdca_main.py:310-394).  every sub-command the reference's
+parser exposes (compute_di, compute_fn, compute_params, compute_fi, compute_fij) runs on the GPU."""
 import logging
 import os
 import sys
@@ -23,14 +23,44 @@ def execute_from_command_line(msa_file=None, biomolecule=None, seqid=None, pseud
         configure_logging()
     if refseq_file:
         raise NotImplementedError('--refseq_file (reference-sequence back-mapping) is outside the accelerated path')
-    if the_command.strip() not in ('compute_fn', 'compute_di'):
-        raise NotImplementedError('{} is not part of the accelerated compute_fn path yet'.format(the_command))
     mfdca_instance = meanfield_dca.MeanFieldDCA(msa_file, biomolecule, pseudocount=pseudocount, seqid=seqid, device=device)
     param_metadata = dca_utilities.mfdca_param_metadata(mfdca_instance)
     if not output_dir:
         msa_file_base_name, _ext = os.path.splitext(os.path.basename(msa_file))
         output_dir = 'MFDCA_output_' + msa_file_base_name
     dca_utilities.create_directories(output_dir)
+    if the_command.strip() == 'compute_params':
+        fields, couplings = mfdca_instance.compute_params(ranked_by=ranked_by, linear_dist=linear_dist,
+                                                          num_site_pairs=num_site_pairs)
+        fields_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='fields_', postfix='.txt')
+        param_metadata.append('#\tTotal number of sites whose fields are extracted: {}'.format(len(fields)))
+        dca_utilities.write_fields_csv(fields_file_path, fields, metadata=param_metadata)
+        couplings_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='couplings_', postfix='.txt')
+        param_metadata.pop()
+        param_metadata.append('#\tTotal number of site pairs whose couplings are extracted: {}'.format(len(couplings)))
+        if ranked_by is None:
+            ranked_by = 'FN_APC'
+        param_metadata.append('#\tDCA ranking method used: {}'.format(ranked_by))
+        if linear_dist is None:
+            linear_dist = 4
+        param_metadata.append('#\tMinimum separation beteween site pairs in sequence: |i - j| > {}'.format(linear_dist))
+        dca_utilities.write_couplings_csv(couplings_file_path, couplings, metadata=param_metadata)
+        return fields_file_path, couplings_file_path
+    if the_command.strip() == 'compute_fi':
+        # pass --pseudocount 0.0 if raw frequencies are desired
+        fi = mfdca_instance.get_reg_single_site_freqs()
+        metadata = param_metadata + dca_utilities.mfdca_residue_repr_metadata(mfdca_instance.biomolecule)
+        fi_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='fi_', postfix='.txt')
+        dca_utilities.write_single_site_freqs(fi_file_path, fi, seqs_len=mfdca_instance.sequences_len,
+                                              num_site_states=mfdca_instance.num_site_states, metadata=metadata)
+        return fi_file_path
+    if the_command.strip() == 'compute_fij':
+        file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='fij_', postfix='.txt')
+        metadata = param_metadata + dca_utilities.mfdca_residue_repr_metadata(mfdca_instance.biomolecule)
+        fij = mfdca_instance.get_reg_pair_site_freqs()
+        dca_utilities.write_pair_site_freqs(file_path, fij, seqs_len=mfdca_instance.sequences_len,
+                                            num_site_states=mfdca_instance.num_site_states, metadata=metadata)
+        return file_path
     if the_command.strip() == 'compute_di':
         if apc:
             sorted_DI = mfdca_instance.compute_sorted_DI_APC()

@@ -183,6 +183,51 @@ class PlmDCA:
         logger.info('\n\tPerforming average product correction (APC) of FN  of DCA scores')
         return _ranked(ctx.plm_scores(True), self.__seqs_len)
 
+    def compute_params(self, seqbackmapper=None, ranked_by=None, linear_dist=None, num_site_pairs=None):
+        """plmdca.py:345-434: fields of every site (gap state dropped) and the gauge-shifted couplings
+        of the top site pairs of a ranking, float32 like the reference's backend array.  Unlike the
+        reference the optimisation is run once here, not once per scoring call."""
+        if seqbackmapper is not None:
+            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
+        if ranked_by is None:
+            ranked_by = 'fn_apc'
+        if linear_dist is None:
+            linear_dist = 4
+        RANKING_METHODS = ('FN', 'FN_APC', 'DI', 'DI_APC')
+        ranked_by = ranked_by.strip().upper()
+        if ranked_by not in RANKING_METHODS:
+            logger.error('\n\tInvalid ranking criterion {}.\nChoose from {}'.format(ranked_by, RANKING_METHODS))
+            raise PlmDCAException
+        ctx = self._run_backend()
+        L, q = self.__seqs_len, self.__num_site_states
+        if ranked_by in ('FN', 'FN_APC'):
+            scores = ctx.plm_scores(ranked_by == 'FN_APC')
+        else:
+            scores = ctx.plm_di_scores(self.get_reg_single_site_freqs(), ranked_by == 'DI_APC')
+        dca_scores = _ranked(scores, L)
+        self.__fields_and_couplings_all = ctx.plm_get_x(np.float32)
+        h = self.__fields_and_couplings_all[:L * q].reshape(L, q)[:, :q - 1]
+        if num_site_pairs is None:
+            num_site_pairs = L
+        fields_mapped = [(i, h[i]) for i in range(L)]
+        logger.info('\n\tExtracting couplings for top {} site pairs (i, j) with |i - j| > {} and ranked by {}'.format(
+            num_site_pairs, linear_dist, ranked_by))
+        pairs = []
+        count_pairs = 0
+        for pair, _score in dca_scores:
+            if abs(pair[0] - pair[1]) > linear_dist:
+                count_pairs += 1
+                if count_pairs > num_site_pairs:
+                    break
+                pairs.append(pair)
+        if count_pairs < num_site_pairs:
+            logger.warning('\n\tObtained couplings for only {} ranked site pairs.'
+                           '\n\tThis is the maximum number of site paris we can obtain under '
+                           'the given criteria'.format(count_pairs))
+        blocks = ctx.plm_pair_couplings(pairs, shift=True).astype(np.float32)
+        couplings_ranked = [(pair, blocks[k].reshape(-1)) for k, pair in enumerate(pairs)]
+        return tuple(fields_mapped), tuple(couplings_ranked)
+
     def get_single_site_freqs(self):
         """plmdca.py:590-621: frequencies of the PYTHON reader's alignment (unknown letters -> gap,
         duplicates dropped, fasta_reader.py:122-163) with float64 weights, on the device."""

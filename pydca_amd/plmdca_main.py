@@ -1,6 +1,5 @@
 """`plmdca` command line (mirror of pydca/plmdca_main.py:262-330): same sub-commands, flags,
-output directory and file names.  compute_fn and compute_di run on the GPU; compute_params
-is the next row of the scope table and says so."""
+output directory and file names.  compute_fn, compute_di and compute_params run on the GPU."""
 import logging
 import os
 import sys
@@ -56,7 +55,23 @@ def execute_from_command_line(biomolecule, msa_file, the_command=None, refseq_fi
                 di_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='PLMDCA_raw_di_scores_', postfix='.txt')
             dca_utilities.write_sorted_dca_scores(di_file_path, sorted_DI, metadata=param_metadata, score_type=score_type)
             return di_file_path
-        raise NotImplementedError('{} is not part of the accelerated compute_fn path yet'.format(the_command))
+        if the_command == 'compute_params':
+            fields, couplings = plmdca_instance.compute_params(ranked_by=ranked_by, linear_dist=linear_dist,
+                                                               num_site_pairs=num_site_pairs)
+            fields_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='fields_', postfix='.txt')
+            param_metadata.append('#\tTotal number of sites whose fields are extracted: {}'.format(len(fields)))
+            dca_utilities.write_fields_csv(fields_file_path, fields, metadata=param_metadata)
+            couplings_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='couplings_', postfix='.txt')
+            param_metadata.pop()
+            param_metadata.append('#\tTotal number of site pairs whose couplings are extracted: {}'.format(len(couplings)))
+            if ranked_by is None:
+                ranked_by = 'FN_APC'
+            param_metadata.append('#\tDCA ranking method used: {}'.format(ranked_by))
+            if linear_dist is None:
+                linear_dist = 4
+            param_metadata.append('#\tMinimum separation beteween site pairs in sequence: |i - j| > {}'.format(linear_dist))
+            dca_utilities.write_couplings_csv(couplings_file_path, couplings, metadata=param_metadata)
+            return fields_file_path, couplings_file_path
     return None
 
 

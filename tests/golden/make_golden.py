@@ -210,11 +210,41 @@ def di_golden(tag, path, bio, pseudocount, seqid, plm_seqid=None):
     print("di_%s: mf top %.6g  plm top %.6g" % (tag, out["mf_di"].max(), out["plm_di"].max()))
 
 
+def params_golden(tag, path, bio, pseudocount, seqid):
+    """MeanFieldDCA.compute_fields / compute_params goldens through the stubbed import
+    (meanfield_dca.py:588-752), three rankings with different filters."""
+    from pydca.meanfield_dca import meanfield_dca
+    inst = meanfield_dca.MeanFieldDCA(path, bio, pseudocount=pseudocount, seqid=seqid)
+    L = inst.sequences_len
+    fd = inst.compute_fields()
+    out = dict(L=L, q=inst.num_site_states, pseudocount=pseudocount, seqid=seqid,
+               fields=np.array([fd[i] for i in range(L)]))
+    for name, kw in (("default", {}), ("fn_ld2_n5", dict(ranked_by="fn", linear_dist=2, num_site_pairs=5)),
+                     ("diapc_ld1_n40", dict(ranked_by="DI_APC", linear_dist=1, num_site_pairs=40))):
+        fields, couplings = inst.compute_params(**kw)
+        out["%s_field_sites" % name] = np.array([s for s, _ in fields], dtype=np.int32)
+        out["%s_fields" % name] = np.array([f for _, f in fields])
+        out["%s_pairs" % name] = np.array([p for p, _ in couplings], dtype=np.int32).reshape(-1, 2)
+        out["%s_couplings" % name] = np.array([c for _, c in couplings]).reshape(len(couplings), -1)
+    np.savez_compressed(os.path.join(HERE, "params_%s.npz" % tag), **out)
+    print("params_%s: %d default pairs, first %s" % (tag, len(out["default_pairs"]), out["default_pairs"][:1]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-slow", action="store_true")
+    ap.add_argument("--only-params", action="store_true", help="regenerate only params_*.npz")
     ap.add_argument("--only-di", action="store_true", help="regenerate only di_*.npz (needs plm_*.npz present)")
     args = ap.parse_args()
+    if args.only_params:
+        tmp = tempfile.mkdtemp(prefix="pydca_stubs_")
+        try:
+            install_stubs(tmp)
+            params_golden("toy_rna", os.path.join(DATA, "toy_rna.fa"), "rna", 0.5, 0.8)
+            params_golden("toy_protein", os.path.join(DATA, "toy_protein.fa"), "protein", 0.5, 0.8)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return
     if args.only_di:
         tmp = tempfile.mkdtemp(prefix="pydca_stubs_")
         try:
@@ -270,6 +300,8 @@ def main():
         di_golden("toy_rna", toy_rna, "rna", 0.5, 0.8)
         di_golden("toy_protein", toy_prot, "protein", 0.5, 0.8)
         di_golden("rf71", rf71, "rna", 0.5, 0.8)
+        params_golden("toy_rna", toy_rna, "rna", 0.5, 0.8)
+        params_golden("toy_protein", toy_prot, "protein", 0.5, 0.8)
         if not args.skip_slow:
             mf_golden("pf02826", pf, "protein", 0.5, 0.8, stages=False)
     finally:

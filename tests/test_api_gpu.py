@@ -193,3 +193,57 @@ def test_direct_information_through_the_classes(tmp_path):
     out = plmdca_main.run_plm_dca(["compute_di", "rna", data_file("toy_rna.fa"), "--max_iterations", "5",
                                    "--output_dir", str(tmp_path / "p")])
     assert os.path.basename(out) == "PLMDCA_raw_di_scores_toy_rna.txt"
+
+
+def test_compute_params_and_frequency_outputs(tmp_path, oracle_mf):
+    """compute_params of both classes and the mfdca compute_params / compute_fi /
+    compute_fij sub-commands: reference-named files, reference's own values."""
+    from pydca_amd import mfdca_main, plmdca_main
+    from pydca_amd.meanfield_dca.meanfield_dca import MeanFieldDCA, MeanFieldDCAException
+    from pydca_amd.plmdca.plmdca import PlmDCA
+    G = golden("params_toy_protein")
+    f = data_file("toy_protein.fa")
+    inst = MeanFieldDCA(f, "protein", pseudocount=0.5, seqid=0.8)
+    fd = inst.compute_fields()
+    assert rel_err(np.array([fd[i] for i in range(int(G["L"]))]), G["fields"]) <= 1e-8
+    for name, kw in (("default", {}), ("fn_ld2_n5", dict(ranked_by="fn", linear_dist=2, num_site_pairs=5)),
+                     ("diapc_ld1_n40", dict(ranked_by="DI_APC", linear_dist=1, num_site_pairs=40))):
+        fields, couplings = inst.compute_params(**kw)
+        assert [s for s, _ in fields] == list(G[name + "_field_sites"])
+        assert [tuple(p) for p, _ in couplings] == [tuple(p) for p in G[name + "_pairs"]]
+        assert rel_err(np.array([c for _, c in couplings]), G[name + "_couplings"]) <= 1e-7
+    with pytest.raises(MeanFieldDCAException):
+        inst.compute_params(ranked_by="xyz")
+    # a caller-supplied couplings matrix goes through the host branch of compute_fields
+    fd2 = inst.compute_fields(couplings=inst.get_couplings())
+    assert rel_err(np.array([fd2[i] for i in range(int(G["L"]))]), G["fields"]) <= 1e-8
+
+    p = PlmDCA(data_file("toy_rna.fa"), "rna", seqid=0.8, lambda_h=1.8, lambda_J=1.8, max_iterations=20)
+    fields, couplings = p.compute_params(ranked_by="fn", linear_dist=2, num_site_pairs=4)
+    x = p.get_fields_and_couplings_from_backend()
+    ref_fields, ref_couplings = oracle_mf.plm_compute_params(x, oracle_mf.sort_scores(oracle_mf.plm_fn(x, 10, 5, apc_correct=False), 10),
+                                                             10, 5, linear_dist=2, num_site_pairs=4)
+    assert [pr for pr, _ in couplings] == [pr for pr, _ in ref_couplings]
+    np.testing.assert_allclose(np.array([c for _, c in couplings]), np.array([c for _, c in ref_couplings]), rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(np.array([h for _, h in fields]), np.array([h for _, h in ref_fields]))
+
+    out = mfdca_main.run_meanfield_dca(["compute_params", "protein", f, "--output_dir", str(tmp_path / "m")])
+    assert [os.path.basename(o) for o in out] == ["fields_toy_protein.txt", "couplings_toy_protein.txt"]
+    rows = [ln for ln in open(out[0]).read().splitlines() if not ln.startswith("#")]
+    assert len(rows) == 8 and len(rows[0].split(",")) == 21
+    assert abs(float(rows[0].split(",")[1]) - G["fields"][0, 0]) <= 1e-7 * abs(G["fields"][0, 0])
+    crow = [ln for ln in open(out[1]).read().splitlines() if not ln.startswith("#")][0].split(",")
+    assert (int(crow[0]) - 1, int(crow[1]) - 1) == tuple(G["default_pairs"][0]) and len(crow) == 2 + 400
+    M = golden("mf_toy_rna")
+    out = mfdca_main.run_meanfield_dca(["compute_fi", "rna", data_file("toy_rna.fa"), "--output_dir", str(tmp_path / "f")])
+    assert os.path.basename(out) == "fi_toy_rna.txt"
+    rows = [ln.split(",") for ln in open(out).read().splitlines() if not ln.startswith("#")]
+    assert len(rows) == 10 * 5 and abs(float(rows[7][2]) - M["reg_fi"][1, 2]) < 1e-12
+    assert "# (1, 'A')(2, 'C')(3, 'G')(4, 'U')(5, '-')" in open(out).read()
+    out = mfdca_main.run_meanfield_dca(["compute_fij", "rna", data_file("toy_rna.fa"), "--output_dir", str(tmp_path / "f")])
+    rows = [ln.split(",") for ln in open(out).read().splitlines() if not ln.startswith("#")]
+    assert len(rows) == 45 * 16 and abs(float(rows[16 + 5][4]) - M["reg_fij"][1, 1, 1]) < 1e-12
+    out = plmdca_main.run_plm_dca(["compute_params", "rna", data_file("toy_rna.fa"), "--max_iterations", "5", "--ranked_by",
+                                   "di", "--num_site_pairs", "3", "--output_dir", str(tmp_path / "p")])
+    assert [os.path.basename(o) for o in out] == ["fields_toy_rna.txt", "couplings_toy_rna.txt"]
+    assert len([ln for ln in open(out[1]).read().splitlines() if not ln.startswith("#")]) == 3

@@ -382,3 +382,44 @@ def test_di_kernel_random_blocks_vs_oracle(L_, oracle_mf):
             np.testing.assert_allclose(ctx.plm_di_scores(fi, apc), oracle_mf.plm_di(x, fi, L, q, apc_correct=apc),
                                        rtol=1e-10, atol=1e-13)
         ctx.close()
+
+
+# ----------------------------------------------------------------------------- fields / params
+@pytest.mark.parametrize("tag", ["toy_rna", "toy_protein"])
+def test_mf_fields_and_pair_couplings_vs_reference(L_, tag):
+    """dca_mf_fields / dca_mf_pair_couplings vs MeanFieldDCA.compute_fields / compute_params of the
+    real reference (golden): fields <= 1e-8 relative (the couplings differ from LAPACK's at
+    ~1e-10), shifted blocks of the reference's own pair selection <= 1e-7."""
+    G, M = golden("params_" + tag), golden("mf_" + tag)
+    X1, q = M["X"], int(G["q"])
+    ctx = _mf_ctx(L_, X1, q, float(G["seqid"]))
+    ctx.mf_run(float(G["pseudocount"]), False)
+    assert rel_err(ctx.mf_fields(), G["fields"]) <= 1e-8
+    for name in ("default", "fn_ld2_n5", "diapc_ld1_n40"):
+        pairs = G[name + "_pairs"]
+        blocks = ctx.mf_pair_couplings(pairs, shift=True)
+        assert blocks.shape == (len(pairs), q - 1, q - 1)
+        if len(pairs):
+            assert rel_err(blocks.reshape(len(pairs), -1), G[name + "_couplings"]) <= 1e-7
+    raw = ctx.mf_pair_couplings([(0, 1)], shift=False)[0]
+    np.testing.assert_allclose(raw, M["couplings"][0:q - 1, q - 1:2 * (q - 1)], rtol=1e-8, atol=1e-10)
+    with pytest.raises(L_.DcaBackendError):
+        ctx.mf_pair_couplings([(3, 2)])
+    ctx.close()
+
+
+def test_plm_pair_couplings_vs_oracle(L_, oracle_mf):
+    P = golden("plm_toy_protein")
+    L, q = int(P["L"]), int(P["q"])
+    ctx = make_ctx(L_, P["X"], q, L_.DCA_F32)
+    ctx.plm_configure(1.0, 1.0)
+    ctx.plm_set_x(P["run_a"])
+    pairs = [(0, 5), (2, 7), (1, 2)]
+    got = ctx.plm_pair_couplings(pairs, shift=True)
+    J = oracle_mf.plm_blocks(P["run_a"], L, q).astype(np.float64)
+    iu, ju = np.triu_indices(L, k=1)
+    idx = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(iu, ju))}
+    for k, pr in enumerate(pairs):
+        np.testing.assert_allclose(got[k], oracle_mf.shift_couplings(J[idx[pr]]), rtol=1e-12, atol=1e-15)
+    np.testing.assert_array_equal(ctx.plm_pair_couplings(pairs, shift=False)[1], J[idx[(2, 7)]])
+    ctx.close()

@@ -191,3 +191,46 @@ def test_plm_direct_information_matches_reference(oracle_mf, tag, fname, bio):
     di = oracle_mf.plm_di(x, reg_fi, L, q)
     assert rel_err(di, g["plm_di"]) <= 1e-9
     assert np.array_equal(np.argsort(-di, kind="stable"), np.argsort(-g["plm_di"], kind="stable"))
+
+
+@pytest.mark.parametrize("tag,fname,bio", DI_CASES[:2])
+def test_mf_fields_and_params_match_reference(oracle_mf, tag, fname, bio):
+    """compute_fields / compute_params restatement vs the reference's own output
+    (meanfield_dca.py:588-752): fields <= 1e-9 relative, identical pair selection for three
+    rankings / filters, shifted couplings <= 1e-8 relative."""
+    g = golden("params_" + tag)
+    X = oracle_mf.letter2int(oracle_mf.read_fasta(data_file(fname)), bio)
+    L, q = int(g["L"]), int(g["q"])
+    theta, seqid = float(g["pseudocount"]), float(g["seqid"])
+    w = oracle_mf.compute_sequences_weight(X, seqid)
+    fi = oracle_mf.get_reg_single_site_freqs(oracle_mf.compute_single_site_freqs(X, q, w), L, q, theta)
+    fij = oracle_mf.get_reg_pair_site_freqs(oracle_mf.compute_pair_site_freqs(X, q, w), L, q, theta)
+    J = oracle_mf.compute_couplings(oracle_mf.construct_corr_mat(fi, fij, L, q))
+    assert rel_err(oracle_mf.compute_fields(J, fi, L, q), g["fields"]) <= 1e-9
+    fn = oracle_mf.frobenius_from_blocks(oracle_mf.mf_blocks(J, L, q))
+    di = oracle_mf.direct_info(oracle_mf.mf_blocks(J, L, q), fi, L, q)
+    rankings = {"default": (oracle_mf.apc(fn, L), {}), "fn_ld2_n5": (fn, dict(linear_dist=2, num_site_pairs=5)),
+                "diapc_ld1_n40": (oracle_mf.apc(di, L), dict(linear_dist=1, num_site_pairs=40))}
+    for name, (scores, kw) in rankings.items():
+        fields, couplings = oracle_mf.mf_compute_params(J, fi, oracle_mf.sort_scores(scores, L), L, q, **kw)
+        assert [s for s, _ in fields] == list(g[name + "_field_sites"])
+        assert rel_err(np.array([f for _, f in fields]), g[name + "_fields"]) <= 1e-9
+        assert [tuple(p) for p, _ in couplings] == [tuple(p) for p in g[name + "_pairs"]]
+        if len(couplings):
+            assert rel_err(np.array([c for _, c in couplings]), g[name + "_couplings"]) <= 1e-8
+
+
+def test_plm_compute_params_restatement(oracle_mf):
+    """PlmDCA.compute_params (plmdca.py:345-434) on the stored reference run: float32 fields and
+    shifted blocks, selection rule shared with the mfDCA variant (pinned above)."""
+    P = golden("plm_toy_rna")
+    L, q = int(P["L"]), int(P["q"])
+    x = P["run_a"]
+    ranked = oracle_mf.sort_scores(oracle_mf.plm_fn(x, L, q), L)
+    fields, couplings = oracle_mf.plm_compute_params(x, ranked, L, q, linear_dist=2, num_site_pairs=4)
+    assert len(fields) == L and fields[3][1].dtype == np.float32 and fields[3][1].shape == (q - 1,)
+    assert np.array_equal(fields[3][1], x[3 * q:3 * q + q - 1])
+    assert len(couplings) == 4 and all(abs(i - j) > 2 for (i, j), _ in couplings)
+    blk = couplings[0][1].reshape(q - 1, q - 1)
+    assert blk.dtype == np.float32
+    assert abs(blk.sum(axis=0)).max() < 1e-5 and abs(blk.sum(axis=1)).max() < 1e-5
