@@ -68,6 +68,21 @@ void freeFieldsAndCouplings(void* h_and_J);
 int dca_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count);
 int dca_count_msa_lines(const char* path);
 
+/* ------------------------------------------------------------------ reference-sequence back-mapping (host)
+ * Local pairwise alignment, Smith-Waterman with affine gaps (a gap of length n costs
+ * gap_open + (n-1)*gap_extend), standing in for Bio.pairwise2.align.localds as called by
+ * SequenceBackmapper.align_pairs_local (sequence_backmapper.py:186-230; biopython 1.74 is a
+ * dependency outside the reference tree).  sub: 26 x 26 substitution scores indexed by
+ * (letter - 'A').  dca_sw_scores is the search loop of find_matching_seqs_from_alignment
+ * (:233-283): best local score of ref against nseq sequences stored back to back in seqs,
+ * sequence k = seqs[offsets[k] .. offsets[k+1]).  dca_sw_align returns one optimal alignment:
+ * the aligned region (with '-') in aligned_a / aligned_b (capacity la + lb + 1 each) and the
+ * 0-based start of the region in each sequence. */
+int dca_sw_scores(const char* ref, int lref, const char* seqs, const int* offsets, int nseq, const int* sub,
+                  int gap_open, int gap_extend, int* scores_out);
+int dca_sw_align(const char* a, int la, const char* b, int lb, const int* sub, int gap_open, int gap_extend,
+                 int* score_out, int* start_a, int* start_b, char* aligned_a, char* aligned_b, int* aligned_len);
+
 /* ------------------------------------------------------------------ context */
 int dca_create(dca_ctx** out, int device, int precision /* DCA_F32 | DCA_F64 */);
 void dca_destroy(dca_ctx* ctx);

@@ -92,6 +92,9 @@ def lib():
         "dca_mf_run": (i, [vp, d, i, vp, vp]),
         "dca_mf_corr_from_freqs": (i, [vp, vp, vp, i, i, vp]),
         "dca_spd_inverse": (i, [vp, vp, i, vp]),
+        "dca_sw_scores": (i, [C.c_char_p, i, C.c_char_p, vp, i, vp, i, i, vp]),
+        "dca_sw_align": (i, [C.c_char_p, i, C.c_char_p, i, vp, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p,
+                             C.c_char_p, C.POINTER(i)]),
         "dca_set_profiling": (i, [vp, i]),
         "dca_get_kernel_time": (i, [vp, C.c_char_p, C.POINTER(d), C.POINTER(i)]),
         "dca_reset_kernel_times": (i, [vp]),
@@ -115,7 +118,7 @@ EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_read_msa", 
            "dca_mf_di_scores", "dca_plm_pair_couplings", "dca_mf_fields", "dca_mf_pair_couplings",
            "dca_mf_single_site_freqs",
            "dca_mf_pair_site_freqs", "dca_mf_corr_mat", "dca_mf_couplings", "dca_mf_scores", "dca_mf_run",
-           "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_set_profiling", "dca_get_kernel_time",
+           "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_sw_scores", "dca_sw_align", "dca_set_profiling", "dca_get_kernel_time",
            "dca_reset_kernel_times", "plmdcaBackend", "freeFieldsAndCouplings"]
 
 
@@ -346,3 +349,30 @@ class Context:
         ms, n = C.c_double(0), C.c_int(0)
         check(self._l.dca_get_kernel_time(self._h, tag.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+def sw_scores(ref, seqs, sub, gap_open, gap_extend):
+    """Best local alignment score of `ref` against every string of `seqs` (host code in libdca_hip.so)."""
+    L = lib()
+    enc = [s.encode("ascii") for s in seqs]
+    offs = np.zeros(len(enc) + 1, dtype=np.int32)
+    offs[1:] = np.cumsum([len(e) for e in enc])
+    blob = b"".join(enc)
+    sub = np.ascontiguousarray(sub, dtype=np.int32)
+    out = np.zeros(len(enc), dtype=np.int32)
+    r = ref.encode("ascii")
+    check(L.dca_sw_scores(r, len(r), blob, _ptr(offs), len(enc), _ptr(sub), int(gap_open), int(gap_extend), _ptr(out)))
+    return out
+
+
+def sw_align(a, b, sub, gap_open, gap_extend):
+    """One optimal local alignment -> (aligned_a, aligned_b, score, start_a, start_b)."""
+    L = lib()
+    ea, eb = a.encode("ascii"), b.encode("ascii")
+    sub = np.ascontiguousarray(sub, dtype=np.int32)
+    cap = len(ea) + len(eb) + 1
+    ba, bb = C.create_string_buffer(cap), C.create_string_buffer(cap)
+    score, sa, sb, n = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    check(L.dca_sw_align(ea, len(ea), eb, len(eb), _ptr(sub), int(gap_open), int(gap_extend), C.byref(score), C.byref(sa),
+                         C.byref(sb), ba, bb, C.byref(n)))
+    return ba.value.decode("ascii"), bb.value.decode("ascii"), score.value, sa.value, sb.value

@@ -152,3 +152,14 @@ def write_pair_site_freqs(file_name, fij, seqs_len=None, num_site_states=None, m
                         fh.write('{},{},{},{},{}\n'.format(i + 1, j + 1, a + 1, b + 1, fij[pair_counter, a, b]))
                 pair_counter += 1
     return None
+
+
+def write_trimmed_msa(file_name, msa_trimmer=None, columns_to_remove=None, metadata=None):
+    """dca_utilities.py:581-607: FASTA, one line per sequence, the listed columns dropped."""
+    logger.info('\n\tWritting trimmed MSA in to file {}'.format(file_name))
+    drop = set(columns_to_remove)
+    with open(file_name, 'w') as fh:
+        for record in msa_trimmer.alignment_data:
+            trimmed_seq = [record.seq[i] for i in range(len(record.seq)) if i not in drop]
+            fh.write('>{}\n{}\n'.format(record.id, ''.join(trimmed_seq)))
+    return None

@@ -87,3 +87,16 @@ def alignment_letter2int(alignment, biomolecule='protein'):
 def get_alignment_int_form(file_name, biomolecule='protein'):
     """fasta_reader.py:166-188."""
     return alignment_letter2int(get_alignment_from_fasta_file(file_name), biomolecule)
+
+
+def sequences_to_char_form(seqs_lst, biomolecule):
+    """fasta_reader.py:227-249: integer sequences -> strings (gap state -> '-')."""
+    RES_TO_CHAR = res_to_char(biomolecule)
+    return [''.join(RES_TO_CHAR[res] for res in seq_int) for seq_int in seqs_lst]
+
+
+def get_alignment_char_form(file_name, biomolecule='PROTEIN'):
+    """fasta_reader.py:191-224: the de-duplicated alignment with non-standard residues turned into
+    '-' (int form and back)."""
+    biomolecule = biomolecule.strip().upper()
+    return sequences_to_char_form(get_alignment_int_form(file_name, biomolecule=biomolecule), biomolecule)

@@ -171,19 +171,35 @@ class MeanFieldDCA:
                 raise e
             raise
 
+    def get_mapped_site_pairs_dca_scores(self, sorted_dca_scores, seqbackmapper):
+        """Keeps the site pairs whose two MSA columns map to the reference sequence and renames
+        them to reference positions (meanfield_dca.py:755-790, plmdca.py:527-562)."""
+        mapping_dict = seqbackmapper.map_to_reference_sequence()
+        self.__refseq_mapping_dict = mapping_dict
+        sorted_scores_mapped = list()
+        for pair, score in sorted_dca_scores:
+            try:
+                mapped_pair = mapping_dict[pair[0]], mapping_dict[pair[1]]
+            except KeyError:
+                pass
+            else:
+                sorted_scores_mapped.append((mapped_pair, score))
+        sorted_scores_mapped = sorted(sorted_scores_mapped, key=lambda k: k[1], reverse=True)
+        logger.info('\n\tTotal number of mapped sites: {}'.format(len(sorted_scores_mapped)))
+        return tuple(sorted_scores_mapped)
+
+    def _maybe_mapped(self, ranked, seqbackmapper):
+        return ranked if seqbackmapper is None else self.get_mapped_site_pairs_dca_scores(ranked, seqbackmapper)
+
     def compute_sorted_FN(self, seqbackmapper=None):
         """meanfield_dca.py:902-943."""
-        if seqbackmapper is not None:
-            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
         logger.info('\n\tComputing Frobenius norm of couplings')
-        return _ranked(self._device_scores(False), self.__sequences_len)
+        return self._maybe_mapped(_ranked(self._device_scores(False), self.__sequences_len), seqbackmapper)
 
     def compute_sorted_FN_APC(self, seqbackmapper=None):
         """meanfield_dca.py:946-988."""
-        if seqbackmapper is not None:
-            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
         logger.info('\n\tPerforming average product correction (APC) to Frobenius norm of couplings.')
-        return _ranked(self._device_scores(True), self.__sequences_len)
+        return self._maybe_mapped(_ranked(self._device_scores(True), self.__sequences_len), seqbackmapper)
 
     def get_couplings(self):
         """-inv(C) of the current pseudocount as float64[L(q-1), L(q-1)] (device resident
@@ -222,8 +238,6 @@ class MeanFieldDCA:
         """meanfield_dca.py:661-752: fields of every site and the gauge-shifted couplings of the top
         site pairs of a ranking.  The blocks are cut and shifted on the device; only the selected
         (q-1)^2 blocks travel to the host."""
-        if seqbackmapper is not None:
-            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
         if ranked_by is None:
             ranked_by = 'fn_apc'
         if linear_dist is None:
@@ -234,43 +248,50 @@ class MeanFieldDCA:
             logger.error('\n\tInvalid ranking criterion {}.\nChoose from {}'.format(ranked_by, RANKING_METHODS))
             raise MeanFieldDCAException
         dca_scores = {'FN': self.compute_sorted_FN, 'FN_APC': self.compute_sorted_FN_APC, 'DI': self.compute_sorted_DI,
-                      'DI_APC': self.compute_sorted_DI_APC}[ranked_by]()
+                      'DI_APC': self.compute_sorted_DI_APC}[ranked_by](seqbackmapper=seqbackmapper)
         f = self.__ctx.mf_fields()
         L = self.__sequences_len
+        if seqbackmapper is not None:
+            # refseq position -> MSA column (the scores above are in refseq positions)
+            mapping_dict = {value: key for key, value in self.__refseq_mapping_dict.items()}
+        else:
+            mapping_dict = {i: i for i in range(L)}
         if num_site_pairs is None:
-            num_site_pairs = L
-        fields_mapped = [(i, f[i]) for i in range(L)]
+            num_site_pairs = len(seqbackmapper.ref_sequence) if seqbackmapper is not None else len(mapping_dict.keys())
+        logger.info('\n\tExtracting fields')
+        fields_mapped = [(i, f[mapping_dict[i]]) for i in mapping_dict.keys()]
         logger.info('\n\tExtracting couplings for top {} site pairs (i, j) with |i - j| > {} and ranked by {}'.format(
             num_site_pairs, linear_dist, ranked_by))
-        pairs = []
+        pairs, names = [], []
         count_pairs = 0
         for pair, _score in dca_scores:
             if abs(pair[0] - pair[1]) > linear_dist:
                 count_pairs += 1
                 if count_pairs > num_site_pairs:
                     break
-                pairs.append(pair)
+                i, j = mapping_dict[pair[0]], mapping_dict[pair[1]]
+                if i > j:
+                    logger.error('\n\tInvalid site pair. Site pair (i, j) should be ordered in i < j')
+                    raise MeanFieldDCAException
+                pairs.append((i, j))
+                names.append(pair)
         if count_pairs < num_site_pairs:
             logger.warning('\n\tObtained couplings for only {} ranked site pairs.'
                            '\n\tThis is the maximum number of site paris we can obtain under '
                            'the given criteria'.format(count_pairs))
         blocks = self.__ctx.mf_pair_couplings(pairs, shift=True)
-        couplings_ranked = [(pair, blocks[k].reshape(-1)) for k, pair in enumerate(pairs)]
+        couplings_ranked = [(pair, blocks[k].reshape(-1)) for k, pair in enumerate(names)]
         return tuple(fields_mapped), tuple(couplings_ranked)
 
     def compute_sorted_DI(self, seqbackmapper=None):
         """meanfield_dca.py:793-845 (two-site model fields + direct information, msa_numerics.py:378-533,
         one workgroup per site pair on the device)."""
-        if seqbackmapper is not None:
-            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
         self._device_scores(False)
         logger.info('\n\tComputing direct information')
-        return _ranked(self.__ctx.mf_di_scores(False), self.__sequences_len)
+        return self._maybe_mapped(_ranked(self.__ctx.mf_di_scores(False), self.__sequences_len), seqbackmapper)
 
     def compute_sorted_DI_APC(self, seqbackmapper=None):
         """meanfield_dca.py:848-899."""
-        if seqbackmapper is not None:
-            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
         self._device_scores(False)
         logger.info('\n\tPerforming average product correction (APC) of DI scores')
-        return _ranked(self.__ctx.mf_di_scores(True), self.__sequences_len)
+        return self._maybe_mapped(_ranked(self.__ctx.mf_di_scores(True), self.__sequences_len), seqbackmapper)

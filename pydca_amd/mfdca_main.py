@@ -7,6 +7,7 @@ from argparse import ArgumentParser
 
 from .dca_utilities import dca_utilities
 from .meanfield_dca import meanfield_dca
+from .sequence_backmapper.sequence_backmapper import SequenceBackmapper
 
 logger = logging.getLogger(__name__)
 SUBCOMMANDS = ('compute_di', 'compute_fn', 'compute_params', 'compute_fi', 'compute_fij')
@@ -21,16 +22,18 @@ def execute_from_command_line(msa_file=None, biomolecule=None, seqid=None, pseud
                               linear_dist=None, num_site_pairs=None, device=0):
     if verbose:
         configure_logging()
-    if refseq_file:
-        raise NotImplementedError('--refseq_file (reference-sequence back-mapping) is outside the accelerated path')
     mfdca_instance = meanfield_dca.MeanFieldDCA(msa_file, biomolecule, pseudocount=pseudocount, seqid=seqid, device=device)
+    seqbackmapper = None
+    if refseq_file:   # do backmapping when a reference sequence file is provided
+        seqbackmapper = SequenceBackmapper(alignment_data=mfdca_instance.alignment, refseq_file=refseq_file,
+                                           biomolecule=mfdca_instance.biomolecule)
     param_metadata = dca_utilities.mfdca_param_metadata(mfdca_instance)
     if not output_dir:
         msa_file_base_name, _ext = os.path.splitext(os.path.basename(msa_file))
         output_dir = 'MFDCA_output_' + msa_file_base_name
     dca_utilities.create_directories(output_dir)
     if the_command.strip() == 'compute_params':
-        fields, couplings = mfdca_instance.compute_params(ranked_by=ranked_by, linear_dist=linear_dist,
+        fields, couplings = mfdca_instance.compute_params(seqbackmapper=seqbackmapper, ranked_by=ranked_by, linear_dist=linear_dist,
                                                           num_site_pairs=num_site_pairs)
         fields_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='fields_', postfix='.txt')
         param_metadata.append('#\tTotal number of sites whose fields are extracted: {}'.format(len(fields)))
@@ -63,22 +66,22 @@ def execute_from_command_line(msa_file=None, biomolecule=None, seqid=None, pseud
         return file_path
     if the_command.strip() == 'compute_di':
         if apc:
-            sorted_DI = mfdca_instance.compute_sorted_DI_APC()
+            sorted_DI = mfdca_instance.compute_sorted_DI_APC(seqbackmapper=seqbackmapper)
             score_type = ' MF DI average product corrected (APC)'
             di_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='MFDCA_apc_di_scores_', postfix='.txt')
         else:
-            sorted_DI = mfdca_instance.compute_sorted_DI()
+            sorted_DI = mfdca_instance.compute_sorted_DI(seqbackmapper=seqbackmapper)
             score_type = 'raw DI'
             di_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='MFDCA_raw_di_scores_', postfix='.txt')
         dca_utilities.write_sorted_dca_scores(di_file_path, sorted_DI, metadata=param_metadata, score_type=score_type)
         return di_file_path
     if apc:
         score_type = 'MFDCA Frobenius norm, average product corrected (APC)'
-        sorted_FN = mfdca_instance.compute_sorted_FN_APC()
+        sorted_FN = mfdca_instance.compute_sorted_FN_APC(seqbackmapper=seqbackmapper)
         fn_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='MFDCA_apc_fn_scores_', postfix='.txt')
     else:
         score_type = 'MFDCA raw Frobenius norm'
-        sorted_FN = mfdca_instance.compute_sorted_FN()
+        sorted_FN = mfdca_instance.compute_sorted_FN(seqbackmapper=seqbackmapper)
         fn_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='MFDCA_raw_fn_scores_', postfix='.txt')
     dca_utilities.write_sorted_dca_scores(fn_file_path, sorted_FN, metadata=param_metadata, score_type=score_type)
     return fn_file_path

@@ -166,29 +166,43 @@ class PlmDCA:
         return couplings_ij - avx - avy + np.mean(couplings_ij)
 
     # ---- scores
+    def get_mapped_site_pairs_dca_scores(self, sorted_dca_scores, seqbackmapper):
+        """Keeps the site pairs whose two MSA columns map to the reference sequence and renames
+        them to reference positions (meanfield_dca.py:755-790, plmdca.py:527-562)."""
+        mapping_dict = seqbackmapper.map_to_reference_sequence()
+        self.__refseq_mapping_dict = mapping_dict
+        sorted_scores_mapped = list()
+        for pair, score in sorted_dca_scores:
+            try:
+                mapped_pair = mapping_dict[pair[0]], mapping_dict[pair[1]]
+            except KeyError:
+                pass
+            else:
+                sorted_scores_mapped.append((mapped_pair, score))
+        sorted_scores_mapped = sorted(sorted_scores_mapped, key=lambda k: k[1], reverse=True)
+        logger.info('\n\tTotal number of mapped sites: {}'.format(len(sorted_scores_mapped)))
+        return tuple(sorted_scores_mapped)
+
+    def _maybe_mapped(self, ranked, seqbackmapper):
+        return ranked if seqbackmapper is None else self.get_mapped_site_pairs_dca_scores(ranked, seqbackmapper)
+
     def compute_sorted_FN(self, seqbackmapper=None):
         """plmdca.py:437-481."""
-        if seqbackmapper is not None:
-            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
         ctx = self._run_backend()
         self.__fields_and_couplings_all = None
         logger.info('\n\tComputing non-APC sorted DCA score')
-        return _ranked(ctx.plm_scores(False), self.__seqs_len)
+        return self._maybe_mapped(_ranked(ctx.plm_scores(False), self.__seqs_len), seqbackmapper)
 
     def compute_sorted_FN_APC(self, seqbackmapper=None):
         """plmdca.py:484-524."""
-        if seqbackmapper is not None:
-            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
         ctx = self._run_backend()
         logger.info('\n\tPerforming average product correction (APC) of FN  of DCA scores')
-        return _ranked(ctx.plm_scores(True), self.__seqs_len)
+        return self._maybe_mapped(_ranked(ctx.plm_scores(True), self.__seqs_len), seqbackmapper)
 
     def compute_params(self, seqbackmapper=None, ranked_by=None, linear_dist=None, num_site_pairs=None):
         """plmdca.py:345-434: fields of every site (gap state dropped) and the gauge-shifted couplings
         of the top site pairs of a ranking, float32 like the reference's backend array.  Unlike the
         reference the optimisation is run once here, not once per scoring call."""
-        if seqbackmapper is not None:
-            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
         if ranked_by is None:
             ranked_by = 'fn_apc'
         if linear_dist is None:
@@ -204,28 +218,39 @@ class PlmDCA:
             scores = ctx.plm_scores(ranked_by == 'FN_APC')
         else:
             scores = ctx.plm_di_scores(self.get_reg_single_site_freqs(), ranked_by == 'DI_APC')
-        dca_scores = _ranked(scores, L)
+        dca_scores = self._maybe_mapped(_ranked(scores, L), seqbackmapper)
         self.__fields_and_couplings_all = ctx.plm_get_x(np.float32)
-        h = self.__fields_and_couplings_all[:L * q].reshape(L, q)[:, :q - 1]
+        f = self.__fields_and_couplings_all[:L * q].reshape(L, q)[:, :q - 1]
+        if seqbackmapper is not None:
+            # refseq position -> MSA column (the scores above are in refseq positions)
+            mapping_dict = {value: key for key, value in self.__refseq_mapping_dict.items()}
+        else:
+            mapping_dict = {i: i for i in range(L)}
         if num_site_pairs is None:
-            num_site_pairs = L
-        fields_mapped = [(i, h[i]) for i in range(L)]
+            num_site_pairs = len(seqbackmapper.ref_sequence) if seqbackmapper is not None else len(mapping_dict.keys())
+        logger.info('\n\tExtracting fields')
+        fields_mapped = [(i, f[mapping_dict[i]]) for i in mapping_dict.keys()]
         logger.info('\n\tExtracting couplings for top {} site pairs (i, j) with |i - j| > {} and ranked by {}'.format(
             num_site_pairs, linear_dist, ranked_by))
-        pairs = []
+        pairs, names = [], []
         count_pairs = 0
         for pair, _score in dca_scores:
             if abs(pair[0] - pair[1]) > linear_dist:
                 count_pairs += 1
                 if count_pairs > num_site_pairs:
                     break
-                pairs.append(pair)
+                i, j = mapping_dict[pair[0]], mapping_dict[pair[1]]
+                if i > j:
+                    logger.error('\n\tInvalid site pair. Site pair (i, j) should be ordered in i < j')
+                    raise PlmDCAException
+                pairs.append((i, j))
+                names.append(pair)
         if count_pairs < num_site_pairs:
             logger.warning('\n\tObtained couplings for only {} ranked site pairs.'
                            '\n\tThis is the maximum number of site paris we can obtain under '
                            'the given criteria'.format(count_pairs))
         blocks = ctx.plm_pair_couplings(pairs, shift=True).astype(np.float32)
-        couplings_ranked = [(pair, blocks[k].reshape(-1)) for k, pair in enumerate(pairs)]
+        couplings_ranked = [(pair, blocks[k].reshape(-1)) for k, pair in enumerate(names)]
         return tuple(fields_mapped), tuple(couplings_ranked)
 
     def get_single_site_freqs(self):
@@ -257,13 +282,9 @@ class PlmDCA:
 
     def compute_sorted_DI(self, seqbackmapper=None):
         """plmdca.py:723-750."""
-        if seqbackmapper is not None:
-            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
-        return _ranked(self.compute_direct_info_unsorted_DI(False), self.__seqs_len)
+        return self._maybe_mapped(_ranked(self.compute_direct_info_unsorted_DI(False), self.__seqs_len), seqbackmapper)
 
     def compute_sorted_DI_APC(self, seqbackmapper=None):
         """plmdca.py:753-790."""
-        if seqbackmapper is not None:
-            raise NotImplementedError('reference-sequence back-mapping is outside the accelerated path (SURVEY 8f3)')
         logger.info('\n\tPerforming average product correction (APC) of DI scores')
-        return _ranked(self.compute_direct_info_unsorted_DI(True), self.__seqs_len)
+        return self._maybe_mapped(_ranked(self.compute_direct_info_unsorted_DI(True), self.__seqs_len), seqbackmapper)

@@ -7,6 +7,7 @@ from argparse import ArgumentParser
 
 from .dca_utilities import dca_utilities
 from .plmdca import plmdca
+from .sequence_backmapper.sequence_backmapper import SequenceBackmapper
 
 logger = logging.getLogger(__name__)
 DCA_COMPUTATION_SUBCOMMANDS = ('compute_fn', 'compute_di', 'compute_params')
@@ -22,8 +23,6 @@ def execute_from_command_line(biomolecule, msa_file, the_command=None, refseq_fi
                               exact_gradient=False):
     if verbose:
         configure_logging()
-    if refseq_file:
-        raise NotImplementedError('--refseq_file (reference-sequence back-mapping) is outside the accelerated path')
     plmdca_instance = plmdca.PlmDCA(msa_file, biomolecule, seqid=seqid, lambda_h=lambda_h, lambda_J=lambda_J,
                                     max_iterations=max_iterations, num_threads=num_threads, verbose=verbose,
                                     device=device, exact_gradient=exact_gradient)
@@ -33,30 +32,34 @@ def execute_from_command_line(biomolecule, msa_file, the_command=None, refseq_fi
             msa_file_base_name, _ext = os.path.splitext(os.path.basename(msa_file))
             output_dir = 'PLMDCA_output_' + msa_file_base_name
         dca_utilities.create_directories(output_dir)
+        seqbackmapper = None
+        if refseq_file:   # do backmapping when a reference sequence file is provided
+            seqbackmapper = SequenceBackmapper(msa_file=msa_file, refseq_file=refseq_file,
+                                               biomolecule=plmdca_instance.biomolecule)
         if the_command == 'compute_fn':
             if apc:
                 score_type = 'PLMDCA Frobenius norm, average product corrected (APC)'
-                sorted_FN = plmdca_instance.compute_sorted_FN_APC()
+                sorted_FN = plmdca_instance.compute_sorted_FN_APC(seqbackmapper=seqbackmapper)
                 fn_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='PLMDCA_apc_fn_scores_', postfix='.txt')
             else:
                 score_type = 'PLMDCA Frobenius norm, non-APC (not average product corrected)'
-                sorted_FN = plmdca_instance.compute_sorted_FN()
+                sorted_FN = plmdca_instance.compute_sorted_FN(seqbackmapper=seqbackmapper)
                 fn_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='PLMDCA_raw_fn_scores_', postfix='.txt')
             dca_utilities.write_sorted_dca_scores(fn_file_path, sorted_FN, metadata=param_metadata, score_type=score_type)
             return fn_file_path
         if the_command == 'compute_di':
             if apc:
                 score_type = 'PLMDCA  DI scores, average product corrected (APC)'
-                sorted_DI = plmdca_instance.compute_sorted_DI_APC()
+                sorted_DI = plmdca_instance.compute_sorted_DI_APC(seqbackmapper=seqbackmapper)
                 di_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='PLMDCA_apc_di_scores_', postfix='.txt')
             else:
                 score_type = 'PLMDCA DI scores, non-APC (not average product corrected)'
-                sorted_DI = plmdca_instance.compute_sorted_DI()
+                sorted_DI = plmdca_instance.compute_sorted_DI(seqbackmapper=seqbackmapper)
                 di_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='PLMDCA_raw_di_scores_', postfix='.txt')
             dca_utilities.write_sorted_dca_scores(di_file_path, sorted_DI, metadata=param_metadata, score_type=score_type)
             return di_file_path
         if the_command == 'compute_params':
-            fields, couplings = plmdca_instance.compute_params(ranked_by=ranked_by, linear_dist=linear_dist,
+            fields, couplings = plmdca_instance.compute_params(seqbackmapper=seqbackmapper, ranked_by=ranked_by, linear_dist=linear_dist,
                                                                num_site_pairs=num_site_pairs)
             fields_file_path = dca_utilities.get_dca_output_file_path(output_dir, msa_file, prefix='fields_', postfix='.txt')
             param_metadata.append('#\tTotal number of sites whose fields are extracted: {}'.format(len(fields)))

@@ -264,7 +264,12 @@ def main():
     shutil.copyfile(os.path.join(REF, "examples", "MSA_RF00167.fa"), rf)
     shutil.copyfile(os.path.join(REF, "examples", "ref_RF00167.fa"), os.path.join(DATA, "ref_RF00167.fa"))
     shutil.copyfile(os.path.join(REF, "tests", "tests_input", "PF02826.faa"), pf)
-    for p in (rf, pf, os.path.join(DATA, "ref_RF00167.fa")):
+    # inputs of the reference's sequence_backmapper / trimming tests (tests/input_files_path.py)
+    extra = ["MSA_RF00059_trimmed_gap_treshold_50.fa", "ref_seq_RF00059.faa", "ref_seq_RF00059_test1.faa",
+             "ref_seq_RF00059_test2.faa", "ref_seq_RF00059_test3.faa", "ref_seq_RF00059_test4.faa", "ref_seq_PF02826.faa"]
+    for name in extra:
+        shutil.copyfile(os.path.join(REF, "tests", "tests_input", name), os.path.join(DATA, name))
+    for p in [rf, pf, os.path.join(DATA, "ref_RF00167.fa")] + [os.path.join(DATA, n) for n in extra]:
         os.chmod(p, 0o644)
     recs = read_records(rf)
     refrec = [s for n, s in recs if "REFERENCE" in n][0]

@@ -247,3 +247,32 @@ def test_compute_params_and_frequency_outputs(tmp_path, oracle_mf):
                                    "di", "--num_site_pairs", "3", "--output_dir", str(tmp_path / "p")])
     assert [os.path.basename(o) for o in out] == ["fields_toy_rna.txt", "couplings_toy_rna.txt"]
     assert len([ln for ln in open(out[1]).read().splitlines() if not ln.startswith("#")]) == 3
+
+
+def test_refseq_backmapping_through_classes_and_cli(tmp_path):
+    """--refseq_file: scores are filtered to the MSA columns that map to the reference
+    sequence and renamed to its positions.  For RF00167 the mapping is columns 16..88 minus the
+    template's gaps -> the mapped FN_APC list must be the unmapped one restricted and renamed."""
+    from pydca_amd import mfdca_main
+    from pydca_amd.meanfield_dca.meanfield_dca import MeanFieldDCA
+    from pydca_amd.sequence_backmapper.sequence_backmapper import SequenceBackmapper
+    f, r = data_file("MSA_RF00167.fa"), data_file("ref_RF00167.fa")
+    inst = MeanFieldDCA(f, "rna", pseudocount=0.5, seqid=0.8)
+    bm = SequenceBackmapper(alignment_data=inst.alignment, refseq_file=r, biomolecule="rna")
+    mapping = bm.map_to_reference_sequence()
+    assert len(mapping) == 71
+    plain = inst.compute_sorted_FN_APC()
+    mapped = inst.compute_sorted_FN_APC(seqbackmapper=bm)
+    want = [((mapping[i], mapping[j]), s) for (i, j), s in plain if i in mapping and j in mapping]
+    assert list(mapped) == want and len(mapped) == 71 * 70 // 2
+    fields, couplings = inst.compute_params(seqbackmapper=bm, num_site_pairs=7)
+    assert [s for s, _ in fields] == sorted(mapping.values()) and len(couplings) == 7
+    inv = {v: k for k, v in mapping.items()}
+    first_pair = couplings[0][0]
+    raw = inst.compute_params(num_site_pairs=400)[1]
+    d = {p: c for p, c in raw}
+    np.testing.assert_allclose(couplings[0][1], d[(inv[first_pair[0]], inv[first_pair[1]])], rtol=1e-12)
+    out = mfdca_main.run_meanfield_dca(["compute_fn", "rna", f, "--apc", "--refseq_file", r, "--output_dir", str(tmp_path / "m")])
+    rows = [ln.split() for ln in open(out).read().splitlines() if not ln.startswith("#")]
+    assert len(rows) == 71 * 70 // 2
+    assert (int(rows[0][0]) - 1, int(rows[0][1]) - 1) == mapped[0][0]
