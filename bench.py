@@ -213,7 +213,7 @@ def main():
         mctx.set_profiling(True)
         mctx.compute_weights(0.8, _lib.DCA_F64)
         scores = mctx.mf_run(0.5, True)
-        order = np.argsort(-scores, kind="stable")
+        order = mctx.scores_order()          # ranked on the device (stable radix sort)
         t_mf = time.perf_counter() - t0
         npairs = L * (L - 1) // 2
         out["mfdca"] = {"pairs_per_s": npairs / t_mf, "seconds": t_mf, "pairs": npairs, "top_pair_index": int(order[0]),

@@ -157,6 +157,13 @@ int dca_plm_di_scores(dca_ctx* ctx, const double* reg_fi, int apc, double* score
  * (plmdca.py:320-342).  Feeds PlmDCA.compute_params (plmdca.py:345-434). */
 int dca_plm_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift, double* out);
 
+/* ------------------------------------------------------------------ ranking
+ * Pair indices of the most recent score vector computed on this context (dca_plm_scores,
+ * dca_plm_di_scores, dca_mf_scores, dca_mf_di_scores, dca_mf_run) in descending score order,
+ * equal scores in ascending pair order: the sorted(..., reverse=True) step of
+ * compute_sorted_FN / _APC / DI (meanfield_dca.py:941, plmdca.py:479), done on the device copy. */
+int dca_scores_order(dca_ctx* ctx, int32_t* order_out, int capacity);
+
 /* ------------------------------------------------------------------ mfDCA
  * Stage functions mirror pydca/meanfield_dca/msa_numerics.py; all float64. */
 int dca_mf_single_site_freqs(dca_ctx* ctx, double* fi_out /* L*q, gap last (:53-89) */);

@@ -92,6 +92,7 @@ def lib():
         "dca_mf_run": (i, [vp, d, i, vp, vp]),
         "dca_mf_corr_from_freqs": (i, [vp, vp, vp, i, i, vp]),
         "dca_spd_inverse": (i, [vp, vp, i, vp]),
+        "dca_scores_order": (i, [vp, vp, i]),
         "dca_sw_scores": (i, [C.c_char_p, i, C.c_char_p, vp, i, vp, i, i, vp]),
         "dca_sw_align": (i, [C.c_char_p, i, C.c_char_p, i, vp, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p,
                              C.c_char_p, C.POINTER(i)]),
@@ -118,7 +119,7 @@ EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_read_msa", 
            "dca_mf_di_scores", "dca_plm_pair_couplings", "dca_mf_fields", "dca_mf_pair_couplings",
            "dca_mf_single_site_freqs",
            "dca_mf_pair_site_freqs", "dca_mf_corr_mat", "dca_mf_couplings", "dca_mf_scores", "dca_mf_run",
-           "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_sw_scores", "dca_sw_align", "dca_set_profiling", "dca_get_kernel_time",
+           "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_sw_scores", "dca_sw_align", "dca_scores_order", "dca_set_profiling", "dca_get_kernel_time",
            "dca_reset_kernel_times", "plmdcaBackend", "freeFieldsAndCouplings"]
 
 
@@ -261,6 +262,12 @@ class Context:
             raise ValueError("reg_fi must be L x q")
         out = np.zeros(self.L * (self.L - 1) // 2, dtype=np.float64)
         check(self._l.dca_plm_di_scores(self._h, _ptr(reg_fi), int(bool(apc)), _ptr(out)))
+        return out
+
+    def scores_order(self):
+        """Pair indices of the last score vector, best first (device radix sort, stable)."""
+        out = np.zeros(self.L * (self.L - 1) // 2, dtype=np.int32)
+        check(self._l.dca_scores_order(self._h, _ptr(out), int(out.size)))
         return out
 
     def _pair_couplings(self, fn, pairs, shift):

@@ -105,8 +105,39 @@ static void free_msa(dca_ctx* ctx)
     hipFree(ctx->dX); ctx->dX = nullptr;
     hipFree(ctx->dCounts); ctx->dCounts = nullptr;
     hipFree(ctx->dWd); ctx->dWd = nullptr;
+    hipFree(ctx->dLastScores); ctx->dLastScores = nullptr; ctx->nLastScores = 0;
+    ctx->hX.clear();
     ctx->have_weights = ctx->have_counts = false;
 }
+
+}  // extern "C" (internal C++ helpers follow)
+
+const uint8_t* dca_host_msa(dca_ctx* ctx)
+{
+    if (ctx->hX.empty() && ctx->dX) {
+        ctx->hX.resize((size_t)ctx->N * ctx->L);
+        if (hipMemcpy2D(ctx->hX.data(), (size_t)ctx->L, ctx->dX, (size_t)ctx->Ls, (size_t)ctx->L, (size_t)ctx->N,
+                        hipMemcpyDeviceToHost) != hipSuccess) {
+            ctx->hX.clear();
+            dca_set_error("copying the alignment back to the host failed");
+            return nullptr;
+        }
+    }
+    return ctx->hX.empty() ? nullptr : ctx->hX.data();
+}
+
+int dca_remember_scores(dca_ctx* ctx, const double* dScores, int n)
+{
+    if (ctx->nLastScores != n) {
+        hipFree(ctx->dLastScores); ctx->dLastScores = nullptr; ctx->nLastScores = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dLastScores), (size_t)n * sizeof(double)));
+        ctx->nLastScores = n;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->dLastScores, dScores, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return DCA_OK;
+}
+
+extern "C" {
 
 void dca_destroy(dca_ctx* ctx)
 {
@@ -125,16 +156,24 @@ int dca_set_msa(dca_ctx* ctx, const uint8_t* X, int N, int L, int q)
 {
     CHECK_CTX(ctx);
     if (!X || N <= 0 || L <= 1 || q < 2 || q > 32) { dca_set_error("dca_set_msa: bad arguments"); return DCA_ERR_ARG; }
-    for (size_t k = 0; k < (size_t)N * L; ++k)
-        if (X[k] >= q) { dca_set_error("dca_set_msa: code %d >= q at element %zu", (int)X[k], k); return DCA_ERR_ARG; }
+    {
+        uint8_t mx = 0;                                   // vectorisable pass; the slow search only runs on failure
+        const size_t total = (size_t)N * L;
+        for (size_t k = 0; k < total; ++k) mx = X[k] > mx ? X[k] : mx;
+        if (mx >= q) {
+            size_t k = 0;
+            while (X[k] < q) ++k;
+            dca_set_error("dca_set_msa: code %d >= q at element %zu", (int)X[k], k);
+            return DCA_ERR_ARG;
+        }
+    }
     free_msa(ctx);
     ctx->N = N; ctx->L = L; ctx->q = q;
     ctx->Ls = (int)round_up((size_t)L, 128);
-    ctx->hX.assign(X, X + (size_t)N * L);
-    std::vector<uint8_t> padded((size_t)N * ctx->Ls, 0);
-    for (int n = 0; n < N; ++n) memcpy(padded.data() + (size_t)n * ctx->Ls, X + (size_t)n * L, (size_t)L);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dX), padded.size()));
-    HIP_TRY(hipMemcpy(ctx->dX, padded.data(), padded.size(), hipMemcpyHostToDevice));
+    ctx->hX.clear();                                       // host copy is made on demand (dca_host_msa)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dX), (size_t)N * ctx->Ls));
+    HIP_TRY(hipMemset(ctx->dX, 0, (size_t)N * ctx->Ls));
+    HIP_TRY(hipMemcpy2D(ctx->dX, (size_t)ctx->Ls, X, (size_t)L, (size_t)L, (size_t)N, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dCounts), (size_t)N * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dWd), (size_t)N * sizeof(double)));
     return DCA_OK;
@@ -250,6 +289,13 @@ int dca_mf_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift,
     DCA_TRY(need_mf(ctx));
     if (npairs < 0 || (npairs > 0 && (!pairs || !out))) return DCA_ERR_ARG;
     return dca_mf_engine_pair_couplings(ctx->mf, pairs, npairs, shift, out);
+}
+int dca_scores_order(dca_ctx* ctx, int32_t* order_out, int capacity)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->dLastScores) { dca_set_error("no score vector has been computed on this context"); return DCA_ERR_STATE; }
+    if (!order_out || capacity < ctx->nLastScores) return DCA_ERR_ARG;
+    return dca_scores_order_device(ctx, ctx->dLastScores, ctx->nLastScores, order_out);
 }
 int dca_mf_di_scores(dca_ctx* ctx, int apc, double* out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); return dca_mf_engine_di(ctx->mf, apc, out); }
 int dca_mf_run(dca_ctx* ctx, double pseudocount, int apc, double* scores_out, double* couplings_out)

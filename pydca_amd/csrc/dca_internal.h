@@ -54,7 +54,9 @@ struct dca_ctx {
     // alignment (device): row-major bytes, row stride Ls (multiple of 128), zero padded
     int N = 0, L = 0, q = 0, Ls = 0;
     uint8_t* dX = nullptr;
-    std::vector<uint8_t> hX;  // host copy, N x L
+    std::vector<uint8_t> hX;  // host copy, N x L, filled on demand by dca_host_msa()
+    double* dLastScores = nullptr;   // most recent score vector (pair order), for dca_scores_order
+    int nLastScores = 0;
 
     // weights
     bool have_weights = false;
@@ -93,6 +95,13 @@ struct ScopedKernelClock {
     }
 };
 void dca_flush_clocks(dca_ctx* ctx);
+
+// host copy of the alignment (N x L), fetched from the device the first time it is needed
+const uint8_t* dca_host_msa(dca_ctx* ctx);
+// keeps a device copy of a score vector for dca_scores_order
+int dca_remember_scores(dca_ctx* ctx, const double* dScores, int n);
+// rank.hip: indices of a device score vector in descending order, ties by ascending index (stable)
+int dca_scores_order_device(dca_ctx* ctx, const double* dScores, int n, int32_t* order_out /* host */);
 
 // ---- weights.hip
 int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision);

@@ -991,7 +991,8 @@ struct PlmEngine : PlmEngineBase {
         T meff = 0;
         for (int n = 0; n < N; ++n) meff += hw[n];
         std::vector<T> h((size_t)L * q, (T)0);
-        const uint8_t* X = ctx->hX.data();
+        const uint8_t* X = dca_host_msa(ctx);
+        if (!X) return DCA_ERR_HIP;
         for (int n = 0; n < N; ++n)
             for (int i = 0; i < L; ++i) h[(size_t)i * q + X[(size_t)n * L + i]] += hw[n];
         for (int i = 0; i < L; ++i) {

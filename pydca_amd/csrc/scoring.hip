@@ -261,7 +261,7 @@ int dca_fn_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L,
         if (e != hipSuccess) { dca_set_error("apc: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     }
     HIP_TRY(hipGetLastError());
-    return DCA_OK;
+    return dca_remember_scores(ctx, dOut, (int)npairs);
 }
 
 // DI / DI_APC of coupling blocks; same source conventions as dca_fn_scores.  dRegFi: device, L*q.
@@ -286,7 +286,7 @@ int dca_di_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, const 
         if (e != hipSuccess) { dca_set_error("apc: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     }
     HIP_TRY(hipGetLastError());
-    return DCA_OK;
+    return dca_remember_scores(ctx, dOut, (int)npairs);
 }
 
 // pairs: host array of 2*npairs ints (i < j); out: host, npairs*(q-1)^2 doubles

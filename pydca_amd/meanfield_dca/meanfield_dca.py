@@ -16,11 +16,13 @@ class MeanFieldDCAException(Exception):
     """Errors related to mean-field DCA computation."""
 
 
-def _ranked(scores, L):
-    """[((i, j), score), ...] sorted by score, descending; ties keep (i, j) order, as
-    Python's stable sorted(..., reverse=True) does in the reference (meanfield_dca.py:940)."""
+def _ranked(scores, L, ctx=None):
+    """[((i, j), score), ...] sorted by score, descending; ties keep (i, j) order, as Python's
+    stable sorted(..., reverse=True) does in the reference (meanfield_dca.py:940, plmdca.py:479).
+    With ctx the order comes from the device (stable radix sort of the score vector the context
+    just produced, dca_scores_order); without it from numpy."""
     iu, ju = np.triu_indices(L, k=1)
-    order = np.argsort(-scores, kind='stable')
+    order = ctx.scores_order() if ctx is not None else np.argsort(-scores, kind='stable')
     return [((int(iu[k]), int(ju[k])), scores[k]) for k in order]
 
 
@@ -194,12 +196,12 @@ class MeanFieldDCA:
     def compute_sorted_FN(self, seqbackmapper=None):
         """meanfield_dca.py:902-943."""
         logger.info('\n\tComputing Frobenius norm of couplings')
-        return self._maybe_mapped(_ranked(self._device_scores(False), self.__sequences_len), seqbackmapper)
+        return self._maybe_mapped(_ranked(self._device_scores(False), self.__sequences_len, self.__ctx), seqbackmapper)
 
     def compute_sorted_FN_APC(self, seqbackmapper=None):
         """meanfield_dca.py:946-988."""
         logger.info('\n\tPerforming average product correction (APC) to Frobenius norm of couplings.')
-        return self._maybe_mapped(_ranked(self._device_scores(True), self.__sequences_len), seqbackmapper)
+        return self._maybe_mapped(_ranked(self._device_scores(True), self.__sequences_len, self.__ctx), seqbackmapper)
 
     def get_couplings(self):
         """-inv(C) of the current pseudocount as float64[L(q-1), L(q-1)] (device resident
@@ -288,10 +290,10 @@ class MeanFieldDCA:
         one workgroup per site pair on the device)."""
         self._device_scores(False)
         logger.info('\n\tComputing direct information')
-        return self._maybe_mapped(_ranked(self.__ctx.mf_di_scores(False), self.__sequences_len), seqbackmapper)
+        return self._maybe_mapped(_ranked(self.__ctx.mf_di_scores(False), self.__sequences_len, self.__ctx), seqbackmapper)
 
     def compute_sorted_DI_APC(self, seqbackmapper=None):
         """meanfield_dca.py:848-899."""
         self._device_scores(False)
         logger.info('\n\tPerforming average product correction (APC) of DI scores')
-        return self._maybe_mapped(_ranked(self.__ctx.mf_di_scores(True), self.__sequences_len), seqbackmapper)
+        return self._maybe_mapped(_ranked(self.__ctx.mf_di_scores(True), self.__sequences_len, self.__ctx), seqbackmapper)

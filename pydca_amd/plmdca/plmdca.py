@@ -16,9 +16,13 @@ class PlmDCAException(Exception):
     """Exceptions related to PlmDCA computation."""
 
 
-def _ranked(scores, L):
+def _ranked(scores, L, ctx=None):
+    """[((i, j), score), ...] sorted by score, descending; ties keep (i, j) order, as Python's
+    stable sorted(..., reverse=True) does in the reference (meanfield_dca.py:940, plmdca.py:479).
+    With ctx the order comes from the device (stable radix sort of the score vector the context
+    just produced, dca_scores_order); without it from numpy."""
     iu, ju = np.triu_indices(L, k=1)
-    order = np.argsort(-scores, kind='stable')
+    order = ctx.scores_order() if ctx is not None else np.argsort(-scores, kind='stable')
     return [((int(iu[k]), int(ju[k])), scores[k]) for k in order]
 
 
@@ -191,13 +195,13 @@ class PlmDCA:
         ctx = self._run_backend()
         self.__fields_and_couplings_all = None
         logger.info('\n\tComputing non-APC sorted DCA score')
-        return self._maybe_mapped(_ranked(ctx.plm_scores(False), self.__seqs_len), seqbackmapper)
+        return self._maybe_mapped(_ranked(ctx.plm_scores(False), self.__seqs_len, ctx), seqbackmapper)
 
     def compute_sorted_FN_APC(self, seqbackmapper=None):
         """plmdca.py:484-524."""
         ctx = self._run_backend()
         logger.info('\n\tPerforming average product correction (APC) of FN  of DCA scores')
-        return self._maybe_mapped(_ranked(ctx.plm_scores(True), self.__seqs_len), seqbackmapper)
+        return self._maybe_mapped(_ranked(ctx.plm_scores(True), self.__seqs_len, ctx), seqbackmapper)
 
     def compute_params(self, seqbackmapper=None, ranked_by=None, linear_dist=None, num_site_pairs=None):
         """plmdca.py:345-434: fields of every site (gap state dropped) and the gauge-shifted couplings
@@ -218,7 +222,7 @@ class PlmDCA:
             scores = ctx.plm_scores(ranked_by == 'FN_APC')
         else:
             scores = ctx.plm_di_scores(self.get_reg_single_site_freqs(), ranked_by == 'DI_APC')
-        dca_scores = self._maybe_mapped(_ranked(scores, L), seqbackmapper)
+        dca_scores = self._maybe_mapped(_ranked(scores, L, ctx), seqbackmapper)
         self.__fields_and_couplings_all = ctx.plm_get_x(np.float32)
         f = self.__fields_and_couplings_all[:L * q].reshape(L, q)[:, :q - 1]
         if seqbackmapper is not None:
@@ -282,9 +286,9 @@ class PlmDCA:
 
     def compute_sorted_DI(self, seqbackmapper=None):
         """plmdca.py:723-750."""
-        return self._maybe_mapped(_ranked(self.compute_direct_info_unsorted_DI(False), self.__seqs_len), seqbackmapper)
+        return self._maybe_mapped(_ranked(self.compute_direct_info_unsorted_DI(False), self.__seqs_len, self.__ctx), seqbackmapper)
 
     def compute_sorted_DI_APC(self, seqbackmapper=None):
         """plmdca.py:753-790."""
         logger.info('\n\tPerforming average product correction (APC) of DI scores')
-        return self._maybe_mapped(_ranked(self.compute_direct_info_unsorted_DI(True), self.__seqs_len), seqbackmapper)
+        return self._maybe_mapped(_ranked(self.compute_direct_info_unsorted_DI(True), self.__seqs_len, self.__ctx), seqbackmapper)

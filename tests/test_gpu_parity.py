@@ -423,3 +423,24 @@ def test_plm_pair_couplings_vs_oracle(L_, oracle_mf):
         np.testing.assert_allclose(got[k], oracle_mf.shift_couplings(J[idx[pr]]), rtol=1e-12, atol=1e-15)
     np.testing.assert_array_equal(ctx.plm_pair_couplings(pairs, shift=False)[1], J[idx[(2, 7)]])
     ctx.close()
+
+
+def test_scores_order_matches_stable_argsort(L_, oracle_mf):
+    """dca_scores_order (device radix sort) == numpy's stable descending argsort, ties included."""
+    rng = np.random.default_rng(9)
+    L, q = 40, 5
+    X = rng.integers(0, q, size=(60, L), dtype=np.uint8)
+    ctx = make_ctx(L_, X, q, L_.DCA_F64, 0.8, L_.DCA_F64)
+    ctx.plm_configure(1.0, 1.0)
+    x = rng.standard_normal(ctx.num_params())
+    x[L * q + 50 * q * q:] = 0.0            # hundreds of exactly tied (zero) scores
+    ctx.plm_set_x(x)
+    for apc in (False, True):
+        s = ctx.plm_scores(apc)
+        assert np.array_equal(ctx.scores_order(), np.argsort(-s, kind="stable"))
+    ctx.close()
+    c2 = L_.Context(0, L_.DCA_F64)
+    c2.set_msa(X, q)
+    with pytest.raises(L_.DcaBackendError):
+        c2.scores_order()
+    c2.close()
