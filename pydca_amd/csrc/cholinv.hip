@@ -134,84 +134,131 @@ void gemm_nt_f64_kernel(GemmArgs g)
 }
 
 // 64x64 leaf: A (lower triangle valid) -> X = inv(chol(A)), written lower + mirrored upper.
-// One workgroup, two 64x65 LDS arrays.
-//  * Cholesky, right-looking, one barrier per column: the trailing update of column k uses the
-//    unscaled column and 1/a_kk, the scaling of column k overlaps the next column's update.
-//  * X = L^-1 by recursive doubling: X starts as diag(1/l_ii); for block sizes b = 1,2,..,32 every
-//    pair of adjacent diagonal blocks (T above B) gets X_BT = -X_BB * (L_BT * X_TT); the
-//    intermediate L_BT * X_TT is parked in the unused upper triangle of X.  12 barriers instead
-//    of a 2000-step serial substitution per thread.
+// One workgroup of 16 x 16 threads; thread (ty, tx) keeps the 4 x 4 block rows 4ty.., columns 4tx..
+// in registers, so a step of either phase is: read one column / row vector from LDS, 16 FMAs on
+// registers, publish the next vector, ONE barrier (the vectors are double buffered).
+//  * Cholesky, right-looking: step k uses the unscaled column a_ik and 1/a_kk
+//    (a_ij -= a_ik a_jk / a_kk); the owners of column k store l_ik = a_ik / sqrt(a_kk) to LDS.
+//  * X = L^-1 by right-looking forward substitution on B = I: row k of X is final before step k
+//    (x_kj = b_kj / l_kk), then b_ij -= l_ik x_kj for the rows below.  X replaces B in registers.
+// The scaling by 1/sqrt(a_kk) is applied to all columns at once after the factorisation loop.
 __global__ __launch_bounds__(256)
 void cholinv_leaf_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info)
 {
     constexpr int n = 64, S = 65;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
-    double* Ls = reinterpret_cast<double*>(dca_smem);
-    double* Xs = Ls + n * S;
+    __shared__ double Lf[n * S];          // L, row-major; upper triangle and diagonal end up zero
+    __shared__ double vec[2][n];          // column k of A below the diagonal / row k of X, double buffered
+    __shared__ double piv[2];             // a_kk of the published column
+    __shared__ double invd[n];            // a_kk, later 1 / l_kk
     const int tid = threadIdx.x;
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e / n, j = e % n;
-        Ls[i * S + j] = (j <= i) ? M[(size_t)i * ld + j] : 0.0;
-        Xs[i * S + j] = 0.0;
+    const int ty = tid >> 4, tx = tid & 15;
+    const int r0 = 4 * ty, c0 = 4 * tx;
+
+    // Every step is branch-free on the element level: the published vectors carry zeros where an
+    // update must not happen, so each thread does 4 multiplies + 16 FMAs on its register block.
+    double a[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[r][c] = (c0 + c <= r0 + r) ? M[(size_t)(r0 + r) * ld + c0 + c] : 0.0;
+    if (tx == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vec[0][r0 + r] = (r0 + r > 0) ? a[r][0] : 0.0;
+        if (ty == 0) piv[0] = a[0][0];
     }
     __syncthreads();
-    for (int k = 0; k < n; ++k) {
-        const double akk = Ls[k * S + k];          // final value of the pivot: updated by steps < k
-        if (tid == 0 && !(akk > 0.0)) atomicCAS(info, 0, pivotBase + k + 1);
-        const double inv = 1.0 / akk;
-        const int m = n - k - 1;
-        for (int e = tid; e < m * m; e += 256) {
-            const int i = k + 1 + e / m, j = k + 1 + e % m;
-            if (j <= i) Ls[i * S + j] -= Ls[i * S + k] * Ls[j * S + k] * inv;
+    for (int kb = 0; kb < 16; ++kb) {
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int k = 4 * kb + kc, cur = k & 1;
+            const double akk = piv[cur];
+            if (tid == 0 && !(akk > 0.0)) atomicCAS(info, 0, pivotBase + k + 1);
+            // 1/a_kk: hardware reciprocal + two Newton steps (a full-precision divide and the sqrt of the
+            // scaling would sit on the critical path of every step; the scaling is applied after the loop)
+            double inv = __builtin_amdgcn_rcp(akk);
+            inv = inv * (2.0 - akk * inv);
+            inv = inv * (2.0 - akk * inv);
+            if (tx == kb) {               // column k is final: keep it unscaled for now
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Lf[(r0 + r) * S + k] = a[r][kc];
+                if (ty == kb) invd[k] = akk;
+            }
+            double ai[4], aj[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ai[r] = vec[cur][r0 + r] * inv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) aj[c] = vec[cur][c0 + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[r][c] -= ai[r] * aj[c];
+            if (k + 1 < n && tx == (k + 1) / 4) {
+                const int cc = (k + 1) & 3;   // static after unrolling
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vec[cur ^ 1][r0 + r] = (r0 + r > k + 1) ? a[r][cc] : 0.0;
+                if (ty == (k + 1) / 4) piv[cur ^ 1] = a[cc][cc];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        // scale column k (not read by later steps' updates, so no barrier is needed after it)
-        const double d = sqrt(akk);
-        if (tid > k && tid < n) Ls[tid * S + k] /= d;
-        if (tid == k) Ls[k * S + k] = d;
+    }
+    // l_ik = a_ik / sqrt(a_kk) below the diagonal, zero elsewhere; 1 / l_kk
+    if (tid < n) invd[tid] = 1.0 / sqrt(invd[tid]);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double v = Lf[(r0 + r) * S + c0 + c] * invd[c0 + c];
+            Lf[(r0 + r) * S + c0 + c] = (c0 + c < r0 + r) ? v : 0.0;
+        }
+    __syncthreads();
+    // ---- X = L^-1
+    double b[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[r][c] = (r0 + r == c0 + c) ? 1.0 : 0.0;
+    if (ty == 0) {
+        const double id = invd[0];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { b[0][c] *= id; vec[0][c0 + c] = b[0][c]; }
     }
     __syncthreads();
-    if (tid < n) Xs[tid * S + tid] = 1.0 / Ls[tid * S + tid];
-    __syncthreads();
-    for (int bsz = 1; bsz < n; bsz <<= 1) {
-        const int pairs = n / (2 * bsz), per = bsz * bsz;
-        // W = L_BT * X_TT, parked at Xs[c][r] (upper triangle)
-        for (int e = tid; e < pairs * per; e += 256) {
-            const int pr = e / per, rr = (e % per) / bsz, cc = e % bsz;
-            const int t0 = pr * 2 * bsz, b0 = t0 + bsz;
-            const int r = b0 + rr, c = t0 + cc;
-            double acc = 0.0;
-            for (int kk = c; kk < b0; ++kk) acc += Ls[r * S + kk] * Xs[kk * S + c];
-            Xs[c * S + r] = acc;
+    for (int kb = 0; kb < 16; ++kb) {
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int k = 4 * kb + kc, cur = k & 1;
+            double li[4], xk[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) li[r] = Lf[(r0 + r) * S + k];       // zero for rows <= k
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xk[c] = vec[cur][c0 + c];           // zero for columns > k
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) b[r][c] -= li[r] * xk[c];
+            if (k + 1 < n && ty == (k + 1) / 4) {   // row k+1 of B is final: scale it, publish it
+                const int rr = (k + 1) & 3;
+                const double id = invd[k + 1];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { b[rr][c] *= id; vec[cur ^ 1][c0 + c] = b[rr][c]; }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        // X_BT = -X_BB * W
-        double vals[16];
-        int cnt = 0;
-        for (int e = tid; e < pairs * per; e += 256) {
-            const int pr = e / per, rr = (e % per) / bsz, cc = e % bsz;
-            const int t0 = pr * 2 * bsz, b0 = t0 + bsz;
-            const int r = b0 + rr, c = t0 + cc;
-            double acc = 0.0;
-            for (int kk = b0; kk <= r; ++kk) acc += Xs[r * S + kk] * Xs[c * S + kk];
-            vals[cnt++] = -acc;
-        }
-        __syncthreads();
-        cnt = 0;
-        for (int e = tid; e < pairs * per; e += 256) {
-            const int pr = e / per, rr = (e % per) / bsz, cc = e % bsz;
-            const int t0 = pr * 2 * bsz, b0 = t0 + bsz;
-            Xs[(b0 + rr) * S + t0 + cc] = vals[cnt++];
-        }
-        __syncthreads();
     }
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e / n, j = e % n;
-        M[(size_t)i * ld + j] = (j <= i) ? Xs[i * S + j] : Xs[j * S + i];
+    if (tx <= ty) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c0 + c <= r0 + r) {
+                    M[(size_t)(r0 + r) * ld + c0 + c] = b[r][c];
+                    M[(size_t)(c0 + c) * ld + r0 + r] = b[r][c];
+                }
     }
 }
 
-constexpr size_t kLeafLds = 2 * 64 * 65 * sizeof(double);
+constexpr size_t kLeafLds = 0;
 
 struct Arena {
     double* base; size_t cap, top = 0;
@@ -263,7 +310,6 @@ int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* 
     int* dInfo = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dInfo), sizeof(int)));
     HIP_TRY(hipMemsetAsync(dInfo, 0, sizeof(int), ctx->stream));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cholinv_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLeafLds));
     Arena ws{dWork, (size_t)n * n};
     int rc = cholinv_rec(ctx, dA, n, n, 0, ws, dInfo);
     if (rc == DCA_OK) {
