@@ -51,12 +51,13 @@ void mf_site_sort_kernel(const uint8_t* __restrict__ XT, const double* __restric
 {
     __shared__ int cnts[32][kSortThreads + 1];
     __shared__ int base[33];
+    __shared__ double wsum[32][kSortThreads];      // per-thread weighted counts of its segment
     const int i = blockIdx.x, t = threadIdx.x;
     const int seg = (N + kSortThreads - 1) / kSortThreads;
     const int nb = min(N, t * seg), ne = min(N, (t + 1) * seg);
     const uint8_t* col = XT + (size_t)i * Nt;
     int local[32];
-    for (int b = 0; b < q; ++b) local[b] = 0;
+    for (int b = 0; b < q; ++b) { local[b] = 0; wsum[b][t] = 0.0; }
     for (int n = nb; n < ne; ++n) local[col[n]]++;
     for (int b = 0; b < q; ++b) cnts[b][t] = local[b];
     __syncthreads();
@@ -79,11 +80,15 @@ void mf_site_sort_kernel(const uint8_t* __restrict__ XT, const double* __restric
     __syncthreads();
     uint32_t* p = perm + (size_t)i * N;
     for (int b = 0; b < q; ++b) local[b] = base[b] + cnts[b][t];
-    for (int n = nb; n < ne; ++n) p[local[col[n]]++] = (uint32_t)n;
+    for (int n = nb; n < ne; ++n) {
+        const int b = col[n];
+        p[local[b]++] = (uint32_t)n;
+        wsum[b][t] += w[n];                         // ascending n inside the segment
+    }
     __syncthreads();
-    if (t < q) {              // weighted count of state t, ascending n
+    if (t < q) {              // weighted count of state t: segments in ascending order (deterministic)
         double s = 0.0;
-        for (int k = base[t]; k < base[t + 1]; ++k) s += w[p[k]];
+        for (int k = 0; k < kSortThreads; ++k) s += wsum[t][k];
         cnt1[i * q + t] = s;
     }
 }
@@ -106,14 +111,27 @@ void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ 
     const int k0 = off[i * (q + 1) + a], k1 = off[i * (q + 1) + a + 1];
     const uint32_t* p = perm + (size_t)i * N;
     const int t = threadIdx.x;
+    constexpr int U = 8;      // sequences fetched ahead: the loop is bound by dependent load latency
     for (int j0 = i + 1; j0 < L; j0 += kCountThreads) {
         const int j = j0 + t;
         for (int b = 0; b < q; ++b) hist[b * kCountThreads + t] = 0.0;
         if (j < L) {
-            for (int k = k0; k < k1; ++k) {
+            const uint8_t* Xj = X + j;
+            int k = k0;
+            for (; k + U <= k1; k += U) {
+                uint32_t n[U];
+                double wv[U];
+                int bb[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) n[u] = p[k + u];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { wv[u] = w[n[u]]; bb[u] = Xj[(size_t)n[u] * Ls]; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) hist[bb[u] * kCountThreads + t] += wv[u];     // list order: ascending n
+            }
+            for (; k < k1; ++k) {
                 const uint32_t n = p[k];
-                const int b = X[(size_t)n * Ls + j];
-                hist[b * kCountThreads + t] += w[n];
+                hist[Xj[(size_t)n * Ls] * kCountThreads + t] += w[n];
             }
             double* dst = Craw + (size_t)(i * q + a) * ldc + (size_t)j * q;
             for (int b = 0; b < q; ++b) dst[b] = hist[b * kCountThreads + t];

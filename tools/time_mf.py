@@ -26,7 +26,7 @@ for rep in range(a.reps):
     ctx.set_profiling(True)
     ctx.compute_weights(0.8, _lib.DCA_F64)
     scores = ctx.mf_run(0.5, True)
-    order = np.argsort(-scores, kind="stable")
+    order = ctx.scores_order()
     dt = time.perf_counter() - t0
     print("rep", rep, "total %.1f ms" % (dt * 1e3), {k: round(ctx.kernel_time(k)[0], 2) for k in ("weights", "mf_counts", "mf_inverse", "scores")},
           "pairs/s %.0f" % (a.L * (a.L - 1) / 2 / dt))
