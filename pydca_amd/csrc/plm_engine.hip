@@ -187,68 +187,105 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
 // weight <= 1 and d softmax has 1-norm <= 1/2, so the start-up error shrinks by >= 2x
 // per step (2^-40 after the default 40) -- far below float/double rounding.
 // In: SR = S (logit sums).  Out: SR = R = w_n (p - delta), fxPart[wave] = -sum w_n log p(x_ni).
+//
+// Memory access: the 64 sites of a wave are one contiguous 64*q*sizeof(T)-byte span of a row.
+// It is fetched with 16-byte loads (prefetched DEPTH rows ahead into registers), transposed
+// through a wave-private LDS buffer (lane l then reads its q values at stride q: conflict free
+// for odd q) and written back the same way, instead of q strided 4-byte accesses per lane.
+typedef uint4 __attribute__((may_alias)) dca_u4a;
+
 template <typename T, int Q>
 __global__ __launch_bounds__(256)
 void plm_softmax_kernel(T* __restrict__ SR, const T* __restrict__ x, const uint8_t* __restrict__ X,
                         const T* __restrict__ w, double* __restrict__ fxPart,
                         int N, int L, int Ls, int Cs, int halo, int chunk, int warm, int carry, int numChunks)
 {
+    constexpr int ROWB = 64 * Q * (int)sizeof(T);        // bytes of a wave's span of one row
+    constexpr int NP = (ROWB + 1023) / 1024;             // 16-byte pieces per lane
+    constexpr int DEPTH = NP > 6 ? 2 : 3;                // rows in flight
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int chunkId = blockIdx.y * 4 + wv;
-    const int i = blockIdx.x * 64 + lane;
+    const int i0 = blockIdx.x * 64;
+    const int i = i0 + lane;
+    unsigned char* sIn = dca_smem + (size_t)wv * (2 * NP * 1024);
+    unsigned char* sOut = sIn + NP * 1024;
+    const int rowBytes = (min(64, L - i0) * Q * (int)sizeof(T) + 15) & ~15;
     double facc = 0.0;
-    if (chunkId < numChunks && i < L) {
+    if (chunkId < numChunks) {
         const int s = halo + chunkId * chunk;
         const int e = min(s + chunk, N);
         const int ws = carry ? max(0, s - warm) : s;
-        T h[Q], p[Q], zc[Q], zn[Q];
+        T h[Q], p[Q];
 #pragma unroll
-        for (int a = 0; a < Q; ++a) { h[a] = x[(size_t)i * Q + a]; p[a] = 0; }
-        {
-            const T* row = SR + (size_t)ws * Cs + (size_t)i * Q;
+        for (int a = 0; a < Q; ++a) { h[a] = (i < L) ? x[(size_t)i * Q + a] : (T)0; p[a] = 0; }
+        uint4 buf[DEPTH][NP];
+        int xs[DEPTH];
+        T wns[DEPTH];
+        auto fetch = [&](int n, int d) {
+            const unsigned char* row = reinterpret_cast<const unsigned char*>(SR + (size_t)n * Cs + (size_t)i0 * Q);
 #pragma unroll
-            for (int a = 0; a < Q; ++a) zc[a] = row[a];
-        }
-        for (int n = ws; n < e; ++n) {
-            if (n + 1 < e) {   // prefetch next row while this one is reduced
-                const T* row = SR + (size_t)(n + 1) * Cs + (size_t)i * Q;
-#pragma unroll
-                for (int a = 0; a < Q; ++a) zn[a] = row[a];
+            for (int pc = 0; pc < NP; ++pc) {
+                const int off = pc * 1024 + lane * 16;
+                buf[d][pc] = (off < rowBytes) ? *reinterpret_cast<const dca_u4a*>(row + off) : make_uint4(0, 0, 0, 0);
             }
-            T z[Q];
+            xs[d] = (i < L) ? (int)X[(size_t)n * Ls + i] : 0;
+            wns[d] = w[n];
+        };
 #pragma unroll
-            for (int a = 0; a < Q; ++a) z[a] = zc[a] + h[a];
-            if (carry) {
+        for (int d = 0; d < DEPTH; ++d)
+            if (ws + d < e) fetch(ws + d, d);
+        for (int n0 = ws; n0 < e; n0 += DEPTH) {
 #pragma unroll
-                for (int a = 0; a < Q; ++a) z[a] += p[a];
-            }
-            T m = z[0];
+            for (int d = 0; d < DEPTH; ++d) {
+                const int n = n0 + d;
+                if (n < e) {
 #pragma unroll
-            for (int a = 1; a < Q; ++a) m = z[a] > m ? z[a] : m;
-            T sum = 0;
+                    for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<dca_u4a*>(sIn + pc * 1024 + lane * 16) = buf[d][pc];
+                    __builtin_amdgcn_wave_barrier();
+                    T z[Q];
 #pragma unroll
-            for (int a = 0; a < Q; ++a) { p[a] = t_exp(z[a] - m); sum += p[a]; }
-            const T inv = (T)1 / sum;
+                    for (int a = 0; a < Q; ++a) z[a] = reinterpret_cast<const T*>(sIn)[lane * Q + a] + h[a];
+                    const int xi = xs[d];
+                    const T wn = wns[d];
+                    __builtin_amdgcn_wave_barrier();
+                    if (n + DEPTH < e) fetch(n + DEPTH, d);
+                    if (carry) {
 #pragma unroll
-            for (int a = 0; a < Q; ++a) p[a] *= inv;
-            if (n >= s) {
-                const int xi = X[(size_t)n * Ls + i];
-                const T wn = w[n];
-                T px = p[0];
+                        for (int a = 0; a < Q; ++a) z[a] += p[a];
+                    }
+                    T m = z[0];
 #pragma unroll
-                for (int a = 1; a < Q; ++a) px = (a == xi) ? p[a] : px;
-                facc -= (double)(wn * t_log(px));
-                T* row = SR + (size_t)n * Cs + (size_t)i * Q;
+                    for (int a = 1; a < Q; ++a) m = z[a] > m ? z[a] : m;
+                    T sum = 0;
 #pragma unroll
-                for (int a = 0; a < Q; ++a) {
-                    T r = wn * p[a];
-                    if (a == xi) r -= wn;
-                    row[a] = r;
+                    for (int a = 0; a < Q; ++a) { p[a] = t_exp(z[a] - m); sum += p[a]; }
+                    const T inv = (T)1 / sum;
+#pragma unroll
+                    for (int a = 0; a < Q; ++a) p[a] *= inv;
+                    if (n >= s) {
+                        T px = p[0];
+#pragma unroll
+                        for (int a = 1; a < Q; ++a) px = (a == xi) ? p[a] : px;
+                        if (i < L) facc -= (double)(wn * t_log(px));
+#pragma unroll
+                        for (int a = 0; a < Q; ++a) {
+                            T r = wn * p[a];
+                            if (a == xi) r -= wn;
+                            reinterpret_cast<T*>(sOut)[lane * Q + a] = r;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        unsigned char* row = reinterpret_cast<unsigned char*>(SR + (size_t)n * Cs + (size_t)i0 * Q);
+#pragma unroll
+                        for (int pc = 0; pc < NP; ++pc) {
+                            const int off = pc * 1024 + lane * 16;
+                            if (off < rowBytes) *reinterpret_cast<dca_u4a*>(row + off) = *reinterpret_cast<const dca_u4a*>(sOut + off);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
             }
-#pragma unroll
-            for (int a = 0; a < Q; ++a) zc[a] = zn[a];
         }
     }
     // fixed-order wave reduction, one partial per wave
@@ -710,7 +747,7 @@ __global__ void vec_final_kernel(const double* __restrict__ partials, int nb, in
 // out[0] = (add ? out[0] : 0) + sum partials[0..n)
 __global__ void sum_partials_kernel(const double* __restrict__ partials, int n, double* __restrict__ out, int add)
 {
-    __shared__ double red[256];
+    __shared__ double red[1024];
     double s = 0;
     for (int b = threadIdx.x; b < n; b += blockDim.x) s += partials[b];
     red[threadIdx.x] = s;
@@ -1071,7 +1108,10 @@ struct PlmEngine : PlmEngineBase {
         {
             dim3 grid(ceil_div(L, 64), ceil_div(numScanChunks, 4));
             ScopedKernelClock kc(ctx, "plm_softmax");
-            hipLaunchKernelGGL((plm_softmax_kernel<T, Q>), grid, dim3(256), 0, st, dSR, dx, ctx->dX, dw, dFxPart,
+            constexpr int softNP = (64 * Q * (int)sizeof(T) + 1023) / 1024;
+            const size_t softLds = (size_t)4 * 2 * softNP * 1024;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plm_softmax_kernel<T, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)softLds));
+            hipLaunchKernelGGL((plm_softmax_kernel<T, Q>), grid, dim3(256), softLds, st, dSR, dx, ctx->dX, dw, dFxPart,
                                N, L, Ls, Cs, halo, chunk, warm, carry_mode != DCA_CARRY_EXACT ? 1 : 0, numScanChunks);
         }
         {
@@ -1098,8 +1138,8 @@ struct PlmEngine : PlmEngineBase {
                                dRegPart + npairs, Lq, q, Cs, (T)lambda_h, add_reg);
         }
         // fx = regulariser + data term  -> ctx->dScal[0]
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, dRegPart, nRegPart, ctx->dScal, 0);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, dFxPart, nFxPart, ctx->dScal, 1);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, st, dRegPart, nRegPart, ctx->dScal, 0);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, st, dFxPart, nFxPart, ctx->dScal, 1);
         HIP_TRY(hipGetLastError());
         return DCA_OK;
     }
