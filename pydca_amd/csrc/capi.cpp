@@ -34,6 +34,24 @@ void dca_flush_clocks(dca_ctx* ctx)
         if (_e != hipSuccess) { dca_set_error("hipSetDevice: %s", hipGetErrorString(_e)); return DCA_ERR_HIP; } \
     } while (0)
 
+namespace {
+// dst[n][0..Ls) = src[n][0..L), zero padded
+__global__ void pad_rows_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int N, int L, int Ls)
+{
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= (size_t)N * Ls) return;
+    const size_t n = t / Ls;
+    const int c = (int)(t % Ls);
+    dst[t] = c < L ? src[n * L + c] : (uint8_t)0;
+}
+__global__ void unpad_rows_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int N, int L, int Ls)
+{
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= (size_t)N * L) return;
+    dst[t] = src[(t / L) * Ls + t % L];
+}
+}  // namespace
+
 extern "C" {
 
 const char* dca_last_error(void) { return g_err; }
@@ -116,10 +134,18 @@ const uint8_t* dca_host_msa(dca_ctx* ctx)
 {
     if (ctx->hX.empty() && ctx->dX) {
         ctx->hX.resize((size_t)ctx->N * ctx->L);
-        if (hipMemcpy2D(ctx->hX.data(), (size_t)ctx->L, ctx->dX, (size_t)ctx->Ls, (size_t)ctx->L, (size_t)ctx->N,
-                        hipMemcpyDeviceToHost) != hipSuccess) {
+        uint8_t* dTmp = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dTmp), ctx->hX.size());
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((ctx->hX.size() + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->dX, dTmp, ctx->N, ctx->L, ctx->Ls);
+            e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = hipMemcpy(ctx->hX.data(), dTmp, ctx->hX.size(), hipMemcpyDeviceToHost);
+            hipFree(dTmp);
+        }
+        if (e != hipSuccess) {
             ctx->hX.clear();
-            dca_set_error("copying the alignment back to the host failed");
+            dca_set_error("copying the alignment back to the host failed: %s", hipGetErrorString(e));
             return nullptr;
         }
     }
@@ -171,9 +197,20 @@ int dca_set_msa(dca_ctx* ctx, const uint8_t* X, int N, int L, int q)
     ctx->N = N; ctx->L = L; ctx->q = q;
     ctx->Ls = (int)round_up((size_t)L, 128);
     ctx->hX.clear();                                       // host copy is made on demand (dca_host_msa)
+    // one contiguous copy + a repack kernel (a pitched hipMemcpy2D of narrow rows takes seconds)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dX), (size_t)N * ctx->Ls));
-    HIP_TRY(hipMemset(ctx->dX, 0, (size_t)N * ctx->Ls));
-    HIP_TRY(hipMemcpy2D(ctx->dX, (size_t)ctx->Ls, X, (size_t)L, (size_t)L, (size_t)N, hipMemcpyHostToDevice));
+    {
+        uint8_t* dTmp = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dTmp), (size_t)N * L));
+        hipError_t e = hipMemcpy(dTmp, X, (size_t)N * L, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            const size_t total = (size_t)N * ctx->Ls;
+            hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dTmp, ctx->dX, N, L, ctx->Ls);
+            e = hipStreamSynchronize(ctx->stream);
+        }
+        hipFree(dTmp);
+        if (e != hipSuccess) { dca_set_error("uploading the alignment: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dCounts), (size_t)N * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dWd), (size_t)N * sizeof(double)));
     return DCA_OK;
