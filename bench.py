@@ -207,17 +207,22 @@ def main():
     if world == 1 and not args.no_mfdca:
         # second half of the headline metric: mfDCA residue pairs/s, encoded MSA on host ->
         # FN_APC scores ranked on host (weights + counts + C + inverse + scoring + sort)
-        mctx = _lib.Context(local_rank, _lib.DCA_F64)
-        t0 = time.perf_counter()
-        mctx.set_msa(X, q)
-        mctx.set_profiling(True)
-        mctx.compute_weights(0.8, _lib.DCA_F64)
-        scores = mctx.mf_run(0.5, True)
-        order = mctx.scores_order()          # ranked on the device (stable radix sort)
-        t_mf = time.perf_counter() - t0
+        # one untimed pass first (like the warm-up iterations of the plmDCA leg: first-use code
+        # loading and allocator growth are not part of the metric), then a fresh context is timed
+        for timed in (False, True):
+            mctx = _lib.Context(local_rank, _lib.DCA_F64)
+            t0 = time.perf_counter()
+            mctx.set_msa(X, q)
+            mctx.set_profiling(True)
+            mctx.compute_weights(0.8, _lib.DCA_F64)
+            scores = mctx.mf_run(0.5, True)
+            order = mctx.scores_order()          # ranked on the device (stable radix sort)
+            t_mf = time.perf_counter() - t0
+            if not timed:
+                mctx.close()
         npairs = L * (L - 1) // 2
         out["mfdca"] = {"pairs_per_s": npairs / t_mf, "seconds": t_mf, "pairs": npairs, "top_pair_index": int(order[0]),
-                        "stages_ms": {k: mctx.kernel_time(k)[0] for k in ("weights", "mf_counts", "mf_inverse", "scores")},
+                        "stages_ms": {k: mctx.kernel_time(k)[0] for k in ("weights", "mf_sort", "mf_counts", "mf_inverse", "scores")},
                         "inverse_flops": float((L * (q - 1)) ** 3),
                         "inverse_tflops": float((L * (q - 1)) ** 3) / max(mctx.kernel_time("mf_inverse")[0], 1e-9) / 1e9}
         mctx.close()

@@ -47,7 +47,8 @@ __global__ void weights_bitplanes_kernel(const uint8_t* __restrict__ X, uint32_t
 
 template <int PL>
 __global__ __launch_bounds__(256)
-void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__ counts, int N, int L, int G, int thresh)
+void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__ counts, int N, int L, int G, int thresh,
+                          int tilesPerSide)
 {
     constexpr int PLP = (PL + 1) & ~1;
     constexpr int ROWDW = kKG * PLP;
@@ -57,10 +58,18 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
     __shared__ unsigned sCol[kTile];
     // identity is symmetric: only tile pairs with column tile >= row tile are computed; an
     // off-diagonal tile also credits its columns' sequences (rows of the mirrored tile)
-    if (blockIdx.x < blockIdx.y) return;
-    const bool offDiag = blockIdx.x > blockIdx.y;
+    // The 1-D grid walks the tile-pair matrix in 32 x 32 super-tiles so that the workgroups in flight
+    // share row and column tiles in L2 (a row-major walk streams the whole plane array per tile row:
+    // 6 GB of fabric traffic at config D for 16 MB of planes).
+    constexpr int S = 32;
+    const int superPerSide = (tilesPerSide + S - 1) / S;
+    const int sid = blockIdx.x / (S * S), within = blockIdx.x % (S * S);
+    const int tileY = (sid / superPerSide) * S + within / S;
+    const int tileX = (sid % superPerSide) * S + within % S;
+    if (tileY >= tilesPerSide || tileX >= tilesPerSide || tileX < tileY) return;
+    const bool offDiag = tileX > tileY;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int rowBase = blockIdx.y * kTile, colBase = blockIdx.x * kTile;
+    const int rowBase = tileY * kTile, colBase = tileX * kTile;
     if (threadIdx.x < kTile) sCol[threadIdx.x] = 0;
     const int rowDwords = G * PLP;
     unsigned mism[4][4];
@@ -169,13 +178,15 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision)
         uint32_t* dP = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dP), (size_t)N * G * PLP * sizeof(uint32_t)));
         const unsigned tb = (unsigned)(((size_t)N * G + 255) / 256);
-        dim3 grid(ceil_div(N, kTile), ceil_div(N, kTile));
+        const int tilesPerSide = ceil_div(N, kTile);
+        const int superPerSide = ceil_div(tilesPerSide, 32);
+        dim3 grid((unsigned)(superPerSide * superPerSide * 32 * 32));
         if (small) {
             hipLaunchKernelGGL(weights_bitplanes_kernel<3>, dim3(tb), dim3(256), 0, ctx->stream, ctx->dX, dP, N, ctx->Ls);
-            hipLaunchKernelGGL(weights_count_kernel<3>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh);
+            hipLaunchKernelGGL(weights_count_kernel<3>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide);
         } else {
             hipLaunchKernelGGL(weights_bitplanes_kernel<5>, dim3(tb), dim3(256), 0, ctx->stream, ctx->dX, dP, N, ctx->Ls);
-            hipLaunchKernelGGL(weights_count_kernel<5>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh);
+            hipLaunchKernelGGL(weights_count_kernel<5>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide);
         }
         hipError_t e = hipStreamSynchronize(ctx->stream);
         hipFree(dP);
