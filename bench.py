@@ -186,7 +186,12 @@ def main():
                 "avg_kernel_ms": ms / max(launches, 1), "launches": launches,
                 "note": "gather kernels: bound on chip (LDS reads + VALU/SALU issue), not by HBM (DESIGN.md section 4); see onchip",
                 "onchip": {"bound": "lds", "achieved": lds_bytes[dom] / avg_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                           "frac": lds_bytes[dom] / avg_s / 1e9 / LDS_PEAK_GBS}}
+                           "frac": lds_bytes[dom] / avg_s / 1e9 / LDS_PEAK_GBS},
+                # the adds themselves: N*L*Lq fp32 (fp64) adds per launch against the vector peak counted in
+                # adds (157.3 TFLOP/s fp32 = 78.6e12 FMA slots/s; fp64 half of that)
+                "valu": {"bound": "valu", "achieved": n_local * L * Lq / avg_s / 1e12,
+                         "peak": 78.6 if args.precision == 32 else 39.3, "unit": "Tadd/s",
+                         "frac": n_local * L * Lq / avg_s / 1e12 / (78.6 if args.precision == 32 else 39.3)}}
     kernels_ms = {k: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in ktimes.items()}
 
     out = {
