@@ -444,3 +444,27 @@ def test_scores_order_matches_stable_argsort(L_, oracle_mf):
     with pytest.raises(L_.DcaBackendError):
         c2.scores_order()
     c2.close()
+
+
+@pytest.mark.parametrize("N,L,q", [(1, 2, 5), (3, 2, 21), (7, 5, 21), (33, 7, 5), (129, 13, 21), (130, 33, 5),
+                                    (513, 6, 21), (640, 25, 5), (257, 31, 21)])
+def test_gradient_edge_shapes(L_, oracle_plm, N, L, q):
+    """Shapes at and across the tile boundaries of the two gather kernels: fewer sequences than one
+    32-sequence wave block / 128-row tile / 512-sequence workgroup (+1), fewer sites than one LDS tile
+    of W (6 resp. 24 sites) or one 32-site scatter group (+1), a single sequence, the minimum L = 2."""
+    rng = np.random.default_rng(1000 * N + 10 * L + q)
+    X = rng.integers(0, q, size=(N, L), dtype=np.uint8)
+    X = np.unique(X, axis=0)                      # the library expects de-duplicated rows like the reader yields
+    rng.shuffle(X, axis=0)
+    w = oracle_plm.weights(X, 0.8, np.float32)
+    x = perturbed(oracle_plm.init_x(X, w, q), L, q)
+    fx_o, g_o = oracle_plm.gradient(X, w.astype(np.float64), q, 0.7, 3.0, x.astype(np.float64), carry=True)
+    for prec, tol in ((L_.DCA_F32, 2e-5), (L_.DCA_F64, 1e-10)):
+        ctx = make_ctx(L_, X, q, prec, 0.8, L_.DCA_F32)
+        ctx.plm_configure(0.7, 3.0)
+        ctx.plm_set_x(x)
+        fx = ctx.plm_gradient()
+        g = ctx.plm_get_g(np.float64)
+        assert abs(fx - fx_o) <= tol * abs(fx_o), (prec, fx, fx_o)
+        assert rel_err(g, g_o) < tol, (prec, rel_err(g, g_o))
+        ctx.close()
