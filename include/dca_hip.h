@@ -183,6 +183,12 @@ int dca_mf_fields(dca_ctx* ctx, double* fields_out);
 /* coupling blocks of selected pairs, optionally gauge shifted (MeanFieldDCA.compute_params,
  * meanfield_dca.py:661-752; shift_couplings :636-658) */
 int dca_mf_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift, double* out);
+/* Sequence sharding of the pair counts: with a hook set, every shard context (its block of the
+ * alignment, the GLOBAL weights of those sequences via dca_set_weights) calls it once after its
+ * local counts are on the device: g_dev = the Lq x Lq raw weighted counts (doubles), fx_dev = Meff
+ * (one double); the hook sums both over the shards in place.  Everything downstream (frequencies,
+ * correlation matrix, inverse, scores) is then identical on every shard. */
+int dca_mf_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user);
 /* whole chain on the device: counts -> C -> -inv -> scores */
 int dca_mf_run(dca_ctx* ctx, double pseudocount, int apc, double* scores_out, double* couplings_out /* may be NULL */);
 /* stage API on caller-provided arrays: construct_corr_mat (:270-318) from regularised

@@ -319,6 +319,13 @@ int dca_plm_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift
     if (npairs < 0 || (npairs > 0 && (!pairs || !out))) return DCA_ERR_ARG;
     return ctx->plm->pair_couplings(pairs, npairs, shift, out);
 }
+int dca_mf_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user)
+{
+    CHECK_CTX(ctx);
+    DCA_TRY(need_mf(ctx));
+    dca_mf_engine_set_hook(ctx->mf, hook, user);
+    return DCA_OK;
+}
 int dca_mf_fields(dca_ctx* ctx, double* out) { CHECK_CTX(ctx); DCA_TRY(need_mf(ctx)); if (!out) return DCA_ERR_ARG; return dca_mf_engine_fields(ctx->mf, out); }
 int dca_mf_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift, double* out)
 {

@@ -154,6 +154,7 @@ int dca_mf_engine_couplings(MfEngine*, double* out);
 int dca_mf_engine_scores(MfEngine*, int apc, double* out);
 int dca_mf_engine_di(MfEngine*, int apc, double* out);
 int dca_mf_engine_fields(MfEngine*, double* out);
+void dca_mf_engine_set_hook(MfEngine*, dca_reduce_hook hook, void* user);
 int dca_mf_engine_pair_couplings(MfEngine*, const int* pairs, int npairs, int shift, double* out);
 
 // ---- cholinv.hip : in-place inverse of an SPD matrix on the device (f64 MFMA)

@@ -259,6 +259,8 @@ struct MfEngine {
     bool have_counts = false, have_corr = false, have_J = false;
     double theta = 0.0;
     double* dRegFi = nullptr;
+    dca_reduce_hook hook = nullptr;   // sequence sharding: sums Craw and Meff over the shards
+    void* hook_user = nullptr;
     ~MfEngine() { hipFree(dRegFi); hipFree(dPerm); hipFree(dOff); hipFree(dXT); hipFree(dDom); hipFree(dCnt1); hipFree(dCraw); hipFree(dFi); hipFree(dC); hipFree(dJ); hipFree(dWork); }
 };
 
@@ -302,6 +304,17 @@ static int mf_counts(MfEngine* m)
                            m->dPerm, m->dOff, m->dDom, m->dCraw, m->N, m->L, m->Ls, m->q, m->Lq);
         hipLaunchKernelGGL(mf_complete_kernel, dim3(m->L, m->L), dim3(64), 0, ctx->stream, m->dCraw, m->dCnt1, m->dDom,
                            m->L, m->q, m->Lq);
+    }
+    if (m->hook) {
+        // the counts are linear in the sequences: shards hold contiguous blocks of the alignment with the
+        // GLOBAL weights, the hook sums the Lq x Lq raw counts and the effective sequence number in place
+        HIP_TRY(hipMemcpyAsync(ctx->dScal, &ctx->meff, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (m->hook(m->hook_user, m->dCraw, (size_t)m->Lq * m->Lq, DCA_F64, ctx->dScal) != 0) {
+            dca_set_error("reduce hook failed");
+            return DCA_ERR_ARG;
+        }
+        HIP_TRY(hipMemcpy(&ctx->meff, ctx->dScal, sizeof(double), hipMemcpyDeviceToHost));
     }
     hipLaunchKernelGGL(mf_fi_kernel, dim3(ceil_div(m->Lq, 256)), dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->Lq, m->Lq, ctx->meff);
     HIP_TRY(hipGetLastError());
@@ -497,4 +510,11 @@ int dca_mf_engine_pair_couplings(MfEngine* m, const int* pairs, int npairs, int 
 {
     if (!m->have_J) { dca_set_error("dca_mf_couplings first"); return DCA_ERR_STATE; }
     return dca_pair_blocks(m->ctx, m->dJ, 1, DCA_F64, m->L, m->q, m->np, pairs, npairs, shift, out);
+}
+
+void dca_mf_engine_set_hook(MfEngine* m, dca_reduce_hook hook, void* user)
+{
+    m->hook = hook;
+    m->hook_user = user;
+    m->have_counts = m->have_corr = m->have_J = false;
 }

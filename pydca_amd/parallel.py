@@ -9,6 +9,11 @@ torch.distributed from the library's reduce hook.  The regulariser is added on r
 only.  Weights depend on the whole alignment, so they are computed once on the full MSA
 (it is tens of MB) and the shard's slice is handed to the shard context.
 
+mfDCA shards the same way for its one N-dependent stage, the weighted pair counts: every rank
+counts its block (global weights), ONE all-reduce(sum) of the (L q)^2 raw counts and of Meff through
+the same hook protocol (`Context.mf_set_reduce_hook`), after which frequencies, correlation
+matrix, inverse and scores are computed identically on every rank (`make_sharded_mf_context`).
+
 No reference counterpart: pydca is single-process.
 """
 import ctypes as C
@@ -127,3 +132,14 @@ def initial_x(X, weights, q, dtype=np.float32):
     x = np.zeros(P, dtype=dtype)
     x[:L * q] = h.reshape(-1)
     return x
+
+
+def make_sharded_mf_context(lib_mod, X, q, weights, rank, world, device):
+    """Shard context for the mfDCA pair counts: the rank's block of the alignment (0-based codes) with
+    the global weights of those sequences; set a reduce hook (e.g. TorchAllReduceHook) before
+    calling mf_run / mf_corr_mat."""
+    start, stop = shard_bounds(X.shape[0], world, rank)
+    ctx = lib_mod.Context(device, lib_mod.DCA_F64)
+    ctx.set_msa(np.ascontiguousarray(X[start:stop]), q)
+    ctx.set_weights(np.ascontiguousarray(weights[start:stop], dtype=np.float64))
+    return ctx

@@ -131,6 +131,54 @@ def test_sharded_contexts_sum_to_unsharded(oracle_plm, world):
     assert rel_err(g_sum, g_full) < 1e-11
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_mf_counts_sum_to_unsharded(world):
+    """mfDCA sequence sharding emulated on one GPU: every shard context counts its block with the
+    global weights; a recording hook collects the partial counts, a second pass hands every shard
+    the sum -- scores and frequencies must equal the unsharded run (<= 1e-12)."""
+    import ctypes as C
+    from pydca_amd import _lib, parallel
+    M = golden("mf_rf71")
+    X = (M["X"] - 1).astype(np.uint8)
+    q, theta, w = int(M["q"]), float(M["pseudocount"]), M["w"]
+    Lq = X.shape[1] * q
+    full = _lib.Context(0, _lib.DCA_F64)
+    full.set_msa(X, q)
+    full.set_weights(w)
+    ref_scores = full.mf_run(theta, True)
+    ref_fi = full.mf_single_site_freqs()
+    full.close()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    total = np.zeros(Lq * Lq)
+    meff = np.zeros(1)
+
+    def recorder(dev, count, dtype, scalar_dev):
+        part, m = np.zeros(count), np.zeros(1)
+        assert dtype == 64 and count == Lq * Lq
+        assert hip.hipMemcpy(part.ctypes.data, dev, count * 8, 2) == 0 and hip.hipMemcpy(m.ctypes.data, scalar_dev, 8, 2) == 0
+        total[:] += part
+        meff[:] += m
+        return 0
+
+    def replayer(dev, count, dtype, scalar_dev):
+        assert hip.hipMemcpy(dev, total.ctypes.data, count * 8, 1) == 0 and hip.hipMemcpy(scalar_dev, meff.ctypes.data, 8, 1) == 0
+        return 0
+
+    for rank in range(world):
+        ctx = parallel.make_sharded_mf_context(_lib, X, q, w, rank, world, 0)
+        ctx.mf_set_reduce_hook(recorder)
+        ctx.mf_single_site_freqs()
+        ctx.close()
+    assert abs(meff[0] - w.sum()) <= 1e-12 * w.sum()
+    for rank in range(world):
+        ctx = parallel.make_sharded_mf_context(_lib, X, q, w, rank, world, 0)
+        ctx.mf_set_reduce_hook(replayer)
+        np.testing.assert_allclose(ctx.mf_single_site_freqs(), ref_fi, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(ctx.mf_run(theta, True), ref_scores, rtol=1e-9)
+        ctx.close()
+
+
 def test_reduce_hook_through_torch_distributed():
     """The all-reduce hook path (torch.distributed, backend nccl = RCCL) with a 1-rank group:
     the gradient must come back unchanged and the optimiser must still run."""
@@ -159,6 +207,18 @@ def test_reduce_hook_through_torch_distributed():
         st = ctx.plm_lbfgs_iterate(5)
         assert st.iterations == 5 and hook.calls == 1 + st.evaluations
         ctx.close()
+        # the same hook on the mfDCA pair counts (float64 buffer of (L q)^2 counts + Meff)
+        M = golden("mf_toy_protein")
+        mctx = _lib.Context(0, _lib.DCA_F64)
+        mctx.set_msa((M["X"] - 1).astype(np.uint8), int(M["q"]))
+        mctx.compute_weights(float(M["seqid"]), _lib.DCA_F64)
+        mhook = parallel.TorchAllReduceHook(0)
+        mctx.mf_set_reduce_hook(mhook)
+        scores = mctx.mf_run(float(M["pseudocount"]), True)
+        assert mhook.calls == 1
+        ranked = sorted(zip(scores, range(len(scores))), key=lambda t: (-t[0], t[1]))
+        np.testing.assert_allclose([s for s, _ in ranked], M["apc_scores"], rtol=1e-9)
+        mctx.close()
     finally:
         dist.destroy_process_group()
 
