@@ -391,7 +391,7 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
     const int jc0 = min(j0, L - 1), jc1 = min(j0 + 1, L - 1);
 
     // blockIdx.y splits the tile range; every split writes its own slab of G (summed by
-    // plm_sum_slabs_kernel in a fixed order), so small L*q shapes still fill the chip.
+    // the fold kernels in a fixed order), so small L*q shapes still fill the chip.
     const int cBegin = blockIdx.y * chunksPerSplit;
     const int cEnd = min(numChunks, cBegin + chunksPerSplit);
 
@@ -452,25 +452,24 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
         scatter_store_site<Q>(acc1, reinterpret_cast<unsigned char*>(Gslab + (size_t)(j0 + 1) * Q * Cs + (size_t)ct * CW) + lane * 8, rowStrideBytes);
 }
 
-// G[0] += G[1] + ... + G[nsplit-1], fixed order (deterministic)
-template <typename T>
-__global__ void plm_sum_slabs_kernel(T* __restrict__ G, size_t slabElems, int nsplit)
-{
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < slabElems; i += (size_t)gridDim.x * blockDim.x) {
-        T a = G[i];
-        for (int sidx = 1; sidx < nsplit; ++sidx) a += G[(size_t)sidx * slabElems + i];
-        G[i] = a;
-    }
-}
-
 // ------------------------------------------------------------------ fold
 // g[J_ij(a,b)] = 2 lambda_J J + G[(j,b)][(i,a)] + G[(i,a)][(j,b)]   (plmdca_numerics.cpp:541-602:
 // the site-i and the site-j conditional both contribute), regulariser value per pair
 // (:473-486) as a double partial.
+// G arrives as `nsplit` slabs (one per tile-range split of the scatter grid); they are summed here in
+// slab order, which is what a separate pass over the slabs would produce.
+template <typename T>
+__device__ __forceinline__ T slab_sum(const T* __restrict__ G, size_t off, size_t slabElems, int nsplit)
+{
+    T a = G[off];
+    for (int sidx = 1; sidx < nsplit; ++sidx) a += G[(size_t)sidx * slabElems + off];
+    return a;
+}
+
 template <typename T>
 __global__ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
                                       const PairIJ* __restrict__ pairs, double* __restrict__ regPart,
-                                      int L, int q, int Cs, T lambdaJ, int addReg)
+                                      int L, int q, int Cs, T lambdaJ, int addReg, size_t slabElems, int nsplit)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
     T* tile = reinterpret_cast<T*>(dca_smem);                 // G[(j,b)][(i,a)] stored as tile[b*q+a]
@@ -480,7 +479,7 @@ __global__ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restri
     const int q2 = q * q;
     for (int t = threadIdx.x; t < q2; t += blockDim.x) {
         const int b = t / q, a = t % q;
-        tile[t] = G[(size_t)(j * q + b) * Cs + i * q + a];
+        tile[t] = slab_sum(G, (size_t)(j * q + b) * Cs + i * q + a, slabElems, nsplit);
     }
     __syncthreads();
     const size_t base = (size_t)L * q + (size_t)p * q2;
@@ -489,7 +488,7 @@ __global__ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restri
         const int a = t / q, b = t % q;
         const T xv = x[base + t];
         T gv = addReg ? (T)2 * lambdaJ * xv : (T)0;
-        gv += G[(size_t)(i * q + a) * Cs + j * q + b];
+        gv += slab_sum(G, (size_t)(i * q + a) * Cs + j * q + b, slabElems, nsplit);
         gv += tile[b * q + a];
         g[base + t] = gv;
         if (addReg) reg += (double)lambdaJ * (double)xv * (double)xv;
@@ -507,7 +506,8 @@ __global__ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restri
 // any site's rows of G (site 0 here).  (:463-471, :538-539, :573-578)
 template <typename T>
 __global__ void plm_fold_fields_kernel(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
-                                       double* __restrict__ regPart, int Lq, int q, int Cs, T lambdaH, int addReg)
+                                       double* __restrict__ regPart, int Lq, int q, int Cs, T lambdaH, int addReg,
+                                       size_t slabElems, int nsplit)
 {
     __shared__ double red[256];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -516,7 +516,7 @@ __global__ void plm_fold_fields_kernel(const T* __restrict__ x, const T* __restr
         const T xv = x[c];
         T gv = addReg ? (T)2 * lambdaH * xv : (T)0;
         T s = 0;
-        for (int b = 0; b < q; ++b) s += G[(size_t)b * Cs + c];
+        for (int b = 0; b < q; ++b) s += slab_sum(G, (size_t)b * Cs + c, slabElems, nsplit);
         g[c] = gv + s;
         if (addReg) reg = (double)lambdaH * (double)xv * (double)xv;
     }
@@ -1126,16 +1126,14 @@ struct PlmEngine : PlmEngineBase {
             hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(kScatWavesC * 64), lds, st, dSR, dXT2, dZeros, dG, N, L, Cs, halo,
                                numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs,
                                getenv("DCA_SCATTER_ABLATE") ? atoi(getenv("DCA_SCATTER_ABLATE")) : 0);
-            if (scatSplit > 1)
-                hipLaunchKernelGGL(plm_sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, st, dG, (size_t)Grows * Cs, scatSplit);
         }
         {
             ScopedKernelClock kc(ctx, "plm_fold");
             const size_t lds = ((size_t)q * q * sizeof(T) + 15) / 16 * 16 + 256 * sizeof(double);
             hipLaunchKernelGGL(plm_fold_pairs_kernel<T>, dim3((unsigned)npairs), dim3(256), lds, st, dx, dG, dg, dPairs,
-                               dRegPart, L, q, Cs, (T)lambda_J, add_reg);
+                               dRegPart, L, q, Cs, (T)lambda_J, add_reg, (size_t)Grows * Cs, scatSplit);
             hipLaunchKernelGGL(plm_fold_fields_kernel<T>, dim3(ceil_div(Lq, 256)), dim3(256), 0, st, dx, dG, dg,
-                               dRegPart + npairs, Lq, q, Cs, (T)lambda_h, add_reg);
+                               dRegPart + npairs, Lq, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, scatSplit);
         }
         // fx = regulariser + data term  -> ctx->dScal[0]
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, st, dRegPart, nRegPart, ctx->dScal, 0);
