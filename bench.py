@@ -94,12 +94,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # self-test of the multi-process path on a box with ONE GPU: DCA_BENCH_SELFTEST=1 puts every rank on
+    # device 0 and uses gloo (RCCL refuses two ranks on one device); numbers from it are meaningless
+    selftest = os.environ.get("DCA_BENCH_SELFTEST") == "1"
+    if selftest:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if selftest:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:
@@ -130,8 +138,14 @@ def main():
         ctx = parallel.make_sharded_plm_context(_lib, X, q, w32.astype(np.float64), lh, lJ, rank, world, local_rank,
                                                 precision=args.precision)
         ctx.plm_set_x(parallel.initial_x(X, w32, q, np.float32))
-        hook = parallel.TorchAllReduceHook(local_rank)
-        ctx.plm_set_reduce_hook(hook)
+        # sequences AND optimiser vectors sharded: reduce-scatter(g) + all-gather(x) per evaluation
+        # (DCA_BENCH_ALLREDUCE=1 selects the plain all-reduce of g with replicated vectors instead)
+        if os.environ.get("DCA_BENCH_ALLREDUCE") == "1":
+            hook = parallel.TorchAllReduceHook(local_rank)
+            ctx.plm_set_reduce_hook(hook)
+        else:
+            hook = parallel.TorchVectorComm(local_rank, rank, world)
+            ctx.plm_set_vector_sharding(rank, world, hook)
     t_setup = time.perf_counter() - t0
 
     # ---- warm-up iterations, then exactly K timed iterations
@@ -201,7 +215,7 @@ def main():
         "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
         "config": {"workload": "plmdca compute_fn protein, synthetic MSA L=%d N=%d q=%d, lambda_h=%g lambda_J=%g seqid=0.8, "
                                "reference carry-over semantics (chunked scan)" % (L, N, q, lh, lJ),
-                   "config_id": args.workload, "num_params": P, "parallelism": "sequences sharded x%d + all-reduce(g)" % world},
+                   "config_id": args.workload, "num_params": P, "parallelism": "sequences sharded x%d, reduce-scatter(g) + all-gather(x) over RCCL, L-BFGS vectors sharded x%d" % (world, world)},
         "evaluations_per_iteration": evals / max(steps_done, 1), "evaluations_per_s": evals / dt,
         "lbfgs_status": st.status, "fx": st.fx,
         "setup_s": {"generate_msa": t_gen, "weights_kernel": t_weights_ms / 1e3, "total_setup": t_setup},

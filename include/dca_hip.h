@@ -124,6 +124,21 @@ int dca_plm_get_g(dca_ctx* ctx, void* g_out, int dtype);
 typedef int (*dca_reduce_hook)(void* user, void* g_dev, size_t count, int dtype, void* fx_dev);
 int dca_plm_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user);
 
+/* Sharded optimiser state (optional, on top of sequence sharding).  With a comm hook set the
+ * P-vectors of the L-BFGS (x_prev, g, g_prev, d, 5 x (s, y)) are only maintained on this rank's
+ * slice: an evaluation ends with REDUCE_SCATTER of the local gradients (instead of the all-reduce of
+ * dca_plm_set_reduce_hook, which is then not used), a step ends with ALL_GATHER of x, and the dot
+ * products are ALL_REDUCEd as a handful of doubles.  Same bytes on the wire as one all-reduce per
+ * evaluation, but the vector work is divided by `world`.  The hook works on DEVICE memory, in place:
+ *   DCA_COMM_ALL_REDUCE     buf[0..count) summed over the ranks (dtype DCA_F64 scalars)
+ *   DCA_COMM_REDUCE_SCATTER buf[0..count) summed; the rank needs only its slice afterwards
+ *   DCA_COMM_ALL_GATHER     the rank's slice of buf is valid; all of buf[0..count) afterwards
+ * count is a multiple of world; rank r's slice is [r * count / world, (r + 1) * count / world).
+ * The context's stream is idle when the hook runs.  Call after dca_plm_configure. */
+enum { DCA_COMM_ALL_REDUCE = 0, DCA_COMM_REDUCE_SCATTER = 1, DCA_COMM_ALL_GATHER = 2 };
+typedef int (*dca_comm_hook)(void* user, int op, void* buf_dev, size_t count, int dtype);
+int dca_plm_set_vector_sharding(dca_ctx* ctx, int rank, int world, dca_comm_hook hook, void* user);
+
 typedef struct {
     int status;        /* libLBFGS code as the reference would report it (lbfgs.h:76-149): 0, -997, -998, -1001 ... */
     int iterations;    /* completed iterations since dca_plm_lbfgs_begin */

@@ -32,6 +32,8 @@ class PlmStats(C.Structure):
                 ("seconds", C.c_double)]
 
 
+COMM_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int)
+COMM_ALL_REDUCE, COMM_REDUCE_SCATTER, COMM_ALL_GATHER = 0, 1, 2
 REDUCE_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 
@@ -77,6 +79,7 @@ def lib():
         "dca_plm_get_g": (i, [vp, vp, i]),
         "dca_plm_set_reduce_hook": (i, [vp, REDUCE_HOOK, vp]),
         "dca_mf_set_reduce_hook": (i, [vp, REDUCE_HOOK, vp]),
+        "dca_plm_set_vector_sharding": (i, [vp, i, i, COMM_HOOK, vp]),
         "dca_plm_lbfgs_begin": (i, [vp, i, i]),
         "dca_plm_lbfgs_iterate": (i, [vp, i, C.POINTER(PlmStats)]),
         "dca_plm_scores": (i, [vp, i, vp]),
@@ -115,7 +118,7 @@ def lib():
 EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_read_msa", "dca_count_msa_lines", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_num_params", "dca_plm_init_x",
-           "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook",
+           "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_plm_set_vector_sharding",
            "dca_plm_lbfgs_begin", "dca_plm_lbfgs_iterate", "dca_plm_scores", "dca_plm_di_scores",
            "dca_mf_di_scores", "dca_plm_pair_couplings", "dca_mf_fields", "dca_mf_pair_couplings",
            "dca_mf_single_site_freqs",
@@ -243,6 +246,20 @@ class Context:
                 return 1
         self._hook = REDUCE_HOOK(tramp) if pyfunc is not None else C.cast(None, REDUCE_HOOK)
         check(self._l.dca_plm_set_reduce_hook(self._h, self._hook, None))
+
+    def plm_set_vector_sharding(self, rank, world, pyfunc):
+        """Shard the optimiser's P-vectors over `world` ranks; pyfunc(op, buf_dev_ptr, count, dtype) -> 0
+        runs the collectives (COMM_ALL_REDUCE / COMM_REDUCE_SCATTER / COMM_ALL_GATHER, in place on
+        device memory).  pyfunc=None switches back to replicated vectors."""
+        def tramp(user, op, buf, count, dtype):
+            try:
+                return int(pyfunc(op, buf, count, dtype) or 0)
+            except Exception:   # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._comm = COMM_HOOK(tramp) if pyfunc is not None else C.cast(None, COMM_HOOK)
+        check(self._l.dca_plm_set_vector_sharding(self._h, int(rank), int(world), self._comm, None))
 
     def mf_set_reduce_hook(self, pyfunc):
         """Same hook protocol for the mfDCA pair counts: pyfunc(craw_dev_ptr, count, 64, meff_dev_ptr)."""

@@ -280,6 +280,12 @@ int dca_plm_set_x(dca_ctx* ctx, const void* x, int dtype) { CHECK_CTX(ctx); DCA_
 int dca_plm_get_x(dca_ctx* ctx, void* x, int dtype) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->get_x(x, dtype); }
 int dca_plm_get_g(dca_ctx* ctx, void* g, int dtype) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->get_g(g, dtype); }
 int dca_plm_gradient(dca_ctx* ctx, double* fx_out) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->gradient(fx_out); }
+int dca_plm_set_vector_sharding(dca_ctx* ctx, int rank, int world, dca_comm_hook hook, void* user)
+{
+    CHECK_CTX(ctx);
+    DCA_TRY(need_plm(ctx));
+    return ctx->plm->set_vector_sharding(rank, world, hook, user);
+}
 int dca_plm_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user)
 {
     CHECK_CTX(ctx);

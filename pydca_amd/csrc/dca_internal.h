@@ -126,6 +126,7 @@ struct PlmEngineBase {
     virtual int scores(int apc, double* out) = 0;
     virtual int di_scores(const double* reg_fi, int apc, double* out) = 0;
     virtual int pair_couplings(const int* pairs, int npairs, int shift, double* out) = 0;
+    virtual int set_vector_sharding(int rank, int world, dca_comm_hook hook, void* user) = 0;
     dca_reduce_hook hook = nullptr;
     void* hook_user = nullptr;
 };

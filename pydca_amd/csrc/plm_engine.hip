@@ -891,6 +891,12 @@ struct PlmEngine : PlmEngineBase {
     double *dFxPart = nullptr, *dRegPart = nullptr, *dVecPart = nullptr;
     int nFxPart = 0, nRegPart = 0;
     bool lbfgs_alloc = false;
+    // vector sharding (dca_plm_set_vector_sharding): this rank's slice [vlo, vlo + vn) of every P-vector;
+    // collectives run over Ppad = world * slice elements.  Unsharded: vlo = 0, vn = Ppad = P.
+    static constexpr size_t kVecPad = 256;
+    size_t vlo = 0, vn = 0, Ppad = 0;
+    dca_comm_hook comm = nullptr;
+    void* comm_user = nullptr;
 
     // optimiser state (resumable)
     struct {
@@ -951,7 +957,7 @@ struct PlmEngine : PlmEngineBase {
         Grows = ceil_div(L, JG) * JG * q;
         Npad = (int)round_up(N, kLogitSeqPerWG);
 
-        DCA_TRY(dalloc(&dx, P)); DCA_TRY(dalloc(&dg, P));
+        DCA_TRY(dalloc(&dx, P + kVecPad)); DCA_TRY(dalloc(&dg, P + kVecPad));
         DCA_TRY(dalloc(&dWt, (size_t)Wrows * Cs));
         DCA_TRY(dalloc(&dSR, (size_t)N * Cs));
         {
@@ -977,8 +983,9 @@ struct PlmEngine : PlmEngineBase {
         DCA_TRY(dalloc(&dRegPart, nRegPart));
         DCA_TRY(dalloc(&dVecPart, 25 * kVecBlocks));
 
-        HIP_TRY(hipMemsetAsync(dx, 0, P * sizeof(T), ctx->stream));
-        HIP_TRY(hipMemsetAsync(dg, 0, P * sizeof(T), ctx->stream));
+        HIP_TRY(hipMemsetAsync(dx, 0, (P + kVecPad) * sizeof(T), ctx->stream));
+        HIP_TRY(hipMemsetAsync(dg, 0, (P + kVecPad) * sizeof(T), ctx->stream));
+        vlo = 0; vn = P; Ppad = P; comm = nullptr; comm_user = nullptr;
         HIP_TRY(hipMemsetAsync(dWt, 0, (size_t)Wrows * Cs * sizeof(T), ctx->stream));
         HIP_TRY(hipMemsetAsync(dG, 0, (size_t)scatSplit * Grows * Cs * sizeof(T), ctx->stream));
 
@@ -1079,6 +1086,7 @@ struct PlmEngine : PlmEngineBase {
     int get_g(void* g, int dtype) override
     {
         if (!configured) return DCA_ERR_STATE;
+        DCA_TRY(gather_vector(dg));
         if (dtype == DCA_F32) return download(dg, static_cast<float*>(g));
         if (dtype == DCA_F64) return download(dg, static_cast<double*>(g));
         return DCA_ERR_ARG;
@@ -1149,13 +1157,49 @@ struct PlmEngine : PlmEngineBase {
         int rc = (q == 21) ? launch_eval<21>() : launch_eval<5>();
         if (rc != DCA_OK) return rc;
         o.evals += 1;
-        if (hook) {
+        if (comm) {
+            // sharded vectors: sum the shards' gradients, keep this rank's slice; fx is summed with the
+            // scalars of the caller (eval_scalars / gradient)
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (comm(comm_user, DCA_COMM_REDUCE_SCATTER, dg, Ppad, (int)sizeof(T) * 8) != 0) { dca_set_error("comm hook failed (reduce-scatter)"); return DCA_ERR_ARG; }
+        } else if (hook) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             if (hook(hook_user, dg, P, (int)sizeof(T) * 8, ctx->dScal) != 0) {
                 dca_set_error("reduce hook failed");
                 return DCA_ERR_ARG;
             }
         }
+        return DCA_OK;
+    }
+
+    // sum `count` device doubles ctx->dScal[first..] over the ranks (no-op when vectors are not sharded)
+    int reduce_scalars(int first, int count)
+    {
+        if (!comm) return DCA_OK;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (comm(comm_user, DCA_COMM_ALL_REDUCE, ctx->dScal + first, (size_t)count, DCA_F64) != 0) { dca_set_error("comm hook failed (all-reduce)"); return DCA_ERR_ARG; }
+        return DCA_OK;
+    }
+    // make a P-vector whose slices are valid on their owners valid everywhere
+    int gather_vector(T* v)
+    {
+        if (!comm) return DCA_OK;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (comm(comm_user, DCA_COMM_ALL_GATHER, v, Ppad, (int)sizeof(T) * 8) != 0) { dca_set_error("comm hook failed (all-gather)"); return DCA_ERR_ARG; }
+        return DCA_OK;
+    }
+    int set_vector_sharding(int rank, int world, dca_comm_hook h, void* user) override
+    {
+        if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
+        if (o.begun && !o.finished) { dca_set_error("vector sharding cannot change during an optimisation"); return DCA_ERR_STATE; }
+        if (!h || world < 1) { vlo = 0; vn = P; Ppad = P; comm = nullptr; comm_user = nullptr; return DCA_OK; }
+        if (rank < 0 || rank >= world || world > 64) { dca_set_error("bad rank / world"); return DCA_ERR_ARG; }
+        const size_t slice = (P + (size_t)world * 4 - 1) / ((size_t)world * 4) * 4;    // multiple of 4 elements: 16-byte aligned slices
+        if (slice * world > P + kVecPad) { dca_set_error("world too large for the vector padding"); return DCA_ERR_ARG; }
+        Ppad = slice * world;
+        vlo = slice * rank;
+        vn = vlo >= P ? 0 : std::min(slice, P - vlo);
+        comm = h; comm_user = user;
         return DCA_OK;
     }
 
@@ -1169,16 +1213,18 @@ struct PlmEngine : PlmEngineBase {
     int gradient(double* fx_out) override
     {
         DCA_TRY(evaluate_async());
+        DCA_TRY(reduce_scalars(0, 1));
+        DCA_TRY(gather_vector(dg));
         DCA_TRY(read_scalars(1));
         if (fx_out) *fx_out = ctx->hScal[0];
         return DCA_OK;
     }
 
     // ---------------- vector helpers
-    void v_neg(T* d, const T* g) { hipLaunchKernelGGL(vec_neg_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, d, g, P); }
-    void v_axpy(T* y, double a, const T* x) { hipLaunchKernelGGL(vec_axpy_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, y, (T)a, x, P); }
-    void v_scale(T* y, double a) { hipLaunchKernelGGL(vec_scale_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, y, (T)a, P); }
-    void v_step(T* x, const T* xp, double stp, const T* d) { hipLaunchKernelGGL(vec_step_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, x, xp, (T)stp, d, P); }
+    void v_neg(T* d, const T* g) { hipLaunchKernelGGL(vec_neg_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, d + vlo, g + vlo, vn); }
+    void v_axpy(T* y, double a, const T* x) { hipLaunchKernelGGL(vec_axpy_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, y + vlo, (T)a, x + vlo, vn); }
+    void v_scale(T* y, double a) { hipLaunchKernelGGL(vec_scale_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, y + vlo, (T)a, vn); }
+    void v_step(T* x, const T* xp, double stp, const T* d) { hipLaunchKernelGGL(vec_step_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, x + vlo, xp + vlo, (T)stp, d + vlo, vn); }
     int v_copy(T* dst, const T* src) { HIP_TRY(hipMemcpyAsync(dst, src, P * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream)); return DCA_OK; }
     int v_dot(const T* a, const T* b, double* out)
     {
@@ -1192,8 +1238,9 @@ struct PlmEngine : PlmEngineBase {
     // after an evaluation: fx (slot 0), g.d, x.x, g.g (slots 1..3) in one round trip
     int eval_scalars(double* fx, double* gd, double* xx, double* gg)
     {
-        hipLaunchKernelGGL(vec_dot3_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dg, dd, dx, P, dVecPart);
+        hipLaunchKernelGGL(vec_dot3_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dg + vlo, dd + vlo, dx + vlo, vn, dVecPart);
         hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 3, ctx->dScal + 1);
+        DCA_TRY(reduce_scalars(0, 4));     // fx (local data term) and the three partial dot products
         DCA_TRY(read_scalars(4));
         *fx = ctx->hScal[0]; *gd = ctx->hScal[1]; *xx = ctx->hScal[2]; *gg = ctx->hScal[3];
         return DCA_OK;
@@ -1203,13 +1250,16 @@ struct PlmEngine : PlmEngineBase {
     {
         if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
         if (!lbfgs_alloc) {
-            DCA_TRY(dalloc(&dxp, P)); DCA_TRY(dalloc(&dgp, P)); DCA_TRY(dalloc(&dd, P));
-            for (int i = 0; i < 5; ++i) { DCA_TRY(dalloc(&dS[i], P)); DCA_TRY(dalloc(&dY[i], P)); }
+            DCA_TRY(dalloc(&dxp, P + kVecPad)); DCA_TRY(dalloc(&dgp, P + kVecPad)); DCA_TRY(dalloc(&dd, P + kVecPad));
+            for (int i = 0; i < 5; ++i) { DCA_TRY(dalloc(&dS[i], P + kVecPad)); DCA_TRY(dalloc(&dY[i], P + kVecPad)); }
+            HIP_TRY(hipMemsetAsync(dxp, 0, (P + kVecPad) * sizeof(T), ctx->stream));
+            HIP_TRY(hipMemsetAsync(dgp, 0, (P + kVecPad) * sizeof(T), ctx->stream));
+            HIP_TRY(hipMemsetAsync(dd, 0, (P + kVecPad) * sizeof(T), ctx->stream));
             lbfgs_alloc = true;
         }
         for (int i = 0; i < 5; ++i) {   // unused history slots take part in the Gram kernel as zeros
-            HIP_TRY(hipMemsetAsync(dS[i], 0, P * sizeof(T), ctx->stream));
-            HIP_TRY(hipMemsetAsync(dY[i], 0, P * sizeof(T), ctx->stream));
+            HIP_TRY(hipMemsetAsync(dS[i], 0, (P + kVecPad) * sizeof(T), ctx->stream));
+            HIP_TRY(hipMemsetAsync(dY[i], 0, (P + kVecPad) * sizeof(T), ctx->stream));
         }
         o = decltype(o)();
         o.max_iterations = max_iterations;
@@ -1255,6 +1305,7 @@ struct PlmEngine : PlmEngineBase {
                 (brackt && (stmax - stmin <= xtol * stmax)))
                 *stp = bx.st;
             v_step(dx, dxp, *stp, dd);
+            if ((*rc_hip = gather_vector(dx))) return 0;      // sharded vectors: every rank needs the whole x
             if ((*rc_hip = evaluate_async())) return 0;
             double dg_;
             if ((*rc_hip = eval_scalars(f, &dg_, xx, gg))) return 0;
@@ -1315,8 +1366,9 @@ struct PlmEngine : PlmEngineBase {
             if (o.max_iterations != 0 && o.max_iterations < o.k + 1) { o.status = LB_MAXIMUMITERATION; o.finished = true; break; }
 
             hipLaunchKernelGGL(vec_diff_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream,
-                               dS[o.end], dY[o.end], dx, dxp, dg, dgp, P, dVecPart);
+                               dS[o.end] + vlo, dY[o.end] + vlo, dx + vlo, dxp + vlo, dg + vlo, dgp + vlo, vn, dVecPart);
             hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 2, ctx->dScal + 1);
+            DCA_TRY(reduce_scalars(1, 2));
             DCA_TRY(read_scalars(3));
             const double ys = ctx->hScal[1], yy = ctx->hScal[2];
             o.ys[o.end] = ys;
@@ -1327,9 +1379,10 @@ struct PlmEngine : PlmEngineBase {
             {
                 ScopedKernelClock kc(ctx, "lbfgs_vec");
                 VecPtrs5 ptrs;
-                for (int i = 0; i < M; ++i) { ptrs.s[i] = dS[i]; ptrs.y[i] = dY[i]; }
-                hipLaunchKernelGGL(vec_gram_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, ptrs, dg, e, P, dVecPart);
+                for (int i = 0; i < M; ++i) { ptrs.s[i] = dS[i] + vlo; ptrs.y[i] = dY[i] + vlo; }
+                hipLaunchKernelGGL(vec_gram_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, ptrs, dg + vlo, e, vn, dVecPart);
                 hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 25, ctx->dScal + 1);
+                DCA_TRY(reduce_scalars(1, 25));
                 HIP_TRY(hipMemcpyAsync(ctx->hScal + 1, ctx->dScal + 1, 25 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                 HIP_TRY(hipStreamSynchronize(ctx->stream));
                 const double* G5 = ctx->hScal + 1;       // [kind*5 + k]
@@ -1363,7 +1416,7 @@ struct PlmEngine : PlmEngineBase {
                     cf.s[j] += o.alpha[j] - beta;
                     j = (j + 1) % M;
                 }
-                hipLaunchKernelGGL(vec_compose_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dd, dg, ptrs, cf, P);
+                hipLaunchKernelGGL(vec_compose_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dd + vlo, dg + vlo, ptrs, cf, vn);
                 // g.d for the next line search, from the same coefficients
                 double gd = cf.g * gg;
                 for (int k2 = 0; k2 < M; ++k2) gd += cf.s[k2] * Sg[k2] + cf.y[k2] * Yg[k2];

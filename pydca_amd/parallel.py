@@ -9,6 +9,12 @@ torch.distributed from the library's reduce hook.  The regulariser is added on r
 only.  Weights depend on the whole alignment, so they are computed once on the full MSA
 (it is tens of MB) and the shard's slice is handed to the shard context.
 
+On top of that the optimiser state can be sharded by parameter range (`TorchVectorComm` +
+`Context.plm_set_vector_sharding`): the evaluation then ends with a reduce-scatter of the gradients,
+a step with an all-gather of x, and the L-BFGS dot products are all-reduced as a few doubles --
+the same bytes on the wire as the all-reduce, but the vector work (Gram pass, direction, differences)
+is divided by the number of ranks.  `bench.py --gpus N` uses this mode.
+
 mfDCA shards the same way for its one N-dependent stage, the weighted pair counts: every rank
 counts its block (global weights), ONE all-reduce(sum) of the (L q)^2 raw counts and of Meff through
 the same hook protocol (`Context.mf_set_reduce_hook`), after which frequencies, correlation
@@ -46,7 +52,14 @@ def _hip_rt():
         _hip = C.CDLL("libamdhip64.so")
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _hip.hipMemcpy.restype = C.c_int
+        _hip.hipDeviceSynchronize.restype = C.c_int
     return _hip
+
+
+def _copies_done():
+    """Device-to-device hipMemcpy does not wait for the copy on the host side; the library's
+    stream is non-blocking and would not wait for it either, so the hooks finish with this."""
+    return _hip_rt().hipDeviceSynchronize()
 
 
 _D2D = 3  # hipMemcpyDeviceToDevice
@@ -90,9 +103,139 @@ class TorchAllReduceHook:
             return 1
         if hip.hipMemcpy(fx_dev, self.fbuf.data_ptr(), 8, _D2D) != 0:
             return 1
+        if _copies_done() != 0:
+            return 1
         self.calls += 1
         self.seconds += time.perf_counter() - t0
         return 0
+
+
+class TorchVectorComm:
+    """Comm hook for `Context.plm_set_vector_sharding` on torch.distributed (backend "nccl" = RCCL):
+    in-place all-reduce / reduce-scatter / all-gather on the library's device buffers, staged through
+    one torch tensor (device-to-device copies, negligible next to the collective)."""
+
+    def __init__(self, device, rank, world, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = rank, world
+        # gloo has no reduce-scatter: emulate both slice collectives with all-reduce (self-test of the
+        # multi-process path on a single GPU, see bench.py; the product path is RCCL)
+        self.only_all_reduce = dist.get_backend(group) != "nccl"
+        import os
+        self.trace = os.environ.get("DCA_COMM_TRACE") == "1"
+        self.device = torch.device("cuda", device)
+        self.buf = {}
+        self.calls = [0, 0, 0]
+        self.seconds = 0.0
+
+    def _tensor(self, count, dtype):
+        tdt = self.torch.float32 if dtype == 32 else self.torch.float64
+        t = self.buf.get(dtype)
+        if t is None or t.numel() < count:
+            t = self.torch.empty(count, dtype=tdt, device=self.device)
+            self.buf[dtype] = t
+        return t[:count]
+
+    def __call__(self, op, dev, count, dtype):
+        import time
+        t0 = time.perf_counter()
+        dist, hip = self.dist, _hip_rt()
+        esz = 4 if dtype == 32 else 8
+        if self.trace:
+            import sys
+            print("[comm rank %d] op %d count %d dtype %d" % (self.rank, op, count, dtype), file=sys.stderr, flush=True)
+        t = self._tensor(count, dtype)
+        if op == 0:                                         # all-reduce (scalars)
+            if hip.hipMemcpy(t.data_ptr(), dev, count * esz, _D2D) != 0:
+                return 1
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self.torch.cuda.synchronize(self.device)
+            if hip.hipMemcpy(dev, t.data_ptr(), count * esz, _D2D) != 0:
+                return 1
+        else:
+            ps = count // self.world
+            lo = self.rank * ps
+            mine = t[lo:lo + ps]
+            if self.only_all_reduce:
+                if hip.hipMemcpy(t.data_ptr(), dev, count * esz, _D2D) != 0:
+                    return 1
+                if op == 2:                                 # all-gather as a sum of vectors that are zero off-slice
+                    t[:lo].zero_()
+                    t[lo + ps:].zero_()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                self.torch.cuda.synchronize(self.device)
+                if hip.hipMemcpy(dev, t.data_ptr(), count * esz, _D2D) != 0:
+                    return 1
+            elif op == 1:                                   # reduce-scatter: whole vector in, own slice out
+                if hip.hipMemcpy(t.data_ptr(), dev, count * esz, _D2D) != 0:
+                    return 1
+                dist.reduce_scatter_tensor(mine, t, op=dist.ReduceOp.SUM, group=self.group)
+                self.torch.cuda.synchronize(self.device)
+                if hip.hipMemcpy(dev + lo * esz, mine.data_ptr(), ps * esz, _D2D) != 0:
+                    return 1
+            else:                                           # all-gather: own slice in, whole vector out
+                if hip.hipMemcpy(mine.data_ptr(), dev + lo * esz, ps * esz, _D2D) != 0:
+                    return 1
+                dist.all_gather_into_tensor(t, mine, group=self.group)
+                self.torch.cuda.synchronize(self.device)
+                if hip.hipMemcpy(dev, t.data_ptr(), count * esz, _D2D) != 0:
+                    return 1
+        if _copies_done() != 0:
+            return 1
+        self.calls[op] += 1
+        self.seconds += time.perf_counter() - t0
+        return 0
+
+
+class ThreadComm:
+    """The same three collectives between `world` THREADS of one process (one context each, any
+    devices), staged through host memory -- the stand-in for RCCL that lets the sharded optimiser be
+    exercised on a single GPU (tests/test_api_gpu.py).  One instance is shared; every thread calls
+    `hook(rank)` to get its comm function."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.full = None
+
+    def hook(self, rank):
+        hip = _hip_rt()
+
+        def comm(op, dev, count, dtype):
+            dt = np.float32 if dtype == 32 else np.float64
+            esz = np.dtype(dt).itemsize
+            ps = count // self.world if op else 0
+            lo = rank * ps
+            if op in (0, 1):
+                part = np.empty(count, dtype=dt)
+                if hip.hipMemcpy(part.ctypes.data, dev, count * esz, 2) != 0:
+                    return 1
+                self.slots[rank] = part
+                self.barrier.wait()
+                total = self.slots[0].copy()
+                for r in range(1, self.world):              # rank order: every thread gets the same bits
+                    total += self.slots[r]
+                self.barrier.wait()
+                if op == 0:
+                    return hip.hipMemcpy(dev, total.ctypes.data, count * esz, 1)
+                mine = np.ascontiguousarray(total[lo:lo + ps])
+                return hip.hipMemcpy(dev + lo * esz, mine.ctypes.data, ps * esz, 1)
+            mine = np.empty(ps, dtype=dt)
+            if hip.hipMemcpy(mine.ctypes.data, dev + lo * esz, ps * esz, 2) != 0:
+                return 1
+            if rank == 0:
+                self.full = np.empty(count, dtype=dt)
+            self.barrier.wait()
+            self.full[lo:lo + ps] = mine
+            self.barrier.wait()
+            rc = hip.hipMemcpy(dev, self.full.ctypes.data, count * esz, 1)
+            self.barrier.wait()
+            return rc
+        return comm
 
 
 def make_sharded_plm_context(lib_mod, X, q, weights, lambda_h, lambda_J, rank, world, device,

@@ -207,6 +207,21 @@ def test_reduce_hook_through_torch_distributed():
         st = ctx.plm_lbfgs_iterate(5)
         assert st.iterations == 5 and hook.calls == 1 + st.evaluations
         ctx.close()
+        # sharded optimiser vectors through torch.distributed (1-rank group: the collectives are
+        # identities, but reduce_scatter_tensor / all_gather_into_tensor / all_reduce all run on RCCL)
+        ctx = _lib.Context(0, _lib.DCA_F32)
+        ctx.set_msa(X, q)
+        ctx.compute_weights(0.8, _lib.DCA_F32)
+        ctx.plm_configure(1.0, 5.0)
+        ctx.plm_init_x()
+        vcomm = parallel.TorchVectorComm(0, 0, 1)
+        ctx.plm_set_vector_sharding(0, 1, vcomm)
+        assert ctx.plm_gradient() == fx0 and np.array_equal(ctx.plm_get_g(np.float32), g0)
+        ctx.plm_lbfgs_begin(5)
+        st2 = ctx.plm_lbfgs_iterate(5)
+        assert (st2.status, st2.iterations, st2.evaluations, st2.fx) == (st.status, st.iterations, st.evaluations, st.fx)
+        assert vcomm.calls[1] == 1 + st2.evaluations and vcomm.calls[2] >= st2.evaluations and vcomm.calls[0] > st2.iterations
+        ctx.close()
         # the same hook on the mfDCA pair counts (float64 buffer of (L q)^2 counts + Meff)
         M = golden("mf_toy_protein")
         mctx = _lib.Context(0, _lib.DCA_F64)
@@ -336,3 +351,88 @@ def test_refseq_backmapping_through_classes_and_cli(tmp_path):
     rows = [ln.split() for ln in open(out).read().splitlines() if not ln.startswith("#")]
     assert len(rows) == 71 * 70 // 2
     assert (int(rows[0][0]) - 1, int(rows[0][1]) - 1) == mapped[0][0]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimiser_vectors_with_thread_comm(oracle_plm, world):
+    """Sequence sharding + sharded L-BFGS vectors (dca_plm_set_vector_sharding) exercised on one GPU:
+    `world` threads, one context each, collectives through parallel.ThreadComm.  float64: the run must
+    follow the unsharded optimiser (same status / iterations / evaluations, fx and x to rounding),
+    every rank must end with the same full x, and a standalone gradient must come back complete."""
+    import threading
+    from pydca_amd import _lib, parallel
+    G = golden("plm_rf71")
+    X, q, L = G["X"], int(G["q"]), int(G["L"])
+    w = oracle_plm.weights(X, 0.8, np.float64)
+    x0 = oracle_plm.init_x(X, w, q).astype(np.float64)
+    iters = 12
+    full = _lib.Context(0, _lib.DCA_F64)
+    full.set_msa(X, q)
+    full.set_weights(w)
+    full.plm_configure(1.0, 20.0)
+    full.plm_set_x(x0)
+    fx_ref = full.plm_gradient()
+    g_ref = full.plm_get_g(np.float64)
+    full.plm_lbfgs_begin(iters)
+    st_ref = full.plm_lbfgs_iterate(iters)
+    x_ref = full.plm_get_x(np.float64)
+    full.close()
+
+    comm = parallel.ThreadComm(world)
+    out = [None] * world
+
+    def run(rank):
+        try:
+            ctx = parallel.make_sharded_plm_context(_lib, X, q, w, 1.0, 20.0, rank, world, 0, precision=64)
+            ctx.plm_set_vector_sharding(rank, world, comm.hook(rank))
+            ctx.plm_set_x(x0)
+            fx = ctx.plm_gradient()
+            g = ctx.plm_get_g(np.float64)
+            ctx.plm_lbfgs_begin(iters)
+            st = ctx.plm_lbfgs_iterate(iters)
+            out[rank] = (fx, g, st.status, st.iterations, st.evaluations, st.fx, ctx.plm_get_x(np.float64), ctx.plm_scores(True))
+            ctx.close()
+        except Exception as exc:      # pragma: no cover
+            out[rank] = exc
+            comm.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for r in range(world):
+        assert not isinstance(out[r], Exception) and out[r] is not None, out[r]
+    for r in range(world):
+        fx, g, status, its, evals, fx_end, x_end, scores = out[r]
+        assert abs(fx - fx_ref) <= 1e-11 * abs(fx_ref) and rel_err(g, g_ref) < 1e-11
+        assert (status, its, evals) == (st_ref.status, st_ref.iterations, st_ref.evaluations)
+        assert abs(fx_end - st_ref.fx) <= 1e-9 * abs(st_ref.fx)
+        assert rel_err(x_end, x_ref) < 1e-7
+        assert np.array_equal(x_end, out[0][6]) and np.array_equal(scores, out[0][7])
+
+
+@pytest.mark.parametrize("mode", ["vectors", "allreduce"])
+def test_bench_two_process_selftest(mode):
+    """bench.py under torch.distributed.run with two ranks on ONE GPU (DCA_BENCH_SELFTEST=1: gloo
+    instead of RCCL, which refuses two ranks per device).  Exercises the whole multi-process path --
+    sharding, hooks, barriers, max-over-ranks timing -- and checks the optimiser follows the
+    single-process run."""
+    import json
+    import subprocess
+    env = dict(os.environ, DCA_BENCH_SELFTEST="1", MASTER_ADDR="127.0.0.1")
+    if mode == "allreduce":
+        env["DCA_BENCH_ALLREDUCE"] = "1"
+    port = "29621" if mode == "vectors" else "29622"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "C"]
+    two = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d2 = json.loads(two.stdout.strip().splitlines()[-1])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--workload", "C",
+                          "--no-cpu-baseline", "--no-mfdca"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert d2["n_gpus"] == 2 and d2["steps"] == d1["steps"] == 4 and d2["lbfgs_status"] == d1["lbfgs_status"]
+    assert abs(d2["fx"] - d1["fx"]) <= 1e-6 * abs(d1["fx"])
+    assert d2["scaling"] == "strong" and "roofline" in d1
