@@ -5,13 +5,14 @@
 //
 // One evaluation =
 //   expand : packed x -> symmetric table  W[(j,b)][(i,a)]              (HBM-bound, P floats in)
-//   logits : S[n][(i,a)] = sum_j W[(j,x_nj)][(i,a)]                     (LDS gather, lanes = sequences)
+//   logits : S[n][(i,a)] = sum_j W[(j,x_nj)][(i,a)]                     (register gather, source row selected by M0)
 //   softmax: per site, scan over n with the reference's carried-over probabilities,
 //            R[n][(i,a)] = w_n (p_ni(a) - delta(a,x_ni)),  fx -= w_n log p_ni(x_ni)   (lanes = sites)
-//   scatter: G[(j,b)][(i,a)] = sum_n [x_nj = b] R[n][(i,a)]             (LDS gather over per-chunk sorted lists)
+//   scatter: G[(j,b)][(i,a)] = sum_n [x_nj = b] R[n][(i,a)]             (LDS gather, destination sum selected by M0)
 //   fold   : g = 2 lambda x + G + G^T in the packed layout, regulariser value
-// The two N*L^2*q stages (logits, scatter) are bound by LDS read bandwidth
-// (256 B/clk/CU); see DESIGN.md for the roofline model.
+// The two N*L^2*q stages (logits, scatter) are gathers with a wave-uniform row index: lanes are
+// columns and the VGPR index mode picks the register (generated inner blocks, tools/gen_plm_asm.py).
+// They are bound on chip (fp32 adds + one SALU per 512-byte row piece); see DESIGN.md section 4.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -21,13 +22,9 @@
 namespace {
 
 template <typename T> struct V16;
-template <> struct V16<float> { using type = float4; static constexpr int n = 4; };
-template <> struct V16<double> { using type = double2; static constexpr int n = 2; };
+template <> struct V16<float> { using type = float4; };
+template <> struct V16<double> { using type = double2; };
 
-__device__ __forceinline__ void vadd(float* z, const float4& v) { z[0] += v.x; z[1] += v.y; z[2] += v.z; z[3] += v.w; }
-__device__ __forceinline__ void vadd(double* z, const double2& v) { z[0] += v.x; z[1] += v.y; }
-__device__ __forceinline__ float4 vpack(const float* z) { return make_float4(z[0], z[1], z[2], z[3]); }
-__device__ __forceinline__ double2 vpack(const double* z) { return make_double2(z[0], z[1]); }
 
 __device__ __forceinline__ float t_exp(float v) { return expf(v); }
 __device__ __forceinline__ double t_exp(double v) { return exp(v); }
@@ -859,10 +856,6 @@ int mt_update(LsPoint& best, LsPoint& other, double& t, double ft, double dt, do
     t = newt;
     return 0;
 }
-
-template <typename T> struct Geo;
-template <> struct Geo<float> { static constexpr int CT = 64; };
-template <> struct Geo<double> { static constexpr int CT = 32; };
 
 template <typename T>
 struct PlmEngine : PlmEngineBase {
