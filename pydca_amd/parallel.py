@@ -130,12 +130,12 @@ class TorchVectorComm:
         self.calls = [0, 0, 0]
         self.seconds = 0.0
 
-    def _tensor(self, count, dtype):
+    def _tensor(self, count, dtype, slot="full"):
         tdt = self.torch.float32 if dtype == 32 else self.torch.float64
-        t = self.buf.get(dtype)
+        t = self.buf.get((slot, dtype))
         if t is None or t.numel() < count:
             t = self.torch.empty(count, dtype=tdt, device=self.device)
-            self.buf[dtype] = t
+            self.buf[(slot, dtype)] = t
         return t[:count]
 
     def __call__(self, op, dev, count, dtype):
@@ -157,7 +157,6 @@ class TorchVectorComm:
         else:
             ps = count // self.world
             lo = self.rank * ps
-            mine = t[lo:lo + ps]
             if self.only_all_reduce:
                 if hip.hipMemcpy(t.data_ptr(), dev, count * esz, _D2D) != 0:
                     return 1
@@ -168,20 +167,23 @@ class TorchVectorComm:
                 self.torch.cuda.synchronize(self.device)
                 if hip.hipMemcpy(dev, t.data_ptr(), count * esz, _D2D) != 0:
                     return 1
-            elif op == 1:                                   # reduce-scatter: whole vector in, own slice out
-                if hip.hipMemcpy(t.data_ptr(), dev, count * esz, _D2D) != 0:
-                    return 1
-                dist.reduce_scatter_tensor(mine, t, op=dist.ReduceOp.SUM, group=self.group)
-                self.torch.cuda.synchronize(self.device)
-                if hip.hipMemcpy(dev + lo * esz, mine.data_ptr(), ps * esz, _D2D) != 0:
-                    return 1
-            else:                                           # all-gather: own slice in, whole vector out
-                if hip.hipMemcpy(mine.data_ptr(), dev + lo * esz, ps * esz, _D2D) != 0:
-                    return 1
-                dist.all_gather_into_tensor(t, mine, group=self.group)
-                self.torch.cuda.synchronize(self.device)
-                if hip.hipMemcpy(dev, t.data_ptr(), count * esz, _D2D) != 0:
-                    return 1
+            else:
+                # separate slice buffer: no aliasing between the input and output of the collective
+                mine = self._tensor(ps, dtype, slot="slice")
+                if op == 1:                                 # reduce-scatter: whole vector in, own slice out
+                    if hip.hipMemcpy(t.data_ptr(), dev, count * esz, _D2D) != 0:
+                        return 1
+                    dist.reduce_scatter_tensor(mine, t, op=dist.ReduceOp.SUM, group=self.group)
+                    self.torch.cuda.synchronize(self.device)
+                    if hip.hipMemcpy(dev + lo * esz, mine.data_ptr(), ps * esz, _D2D) != 0:
+                        return 1
+                else:                                       # all-gather: own slice in, whole vector out
+                    if hip.hipMemcpy(mine.data_ptr(), dev + lo * esz, ps * esz, _D2D) != 0:
+                        return 1
+                    dist.all_gather_into_tensor(t, mine, group=self.group)
+                    self.torch.cuda.synchronize(self.device)
+                    if hip.hipMemcpy(dev, t.data_ptr(), count * esz, _D2D) != 0:
+                        return 1
         if _copies_done() != 0:
             return 1
         self.calls[op] += 1
