@@ -129,6 +129,7 @@ def main():
     counts = full.weight_counts()
     w32 = (np.float32(1.0) / counts.astype(np.float32)).astype(np.float32)
     t_weights_ms, _ = full.kernel_time("weights")
+    hook = None
     if world == 1:
         ctx = full
         ctx.plm_configure(lh, lJ, _lib.CARRY_CHUNKED)
@@ -140,7 +141,10 @@ def main():
         ctx.plm_set_x(parallel.initial_x(X, w32, q, np.float32))
         # sequences AND optimiser vectors sharded: reduce-scatter(g) + all-gather(x) per evaluation
         # (DCA_BENCH_ALLREDUCE=1 selects the plain all-reduce of g with replicated vectors instead)
-        if os.environ.get("DCA_BENCH_ALLREDUCE") == "1":
+        # Small parameter vectors (config E: 1.1 MB) are latency-bound: one all-reduce per evaluation beats
+        # four hook calls per iteration, so vector sharding is used from 16 MB of parameters on.
+        small = ctx.num_params() * (4 if args.precision == 32 else 8) < (16 << 20)
+        if os.environ.get("DCA_BENCH_ALLREDUCE") == "1" or (small and os.environ.get("DCA_BENCH_VECTORS") != "1"):
             hook = parallel.TorchAllReduceHook(local_rank)
             ctx.plm_set_reduce_hook(hook)
         else:
@@ -215,7 +219,8 @@ def main():
         "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
         "config": {"workload": "plmdca compute_fn protein, synthetic MSA L=%d N=%d q=%d, lambda_h=%g lambda_J=%g seqid=0.8, "
                                "reference carry-over semantics (chunked scan)" % (L, N, q, lh, lJ),
-                   "config_id": args.workload, "num_params": P, "parallelism": "sequences sharded x%d, reduce-scatter(g) + all-gather(x) over RCCL, L-BFGS vectors sharded x%d" % (world, world)},
+                   "config_id": args.workload, "num_params": P, "parallelism": ("1 GPU" if world == 1 else ("sequences sharded x%d, all-reduce(g) over RCCL" % world) if isinstance(hook, parallel.TorchAllReduceHook)
+                                   else "sequences sharded x%d, reduce-scatter(g) + all-gather(x) over RCCL, L-BFGS vectors sharded x%d" % (world, world))},
         "evaluations_per_iteration": evals / max(steps_done, 1), "evaluations_per_s": evals / dt,
         "lbfgs_status": st.status, "fx": st.fx,
         "setup_s": {"generate_msa": t_gen, "weights_kernel": t_weights_ms / 1e3, "total_setup": t_setup},

@@ -1358,27 +1358,29 @@ struct PlmEngine : PlmEngineBase {
             if (o.gnorm / xn <= 1e-3) { o.status = 0; o.finished = true; break; }
             if (o.max_iterations != 0 && o.max_iterations < o.k + 1) { o.status = LB_MAXIMUMITERATION; o.finished = true; break; }
 
-            hipLaunchKernelGGL(vec_diff_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream,
-                               dS[o.end] + vlo, dY[o.end] + vlo, dx + vlo, dxp + vlo, dg + vlo, dgp + vlo, vn, dVecPart);
-            hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 2, ctx->dScal + 1);
-            DCA_TRY(reduce_scalars(1, 2));
-            DCA_TRY(read_scalars(3));
-            const double ys = ctx->hScal[1], yy = ctx->hScal[2];
-            o.ys[o.end] = ys;
-            const int bound = (M <= o.k) ? M : o.k;
+            // s, y of the accepted step and every dot product the direction needs, in two kernels and ONE
+            // round trip for the scalars: dScal[1..2] = y.s, y.y;  dScal[3..27] = the 25 Gram entries
             const int e = o.end;              // slot of the newest pair
+            VecPtrs5 ptrs;
+            for (int i = 0; i < M; ++i) { ptrs.s[i] = dS[i] + vlo; ptrs.y[i] = dY[i] + vlo; }
+            {
+                ScopedKernelClock kc(ctx, "lbfgs_vec");
+                hipLaunchKernelGGL(vec_diff_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream,
+                                   dS[e] + vlo, dY[e] + vlo, dx + vlo, dxp + vlo, dg + vlo, dgp + vlo, vn, dVecPart);
+                hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 2, ctx->dScal + 1);
+                hipLaunchKernelGGL(vec_gram_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, ptrs, dg + vlo, e, vn, dVecPart);
+                hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 25, ctx->dScal + 3);
+            }
+            DCA_TRY(reduce_scalars(1, 27));
+            DCA_TRY(read_scalars(28));
+            const double ys = ctx->hScal[1], yy = ctx->hScal[2];
+            o.ys[e] = ys;
+            const int bound = (M <= o.k) ? M : o.k;
             ++o.k;
             o.end = (o.end + 1) % M;
             {
                 ScopedKernelClock kc(ctx, "lbfgs_vec");
-                VecPtrs5 ptrs;
-                for (int i = 0; i < M; ++i) { ptrs.s[i] = dS[i] + vlo; ptrs.y[i] = dY[i] + vlo; }
-                hipLaunchKernelGGL(vec_gram_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, ptrs, dg + vlo, e, vn, dVecPart);
-                hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 25, ctx->dScal + 1);
-                DCA_TRY(reduce_scalars(1, 25));
-                HIP_TRY(hipMemcpyAsync(ctx->hScal + 1, ctx->dScal + 1, 25 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-                HIP_TRY(hipStreamSynchronize(ctx->stream));
-                const double* G5 = ctx->hScal + 1;       // [kind*5 + k]
+                const double* G5 = ctx->hScal + 3;       // [kind*5 + k]
                 double Sg[M], Yg[M];
                 for (int k2 = 0; k2 < M; ++k2) {
                     Sg[k2] = G5[k2]; Yg[k2] = G5[5 + k2];
