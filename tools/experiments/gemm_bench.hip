@@ -1,0 +1,40 @@
+// Stand-alone timing of the f64 NT GEMM of csrc/cholinv.hip (the file is included, so the kernel
+// under test is the product kernel): plain and triangular-operand products at the sizes of the inverse.
+// hipcc --offload-arch=gfx950 -O3 -I../../include -I../../pydca_amd/csrc -o gemm_bench gemm_bench.hip
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include "../../pydca_amd/csrc/cholinv.hip"
+void dca_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); }
+void dca_flush_clocks(dca_ctx*) {}
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+int main(int argc, char** argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 5056;
+    dca_ctx ctx;
+    CHECK(hipStreamCreate(&ctx.stream));
+    double *A, *B, *C;
+    CHECK(hipMalloc(&A, (size_t)n * n * 8)); CHECK(hipMalloc(&B, (size_t)n * n * 8)); CHECK(hipMalloc(&C, (size_t)n * n * 8));
+    CHECK(hipMemset(A, 0, (size_t)n * n * 8)); CHECK(hipMemset(B, 0, (size_t)n * n * 8));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    struct Case { const char* name; int maskA, maskB, lower; double flops; } cases[] = {
+        {"plain NT", MASK_NONE, MASK_NONE, 0, 2.0 * n * (double)n * n},
+        {"B lower-triangular (TRSM-like)", MASK_NONE, MASK_LOWER, 0, 1.0 * n * (double)n * n},
+        {"SYRK lower tiles", MASK_NONE, MASK_NONE, 1, 1.0 * n * (double)n * n},
+        {"X^T X (both upper, lower tiles)", MASK_UPPER, MASK_UPPER, 1, 2.0 / 6.0 * n * (double)n * n * 1.0},
+    };
+    for (auto& c : cases) {
+        float best = 1e9;
+        for (int rep = 0; rep < 3; ++rep) {
+            CHECK(hipEventRecord(e0, ctx.stream));
+            launch_gemm(&ctx, GemmArgs{A, n, c.maskA, B, n, c.maskB, C, n, nullptr, 0, n, n, n, 1.0, 0.0, c.lower});
+            CHECK(hipEventRecord(e1, ctx.stream));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        printf("n=%d %-34s %.3f ms  %.1f TFLOP/s (useful flops)\n", n, c.name, best, c.flops / (best * 1e-3) / 1e12);
+    }
+    fflush(stdout);
+    return 0;
+}
