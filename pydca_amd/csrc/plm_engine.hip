@@ -78,7 +78,7 @@ __global__ void plm_expand_kernel(const T* __restrict__ x, T* __restrict__ W, co
 constexpr int kLogitSeqPerWave = 32;
 constexpr int kLogitWavesC = 16;
 constexpr int kLogitSeqPerWG = kLogitSeqPerWave * kLogitWavesC;
-__host__ __device__ constexpr int logits_jt(int q) { return q == 21 ? 6 : 24; }   // sites per LDS tile (<= 128 rows)
+__host__ __device__ constexpr int logits_jt(int q) { return q == 21 ? 6 : 25; }   // sites per LDS tile (<= 128 rows)
 
 // XL[j][n] = 0x2000 | 2 * x_nj (M0 image: src1-relative + register-pair offset); state 0 past N and for
 // the padding sites j >= L of the last tile (their rows of W are zero)
@@ -447,6 +447,18 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
         scatter_store_site<Q>(acc0, reinterpret_cast<unsigned char*>(Gslab + (size_t)j0 * Q * Cs + (size_t)ct * CW) + lane * 8, rowStrideBytes);
     if (j0 + 1 < L)
         scatter_store_site<Q>(acc1, reinterpret_cast<unsigned char*>(Gslab + (size_t)(j0 + 1) * Q * Cs + (size_t)ct * CW) + lane * 8, rowStrideBytes);
+}
+
+// G[0] += G[1] + ... + G[nsplit-1], fixed order (deterministic).  Used when there are many slabs
+// (deep, narrow alignments); with a few slabs the fold kernels add them on the fly.
+template <typename T>
+__global__ void plm_sum_slabs_kernel(T* __restrict__ G, size_t slabElems, int nsplit)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < slabElems; i += (size_t)gridDim.x * blockDim.x) {
+        T a = G[i];
+        for (int sidx = 1; sidx < nsplit; ++sidx) a += G[(size_t)sidx * slabElems + i];
+        G[i] = a;
+    }
 }
 
 // ------------------------------------------------------------------ fold
@@ -1130,11 +1142,16 @@ struct PlmEngine : PlmEngineBase {
         }
         {
             ScopedKernelClock kc(ctx, "plm_fold");
+            int foldSlabs = scatSplit;
+            if (scatSplit > 4) {     // many slabs: one streaming pass is cheaper than strided reads in the fold
+                hipLaunchKernelGGL(plm_sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, st, dG, (size_t)Grows * Cs, scatSplit);
+                foldSlabs = 1;
+            }
             const size_t lds = ((size_t)q * q * sizeof(T) + 15) / 16 * 16 + 256 * sizeof(double);
             hipLaunchKernelGGL(plm_fold_pairs_kernel<T>, dim3((unsigned)npairs), dim3(256), lds, st, dx, dG, dg, dPairs,
-                               dRegPart, L, q, Cs, (T)lambda_J, add_reg, (size_t)Grows * Cs, scatSplit);
+                               dRegPart, L, q, Cs, (T)lambda_J, add_reg, (size_t)Grows * Cs, foldSlabs);
             hipLaunchKernelGGL(plm_fold_fields_kernel<T>, dim3(ceil_div(Lq, 256)), dim3(256), 0, st, dx, dG, dg,
-                               dRegPart + npairs, Lq, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, scatSplit);
+                               dRegPart + npairs, Lq, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, foldSlabs);
         }
         // fx = regulariser + data term  -> ctx->dScal[0]
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, st, dRegPart, nRegPart, ctx->dScal, 0);

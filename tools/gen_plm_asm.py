@@ -131,7 +131,7 @@ NBSEQ = 32
 
 
 def logits_jt(q):
-    return {21: 6, 5: 24}[q]
+    return {21: 6, 5: 25}[q]
 
 
 def logits_body(q, f64):
