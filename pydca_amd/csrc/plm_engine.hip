@@ -305,7 +305,6 @@ void plm_softmax_kernel(T* __restrict__ SR, const T* __restrict__ x, const uint8
 constexpr int kNC = 128;           // sequences per scatter tile
 constexpr int kRowBytes = 512;     // bytes of one staged row (64 lanes x 8 B)
 constexpr int kScatWavesC = 16;
-constexpr int kScatJG = 32;        // sites per workgroup (2 per wave)
 
 // XT2[j][k] = 0x9000 | 2 * x_{halo+k, j}: the M0 image that selects the accumulator of the state
 // (index-enable bits for src0 and dst + register-pair offset); state 0 past N (zero rows); row stride NT
@@ -360,17 +359,19 @@ __device__ __forceinline__ void scatter_store_site(const SiteAcc<Q>& acc, unsign
     }
 }
 
-template <typename T, int Q>
+template <typename T, int Q, int JW>
 __global__ __launch_bounds__(kScatWavesC * 64)
 void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT2, const unsigned char* __restrict__ zeros,
                         T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int NT, int numColTiles,
                         int numJG, int chunksPerSplit, size_t slabElems, int ablate)
 {
     constexpr int WAVES = kScatWavesC;
+    constexpr int JG = WAVES * JW;                     // sites per workgroup
     constexpr int CW = kRowBytes / (int)sizeof(T);     // columns per strip
     constexpr int DMA_PER_WAVE = kNC / 2 / WAVES;      // LDS-DMA instructions per wave and tile
     constexpr int TILE = kNC * kRowBytes;
     static_assert(kNC % (2 * WAVES) == 0, "tile rows must divide over the waves");
+    static_assert((Q == 21 && JW == 2) || (Q == 5 && (JW == 2 || JW == 5)), "no generated gather block for this shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
 
     // workgroup id -> (XCD, column strip, site group): the numJG site groups of a strip run on the
@@ -384,22 +385,23 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j0 = jg * kScatJG + wave * 2;
-    const int jc0 = min(j0, L - 1), jc1 = min(j0 + 1, L - 1);
+    const int j0 = jg * JG + wave * JW;
 
     // blockIdx.y splits the tile range; every split writes its own slab of G (summed by
     // the fold kernels in a fixed order), so small L*q shapes still fill the chip.
     const int cBegin = blockIdx.y * chunksPerSplit;
     const int cEnd = min(numChunks, cBegin + chunksPerSplit);
 
-    SiteAcc<Q> acc0, acc1;
-    acc0.zero();
-    acc1.zero();
+    SiteAcc<Q> acc[JW];
+    const uint32_t* xs[JW];
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+        acc[jj].zero();
+        xs[jj] = reinterpret_cast<const uint32_t*>(XT2 + (size_t)min(j0 + jj, L - 1) * NT);
+    }
 
     const unsigned char* Rstrip = reinterpret_cast<const unsigned char*>(R + (size_t)ct * CW) + (lane & 31) * 16;
     const size_t rowStrideBytes = (size_t)Cs * sizeof(T);
-    const uint32_t* x0 = reinterpret_cast<const uint32_t*>(XT2 + (size_t)jc0 * NT);
-    const uint32_t* x1 = reinterpret_cast<const uint32_t*>(XT2 + (size_t)jc1 * NT);
 
     // rows past N come from a zero row in global memory
     auto stage = [&](int c, int buf) {
@@ -415,41 +417,56 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
         }
     };
 
-    uint32_t st0 = 0, st1 = 0;
+    uint32_t st[JW], stn[JW];
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) st[jj] = 0;
     if (cBegin < cEnd) {
         stage(cBegin, 0);
-        st0 = x0[cBegin * (kNC / 2) + lane];
-        st1 = x1[cBegin * (kNC / 2) + lane];
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) st[jj] = xs[jj][cBegin * (kNC / 2) + lane];
     }
     const uint32_t ldsBase = (uint32_t)(uintptr_t)dca_smem + lane * 8;
     for (int c = cBegin; c < cEnd; ++c) {
         const int buf = (c - cBegin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile c have landed
         __syncthreads();                                    // ... everyone's; and tile c-1 is no longer read
-        uint32_t st0n = 0, st1n = 0;
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) stn[jj] = 0;
         if (c + 1 < cEnd) {
             stage(c + 1, buf ^ 1);
-            st0n = x0[(c + 1) * (kNC / 2) + lane];
-            st1n = x1[(c + 1) * (kNC / 2) + lane];
+#pragma unroll
+            for (int jj = 0; jj < JW; ++jj) stn[jj] = xs[jj][(c + 1) * (kNC / 2) + lane];
         }
         const uint32_t vbase = ldsBase + buf * TILE;
-        if (ablate & 2) { st0 = st0n; st1 = st1n; continue; }   // timing knob (DCA_SCATTER_ABLATE): staging only
-        if constexpr (Q == 21 && sizeof(T) == 4) DCA_GATHER_Q21_F32(vbase, st0, st1, acc0.a, acc0.b, acc0.c, acc1.a, acc1.b, acc1.c);
-        else if constexpr (Q == 21) DCA_GATHER_Q21_F64(vbase, st0, st1, acc0.a, acc0.b, acc0.c, acc1.a, acc1.b, acc1.c);
-        else if constexpr (sizeof(T) == 4) DCA_GATHER_Q5_F32(vbase, st0, st1, acc0.a, acc0.b, acc1.a, acc1.b);
-        else DCA_GATHER_Q5_F64(vbase, st0, st1, acc0.a, acc0.b, acc1.a, acc1.b);
-        st0 = st0n;
-        st1 = st1n;
+        if (!(ablate & 2)) {     // timing knob (DCA_SCATTER_ABLATE): 2 = staging only
+            if constexpr (Q == 21 && sizeof(T) == 4)
+                DCA_GATHER_Q21_F32(vbase, st[0], st[1], acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+            else if constexpr (Q == 21)
+                DCA_GATHER_Q21_F64(vbase, st[0], st[1], acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+            else if constexpr (JW == 2 && sizeof(T) == 4)
+                DCA_GATHER_Q5_F32(vbase, st[0], st[1], acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+            else if constexpr (JW == 2)
+                DCA_GATHER_Q5_F64(vbase, st[0], st[1], acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+            else if constexpr (sizeof(T) == 4)
+                DCA_GATHER_Q5_F32_JW5(vbase, st[0], st[1], st[2], st[3], st[4], acc[0].a, acc[0].b, acc[1].a, acc[1].b,
+                                      acc[2].a, acc[2].b, acc[3].a, acc[3].b, acc[4].a, acc[4].b);
+            else
+                DCA_GATHER_Q5_F64_JW5(vbase, st[0], st[1], st[2], st[3], st[4], acc[0].a, acc[0].b, acc[1].a, acc[1].b,
+                                      acc[2].a, acc[2].b, acc[3].a, acc[3].b, acc[4].a, acc[4].b);
+        }
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) st[jj] = stn[jj];
     }
 
     T* const Gslab = G + (size_t)blockIdx.y * slabElems;
-    if (j0 < L)
-        scatter_store_site<Q>(acc0, reinterpret_cast<unsigned char*>(Gslab + (size_t)j0 * Q * Cs + (size_t)ct * CW) + lane * 8, rowStrideBytes);
-    if (j0 + 1 < L)
-        scatter_store_site<Q>(acc1, reinterpret_cast<unsigned char*>(Gslab + (size_t)(j0 + 1) * Q * Cs + (size_t)ct * CW) + lane * 8, rowStrideBytes);
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj)
+        if (j0 + jj < L)
+            scatter_store_site<Q>(acc[jj], reinterpret_cast<unsigned char*>(Gslab + (size_t)(j0 + jj) * Q * Cs + (size_t)ct * CW) + lane * 8,
+                                  rowStrideBytes);
 }
 
-// G[0] += G[1] + ... + G[nsplit-1], fixed order (deterministic).  Used when there are many slabs
+// G[0] += G[1] + ... + G[nsplit-1], fixed order (deterministic).  Used when there are more than two slabs
 // (deep, narrow alignments); with a few slabs the fold kernels add them on the fly.
 template <typename T>
 __global__ void plm_sum_slabs_kernel(T* __restrict__ G, size_t slabElems, int nsplit)
@@ -882,7 +899,7 @@ struct PlmEngine : PlmEngineBase {
     bool configured = false;
     int numScanChunks = 0, numScatChunks = 0;
     static constexpr int kScatWaves = 16;
-    int scatSplit = 1, scatChunksPerSplit = 0;
+    int scatSplit = 1, scatChunksPerSplit = 0, scatJW = 2;
 
     T *dx = nullptr, *dg = nullptr, *dxp = nullptr, *dgp = nullptr, *dd = nullptr;
     T* dS[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -958,7 +975,16 @@ struct PlmEngine : PlmEngineBase {
         Cs = (int)round_up(Lq, 128);
         const int JT = jt();
         Wrows = ceil_div(L, JT) * JT * q + 128;     // + over-read margin of the last LDS-DMA tile
-        const int JG = kScatJG;
+        // sites per wave of the scatter kernel: 2, or 5 for q = 5 when that covers L with fewer
+        // instruction slots (a 5-site block costs ~0.8 of a 2-site block per site; L = 150: 2 x 80 sites
+        // against 5 x 32).  DCA_SCATTER_JW overrides (tuning knob).
+        scatJW = 2;
+        if (q == 5) {
+            const double cost2 = (double)ceil_div(L, 32) * 32, cost5 = 0.8 * ceil_div(L, 80) * 80;
+            if (cost5 < cost2) scatJW = 5;
+            if (const char* e = getenv("DCA_SCATTER_JW")) { const int v = atoi(e); if (v == 2 || v == 5) scatJW = v; }
+        }
+        const int JG = kScatWavesC * scatJW;
         Grows = ceil_div(L, JG) * JG * q;
         Npad = (int)round_up(N, kLogitSeqPerWG);
 
@@ -966,10 +992,21 @@ struct PlmEngine : PlmEngineBase {
         DCA_TRY(dalloc(&dWt, (size_t)Wrows * Cs));
         DCA_TRY(dalloc(&dSR, (size_t)N * Cs));
         {
-            // split the tile range until the scatter grid has ~2048 workgroups (one per CU at a time)
+            // Split of the tile range over blockIdx.y.  Aim at ~2048 workgroups (8 rounds of one workgroup
+            // per CU) but keep >= 12 tiles per workgroup (prologue + epilogue cost about two tiles), then
+            // take the split within 25 % below that which wastes least in the last, partly filled round:
+            // rounds x (tiles per workgroup + 2).  Measured optima (tools/time_eval.py, DCA_SCATTER_SPLIT):
+            // D 2, D/8 2, C 5-6, E 64-68.
             const int cw = kRowBytes / (int)sizeof(T);
             const int wgs = ceil_div(Cs, cw) * ceil_div(L, JG);
-            scatSplit = std::max(1, std::min(numScatChunks, ceil_div(2048, wgs)));
+            const int s0 = std::max(1, std::min({numScatChunks, ceil_div(2048, wgs), std::max(1, numScatChunks / 12)}));
+            double bestCost = 1e300;
+            scatSplit = s0;
+            for (int sp = std::max(1, s0 * 3 / 4); sp <= s0; ++sp) {
+                const double cost = std::ceil((double)wgs * sp / 256.0) * (ceil_div(numScatChunks, sp) + 2.0);
+                if (cost <= bestCost) { bestCost = cost; scatSplit = sp; }
+            }
+            if (const char* e = getenv("DCA_SCATTER_SPLIT")) scatSplit = std::max(1, std::min(numScatChunks, atoi(e)));   // tuning knob
             scatChunksPerSplit = ceil_div(numScatChunks, scatSplit);
             scatSplit = ceil_div(numScatChunks, scatChunksPerSplit);
         }
@@ -1130,20 +1167,28 @@ struct PlmEngine : PlmEngineBase {
         {
             constexpr int CW = kRowBytes / (int)sizeof(T);
             const int numCT = ceil_div(Cs, CW);
-            const int numJG = ceil_div(L, kScatJG);
+            const int numJG = ceil_div(L, kScatWavesC * scatJW);
             const int blocks = kNumXcd * ceil_div(numCT, kNumXcd) * numJG;
             const size_t lds = (size_t)2 * kNC * kRowBytes;
-            auto kern = plm_scatter_kernel<T, Q>;
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            ScopedKernelClock kc(ctx, "plm_scatter");
-            hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(kScatWavesC * 64), lds, st, dSR, dXT2, dZeros, dG, N, L, Cs, halo,
-                               numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs,
-                               getenv("DCA_SCATTER_ABLATE") ? atoi(getenv("DCA_SCATTER_ABLATE")) : 0);
+            const int ablate = getenv("DCA_SCATTER_ABLATE") ? atoi(getenv("DCA_SCATTER_ABLATE")) : 0;
+            auto launch = [&](auto kern) -> int {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ScopedKernelClock kc(ctx, "plm_scatter");
+                hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(kScatWavesC * 64), lds, st, dSR, dXT2, dZeros, dG, N, L, Cs, halo,
+                                   numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs, ablate);
+                return DCA_OK;
+            };
+            if constexpr (Q == 5) {
+                if (scatJW == 5) { DCA_TRY(launch(plm_scatter_kernel<T, 5, 5>)); }
+                else { DCA_TRY(launch(plm_scatter_kernel<T, 5, 2>)); }
+            } else {
+                DCA_TRY(launch(plm_scatter_kernel<T, Q, 2>));
+            }
         }
         {
             ScopedKernelClock kc(ctx, "plm_fold");
             int foldSlabs = scatSplit;
-            if (scatSplit > 4) {     // many slabs: one streaming pass is cheaper than strided reads in the fold
+            if (scatSplit > 2) {     // more than two slabs: one streaming pass is cheaper than strided reads in the fold
                 hipLaunchKernelGGL(plm_sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, st, dG, (size_t)Grows * Cs, scatSplit);
                 foldSlabs = 1;
             }

@@ -25,7 +25,9 @@ first version used s_bfe_u32 + s_set_gpr_idx_idx per (row, site) and measured SA
 Register plan (physical, fixed; the kernel is built for 128 VGPRs = 4 waves per SIMD):
     q=21: data ring v[28:43], site 0 v[44:85], site 1 v[86:127]
     q=5 : data ring v[92:107], site 0 v[108:117], site 1 v[118:127]
-    state words s[40:71], temporaries s72 (index), s73 (saved M0)
+    q=5, five sites per wave (_JW5 macros): data ring v[62:77], sites v[78:127], 8 state words per
+          site at a time (16 rows per refill) so that 40 SGPRs hold them
+    state words s[40:71] (s[40:79] with five sites), temporaries behind them: s72 / s80 (zero), s73 / s81 (saved M0)
 Accumulator tuples are passed as "+{v[a:b]}" operands so the compiler knows they live there.
 
 Checked on MI355X with tools/experiments/gpridx_bench.hip: bit-exact against sequential CPU
@@ -42,17 +44,27 @@ def tuples(q):
     return {21: [32, 8, 2], 5: [8, 2]}[q]
 
 
-def plan(q):
-    top = 128
-    a1 = top - 2 * q
-    a0 = a1 - 2 * q
-    d0 = a0 - 2 * DEPTH
-    return d0, a0, a1
+def plan(q, jw):
+    """-> (first data-ring register, [first accumulator register of every site])"""
+    acc = [128 - 2 * q * (jw - jj) for jj in range(jw)]
+    return acc[0] - 2 * DEPTH, acc
 
 
-def body(q, f64):
-    d0, a0, a1 = plan(q)
-    acc = [a0, a1]
+def group_words(jw):
+    """state words per site held in SGPRs at a time (two rows per word): 32 SGPRs for two sites,
+    40 for five."""
+    return 16 if jw <= 2 else 8
+
+
+def temp_base(jw):
+    """first of the two temporary SGPRs (zero / index, saved M0): behind the state words"""
+    return max(T0, S0 + group_words(jw) * jw)
+
+
+def body(q, f64, jw=JW):
+    d0, acc = plan(q, jw)
+    gw = group_words(jw)
+    T0 = temp_base(jw)
     add = "v_add_f64" if f64 else "v_pk_add_f32"
     o = ["s_mov_b32 s%d, m0" % (T0 + 1)]
 
@@ -62,21 +74,21 @@ def body(q, f64):
 
     for r in range(DEPTH):
         o.append(ds(r))
-    quarter = ROWS // 4
+    group = 2 * gw                     # rows per SGPR refill
     for r in range(ROWS):
-        if r % quarter == 0:
+        if r % group == 0:
             if r:
                 o.append("s_set_gpr_idx_off")
-            for jj in range(JW):
-                for w in range(16):
-                    o.append("v_readlane_b32 s%d, %%[st%d], %d" % (S0 + jj * 16 + w, jj, (r // quarter) * 16 + w))
+            for jj in range(jw):
+                for w in range(gw):
+                    o.append("v_readlane_b32 s%d, %%[st%d], %d" % (S0 + jj * gw + w, jj, (r // group) * gw + w))
             o.append("s_nop 3")
             o.append("s_mov_b32 s%d, 0" % T0)
             o.append("s_set_gpr_idx_on s%d, 0x9" % T0)
         o.append("s_waitcnt lgkmcnt(%d)" % min(DEPTH - 1, ROWS - 1 - r))
         k = r % DEPTH
-        for jj in range(JW):
-            w = S0 + jj * 16 + (r % quarter) // 2
+        for jj in range(jw):
+            w = S0 + jj * gw + (r % group) // 2
             if r % 2 == 0:
                 o.append("s_pack_ll_b32_b16 m0, s%d, 0" % w)
             else:
@@ -90,23 +102,26 @@ def body(q, f64):
     return o
 
 
-def macro(q, f64):
-    d0, a0, a1 = plan(q)
+def macro(q, f64, jw=JW):
+    d0, acc = plan(q, jw)
+    gw = group_words(jw)
+    T0 = temp_base(jw)
     names = "ABC"[:len(tuples(q))]
-    params = ["VBASE", "ST0", "ST1"] + ["%s%d" % (n, jj) for jj in range(JW) for n in names]
-    lines = ["#define DCA_GATHER_Q%d_%s(%s) \\" % (q, "F64" if f64 else "F32", ", ".join(params)), "    asm volatile( \\"]
-    for ln in body(q, f64):
+    params = ["VBASE"] + ["ST%d" % jj for jj in range(jw)] + ["%s%d" % (n, jj) for jj in range(jw) for n in names]
+    suffix = "" if jw == JW else "_JW%d" % jw
+    lines = ["#define DCA_GATHER_Q%d_%s%s(%s) \\" % (q, "F64" if f64 else "F32", suffix, ", ".join(params)), "    asm volatile( \\"]
+    for ln in body(q, f64, jw):
         lines.append('        "%s\\n" \\' % ln)
     outs = []
-    for jj, base in enumerate((a0, a1)):
+    for jj, base in enumerate(acc):
         r = base
         for n, sz in zip(names, tuples(q)):
             outs.append('"+{v[%d:%d]}"(%s%d)' % (r, r + sz - 1, n, jj))
             r += sz
     lines.append("        : %s \\" % ", ".join(outs))
-    lines.append('        : [vbase] "v"(VBASE), [st0] "v"(ST0), [st1] "v"(ST1) \\')
+    lines.append("        : [vbase] \"v\"(VBASE), %s \\" % ", ".join('[st%d] "v"(ST%d)' % (jj, jj) for jj in range(jw)))
     clob = ['"memory"'] + ['"v%d"' % (d0 + i) for i in range(2 * DEPTH)] + \
-           ['"s%d"' % (S0 + i) for i in range(16 * JW)] + ['"s%d"' % T0, '"s%d"' % (T0 + 1)]
+           ['"s%d"' % (S0 + i) for i in range(gw * jw)] + ['"s%d"' % T0, '"s%d"' % (T0 + 1)]
     lines.append("        : %s)" % ", ".join(clob))
     return "\n".join(lines)
 
@@ -199,6 +214,9 @@ def main():
         for f64 in (0, 1):
             out.append(macro(q, f64))
             out.append("")
+    for f64 in (0, 1):                 # q = 5: five sites per wave (80 per workgroup) when L makes that the better fit
+        out.append(macro(5, f64, 5))
+        out.append("")
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pydca_amd", "csrc", "scatter_gather_asm.inc")
     with open(path, "w") as fh:
         fh.write("\n".join(out))
