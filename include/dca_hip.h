@@ -172,6 +172,15 @@ int dca_plm_di_scores(dca_ctx* ctx, const double* reg_fi, int apc, double* score
  * (plmdca.py:320-342).  Feeds PlmDCA.compute_params (plmdca.py:345-434). */
 int dca_plm_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift, double* out);
 
+/* ------------------------------------------------------------------ DI on caller-provided arrays
+ * The module-level functions of the reference: compute_two_site_model_fields + compute_direct_info
+ * (meanfield_dca/msa_numerics.py:378-533: layout 1 = couplings as the n x n matrix, n = L(q-1);
+ * plmdca/msa_numerics.py:156-311: layout 2 = gap-stripped blocks, pair order, (q-1)^2 each).
+ * All arrays are HOST doubles; reg_fi is L x q; fields_out (optional) receives [pairs][2][q],
+ * di_out (optional) [pairs].  No alignment needs to be set on the context. */
+int dca_di_from_arrays(dca_ctx* ctx, const double* couplings, int layout, const double* reg_fi, int L, int q,
+                       double* fields_out, double* di_out);
+
 /* ------------------------------------------------------------------ ranking
  * Pair indices of the most recent score vector computed on this context (dca_plm_scores,
  * dca_plm_di_scores, dca_mf_scores, dca_mf_di_scores, dca_mf_run) in descending score order,

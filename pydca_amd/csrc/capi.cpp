@@ -325,6 +325,13 @@ int dca_plm_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift
     if (npairs < 0 || (npairs > 0 && (!pairs || !out))) return DCA_ERR_ARG;
     return ctx->plm->pair_couplings(pairs, npairs, shift, out);
 }
+int dca_di_from_arrays(dca_ctx* ctx, const double* couplings, int layout, const double* reg_fi, int L, int q,
+                       double* fields_out, double* di_out)
+{
+    CHECK_CTX(ctx);
+    if (!couplings || !reg_fi || (layout != 1 && layout != 2) || (!fields_out && !di_out)) return DCA_ERR_ARG;
+    return dca_di_from_arrays_impl(ctx, couplings, layout, reg_fi, L, q, fields_out, di_out);
+}
 int dca_mf_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user)
 {
     CHECK_CTX(ctx);

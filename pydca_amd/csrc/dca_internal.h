@@ -144,6 +144,9 @@ int dca_di_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, const 
 int dca_pair_blocks(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L, int q, int ld, const int* pairs, int npairs,
                     int shift, double* out /* host */);
 
+int dca_di_from_arrays_impl(dca_ctx* ctx, const double* couplings, int layout, const double* reg_fi, int L, int q,
+                            double* fields_out, double* di_out);
+
 // ---- mf engine
 struct MfEngine;
 MfEngine* dca_make_mf_engine(dca_ctx* ctx);

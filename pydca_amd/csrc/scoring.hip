@@ -124,7 +124,7 @@ __global__ void apc_apply_kernel(double* __restrict__ fn, const double* __restri
 template <typename S>
 __global__ __launch_bounds__(64)
 void di_kernel(const S* __restrict__ src, int kind, const double* __restrict__ regfi, int L, int q, int ld,
-               double* __restrict__ di)
+               double* __restrict__ di, double* __restrict__ fields)
 {
     __shared__ double E[21 * 21];
     __shared__ double fi[21], fj[21], hi[21], hj[21], ni[21], nj[21];
@@ -148,7 +148,8 @@ void di_kernel(const S* __restrict__ src, int kind, const double* __restrict__ r
         double v = 0.0;
         if (a < qm && b < qm) {
             if (kind == 0) v = (double)src[(size_t)L * q + p * (size_t)q * q + (size_t)a * q + b];
-            else v = (double)src[(size_t)(i * qm + a) * ld + (size_t)j * qm + b];
+            else if (kind == 1) v = (double)src[(size_t)(i * qm + a) * ld + (size_t)j * qm + b];
+            else v = (double)src[p * (size_t)qm * qm + (size_t)a * qm + b];      // gap-stripped blocks, pair order
         }
         E[e] = exp(v);
     }
@@ -179,6 +180,10 @@ void di_kernel(const S* __restrict__ src, int kind, const double* __restrict__ r
         }
         __syncthreads();
         if (!(change > 1.0e-4)) break;
+    }
+    if (fields && t < q) {     // two-site model fields, layout [pair][0 = site i, 1 = site j][q]
+        fields[(p * 2 + 0) * q + t] = hi[t];
+        fields[(p * 2 + 1) * q + t] = hj[t];
     }
     // direct probability and DI
     double zpart = 0.0;
@@ -272,9 +277,9 @@ int dca_di_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, const 
     const size_t npairs = (size_t)L * (L - 1) / 2;
     ScopedKernelClock kc(ctx, "scores");
     if (dtype == DCA_F32)
-        hipLaunchKernelGGL(di_kernel<float>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const float*>(src), src_kind, dRegFi, L, q, ld, dOut);
+        hipLaunchKernelGGL(di_kernel<float>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const float*>(src), src_kind, dRegFi, L, q, ld, dOut, static_cast<double*>(nullptr));
     else
-        hipLaunchKernelGGL(di_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const double*>(src), src_kind, dRegFi, L, q, ld, dOut);
+        hipLaunchKernelGGL(di_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const double*>(src), src_kind, dRegFi, L, q, ld, dOut, static_cast<double*>(nullptr));
     if (apc) {
         double* dAv = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dAv), (size_t)(L + 1) * sizeof(double)));
@@ -313,5 +318,33 @@ int dca_pair_blocks(dca_ctx* ctx, const void* src, int src_kind, int dtype, int 
     if (e == hipSuccess) e = hipMemcpy(out, dOut, (size_t)npairs * per * sizeof(double), hipMemcpyDeviceToHost);
     hipFree(dPairs); hipFree(dOut);
     if (e != hipSuccess) { dca_set_error("pair blocks: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
+    return DCA_OK;
+}
+
+// DI and two-site model fields from caller-provided HOST arrays (the module-level functions of the
+// reference: compute_two_site_model_fields / compute_direct_info, meanfield_dca/msa_numerics.py:378-533
+// with the n x n couplings matrix, plmdca/msa_numerics.py:156-311 with the gap-stripped 1-D array).
+int dca_di_from_arrays_impl(dca_ctx* ctx, const double* couplings, int layout, const double* reg_fi, int L, int q,
+                            double* fields_out, double* di_out)
+{
+    if (q > 21 || q < 2 || L < 2) { dca_set_error("dca_di_from_arrays: bad L / q"); return DCA_ERR_ARG; }
+    const int qm = q - 1, n = L * qm;
+    const size_t npairs = (size_t)L * (L - 1) / 2;
+    const size_t nc = layout == 1 ? (size_t)n * n : npairs * qm * qm;
+    double *dC = nullptr, *dF = nullptr, *dDi = nullptr, *dFields = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dC), nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dF), (size_t)L * q * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dDi), npairs * sizeof(double));
+    if (e == hipSuccess && fields_out) e = hipMalloc(reinterpret_cast<void**>(&dFields), npairs * 2 * q * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(dC, couplings, nc * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dF, reg_fi, (size_t)L * q * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(di_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, dC, layout == 1 ? 1 : 2, dF, L, q, n, dDi, dFields);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess && di_out) e = hipMemcpy(di_out, dDi, npairs * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && fields_out) e = hipMemcpy(fields_out, dFields, npairs * 2 * q * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dC); hipFree(dF); hipFree(dDi); hipFree(dFields);
+    if (e != hipSuccess) { dca_set_error("dca_di_from_arrays: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     return DCA_OK;
 }

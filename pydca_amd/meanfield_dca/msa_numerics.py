@@ -96,3 +96,26 @@ def compute_couplings(corr_mat=None):
     finally:
         ctx.close()
     return -1.0 * inv
+
+
+def compute_two_site_model_fields(couplings=None, reg_fi=None, seqs_len=None, num_site_states=None):
+    """msa_numerics.py:378-470 -> float64[pairs, 2, q]: the two-site model fields h_i, h_j of every
+    pair (fixed point to 1e-4), one workgroup per pair on the device."""
+    n = int(seqs_len) * (int(num_site_states) - 1)
+    if np.asarray(couplings).shape != (n, n):
+        raise ValueError('couplings must be the L(q-1) x L(q-1) matrix')
+    ctx = _lib.Context(_DEVICE, _lib.DCA_F64)
+    try:
+        return ctx.di_from_arrays(couplings, 1, reg_fi, int(seqs_len), int(num_site_states), want_fields=True, want_di=False)[0]
+    finally:
+        ctx.close()
+
+
+def compute_direct_info(couplings=None, fields_ij=None, reg_fi=None, seqs_len=None, num_site_states=None):
+    """msa_numerics.py:473-533 -> float64[pairs].  fields_ij is accepted for signature compatibility;
+    the kernel recomputes the fields (they are a function of couplings and reg_fi)."""
+    ctx = _lib.Context(_DEVICE, _lib.DCA_F64)
+    try:
+        return ctx.di_from_arrays(couplings, 1, reg_fi, int(seqs_len), int(num_site_states))[1]
+    finally:
+        ctx.close()

@@ -1,0 +1,49 @@
+"""Drop-in for the direct-information part of pydca/plmdca/msa_numerics.py (:156-311): same function
+names and keyword arguments; couplings are the gap-stripped 1-D array of
+PlmDCA.get_couplings_no_gap_state (pair order, (q-1)^2 values per pair).  The frequency functions of
+that module are the ones of the mean-field module and are re-exported from there."""
+import numpy as np
+
+from .. import _lib
+from ..meanfield_dca.msa_numerics import (compute_sequences_weight as _weights, compute_single_site_freqs,  # noqa: F401
+                                          get_reg_single_site_freqs)
+
+_DEVICE = 0
+
+
+def set_device(device):
+    global _DEVICE
+    _DEVICE = int(device)
+
+
+def compute_sequences_weight(alignment_data=None, sequence_identity=None):
+    """plmdca/msa_numerics.py:13-49 (keyword `sequence_identity`, float64 comparison)."""
+    return _weights(alignment_data=alignment_data, seqid=sequence_identity)
+
+
+def _check(couplings, seqs_len, num_site_states):
+    L, qm1 = int(seqs_len), int(num_site_states) - 1
+    c = np.asarray(couplings, dtype=np.float64).reshape(-1)
+    if c.size != L * (L - 1) // 2 * qm1 * qm1:
+        raise ValueError('couplings must hold (q-1)^2 values for each of the L(L-1)/2 pairs')
+    return c
+
+
+def compute_two_site_model_fields(couplings=None, reg_fi=None, seqs_len=None, num_site_states=None):
+    """plmdca/msa_numerics.py:156-246 -> float64[pairs, 2, q]."""
+    c = _check(couplings, seqs_len, num_site_states)
+    ctx = _lib.Context(_DEVICE, _lib.DCA_F64)
+    try:
+        return ctx.di_from_arrays(c, 2, reg_fi, int(seqs_len), int(num_site_states), want_fields=True, want_di=False)[0]
+    finally:
+        ctx.close()
+
+
+def compute_direct_info(couplings=None, fields_ij=None, reg_fi=None, seqs_len=None, num_site_states=None):
+    """plmdca/msa_numerics.py:249-311 -> float64[pairs] (fields_ij accepted, recomputed on the device)."""
+    c = _check(couplings, seqs_len, num_site_states)
+    ctx = _lib.Context(_DEVICE, _lib.DCA_F64)
+    try:
+        return ctx.di_from_arrays(c, 2, reg_fi, int(seqs_len), int(num_site_states))[1]
+    finally:
+        ctx.close()

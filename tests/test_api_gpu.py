@@ -436,3 +436,26 @@ def test_bench_two_process_selftest(mode):
     assert d2["n_gpus"] == 2 and d2["steps"] == d1["steps"] == 4 and d2["lbfgs_status"] == d1["lbfgs_status"]
     assert abs(d2["fx"] - d1["fx"]) <= 1e-6 * abs(d1["fx"])
     assert d2["scaling"] == "strong" and "roofline" in d1
+
+
+def test_msa_numerics_direct_information_functions():
+    """Module-level DI functions of both msa_numerics mirrors against the
+    reference's own output (goldens): two-site model fields and DI from caller-provided arrays."""
+    from pydca_amd.meanfield_dca import msa_numerics as mf_num
+    from pydca_amd.plmdca import msa_numerics as plm_num
+    D, M, P = golden("di_toy_protein"), golden("mf_toy_protein"), golden("plm_toy_protein")
+    L, q = int(D["L"]), int(D["q"])
+    fields = mf_num.compute_two_site_model_fields(couplings=M["couplings"], reg_fi=M["reg_fi"], seqs_len=L, num_site_states=q)
+    assert fields.shape == (L * (L - 1) // 2, 2, q) and np.allclose(fields.sum(axis=2), 1.0, atol=1e-12)
+    di = mf_num.compute_direct_info(couplings=M["couplings"], fields_ij=fields, reg_fi=M["reg_fi"], seqs_len=L, num_site_states=q)
+    np.testing.assert_allclose(di, D["mf_di"], rtol=1e-9, atol=1e-14)
+    x = P["run_a"]
+    blocks = x[L * q:].reshape(L * (L - 1) // 2, q, q)[:, :q - 1, :q - 1].reshape(-1)
+    f2 = plm_num.compute_two_site_model_fields(couplings=blocks, reg_fi=D["plm_reg_fi"], seqs_len=L, num_site_states=q)
+    np.testing.assert_allclose(f2, D["plm_fields"], rtol=1e-10, atol=1e-13)
+    d2 = plm_num.compute_direct_info(couplings=blocks, fields_ij=f2, reg_fi=D["plm_reg_fi"], seqs_len=L, num_site_states=q)
+    np.testing.assert_allclose(d2, D["plm_di"], rtol=1e-9, atol=1e-14)
+    X1 = M["X"]
+    np.testing.assert_array_equal(plm_num.compute_sequences_weight(alignment_data=X1, sequence_identity=0.8), M["w"])
+    with pytest.raises(ValueError):
+        plm_num.compute_direct_info(couplings=blocks[:-1], reg_fi=D["plm_reg_fi"], seqs_len=L, num_site_states=q)
