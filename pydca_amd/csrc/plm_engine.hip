@@ -955,7 +955,10 @@ struct PlmEngine : PlmEngineBase {
         if (halo_ < 0 || halo_ >= N) { dca_set_error("halo out of range"); return DCA_ERR_ARG; }
         if (L > 65535) { dca_set_error("L too large"); return DCA_ERR_ARG; }
         lambda_h = lh; lambda_J = lJ; carry_mode = cmode; halo = halo_; add_reg = add_reg_;
-        chunk = chunk_ > 0 ? chunk_ : 128;
+        // scan chunk: 256 sequences (15 % warm-up rows instead of 31 %) when that still leaves at least one
+        // chunk-wave per SIMD and the rows are long (q = 21; config D: 1.20 -> 0.99 ms; with q = 5 the chain
+        // latency dominates and 128 stays faster), else 128
+        chunk = chunk_ > 0 ? chunk_ : ((q >= 16 && (long long)ceil_div(N - halo_, 256) * ceil_div(L, 64) >= 1024) ? 256 : 128);
         warm = warm_ > 0 ? warm_ : 40;
         if (carry_mode == DCA_CARRY_SERIAL) { chunk = N - halo; warm = halo; }
         if (carry_mode == DCA_CARRY_EXACT) warm = 0;

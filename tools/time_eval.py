@@ -23,7 +23,7 @@ X = dedup(generate(a.L, a.N, a.q, a.seed))
 ctx = _lib.Context(0, a.precision)
 ctx.set_msa(X, a.q)
 ctx.compute_weights(0.8, _lib.DCA_F32)
-ctx.plm_configure(1.0, 50.0)
+ctx.plm_configure(1.0, 50.0, chunk=int(os.environ.get('DCA_CHUNK', '0')))
 ctx.plm_init_x()
 if a.iters:
     ctx.plm_lbfgs_begin(1000)
