@@ -298,7 +298,8 @@ void plm_softmax_kernel(T* __restrict__ SR, const T* __restrict__ x, const uint8
 // barrier per tile.  The q accumulators of a site sit in fixed VGPRs and the one that a row adds
 // to is selected with the gfx9 VGPR index mode (s_set_gpr_idx_on; M0 = 0x9000 | 2 x state), so the rows
 // are visited in sequence order with immediate LDS offsets: one ds_read_b64 per row shared by the
-// wave's two sites and one packed add per (row, site).  The inner block is generated assembly
+// wave's two sites and one packed add per (row, site).  The M0 images of the states (XT2) reach SGPRs
+// through scalar loads, one s_load_dwordx16 per site and quarter tile, issued a quarter ahead.  The inner block is generated assembly
 // (tools/gen_scatter_asm.py -> scatter_gather_asm.inc): 84 accumulator + 16 data-ring registers
 // are pinned, which is why the kernel is built for 128 VGPRs (16 waves = one workgroup per CU).
 // The sums of a (site, state) run over n in ascending order: deterministic.
@@ -371,7 +372,7 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
     constexpr int DMA_PER_WAVE = kNC / 2 / WAVES;      // LDS-DMA instructions per wave and tile
     constexpr int TILE = kNC * kRowBytes;
     static_assert(kNC % (2 * WAVES) == 0, "tile rows must divide over the waves");
-    static_assert((Q == 21 && JW == 2) || (Q == 5 && (JW == 2 || JW == 5)), "no generated gather block for this shape");
+    static_assert(JW == 2 && (Q == 21 || Q == 5), "no generated gather block for this shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
 
     // workgroup id -> (XCD, column strip, site group): the numJG site groups of a strip run on the
@@ -417,45 +418,27 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
         }
     };
 
-    uint32_t st[JW], stn[JW];
-#pragma unroll
-    for (int jj = 0; jj < JW; ++jj) st[jj] = 0;
-    if (cBegin < cEnd) {
-        stage(cBegin, 0);
-#pragma unroll
-        for (int jj = 0; jj < JW; ++jj) st[jj] = xs[jj][cBegin * (kNC / 2) + lane];
-    }
+    if (cBegin < cEnd) stage(cBegin, 0);
     const uint32_t ldsBase = (uint32_t)(uintptr_t)dca_smem + lane * 8;
     for (int c = cBegin; c < cEnd; ++c) {
         const int buf = (c - cBegin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile c have landed
         __syncthreads();                                    // ... everyone's; and tile c-1 is no longer read
-#pragma unroll
-        for (int jj = 0; jj < JW; ++jj) stn[jj] = 0;
-        if (c + 1 < cEnd) {
-            stage(c + 1, buf ^ 1);
-#pragma unroll
-            for (int jj = 0; jj < JW; ++jj) stn[jj] = xs[jj][(c + 1) * (kNC / 2) + lane];
-        }
+        if (c + 1 < cEnd) stage(c + 1, buf ^ 1);
         const uint32_t vbase = ldsBase + buf * TILE;
         if (!(ablate & 2)) {     // timing knob (DCA_SCATTER_ABLATE): 2 = staging only
+            // two sites per wave: the state words come through scalar loads inside the block
+            const uint32_t* sp0 = xs[0] + c * (kNC / 2);
+            const uint32_t* sp1 = xs[1] + c * (kNC / 2);
             if constexpr (Q == 21 && sizeof(T) == 4)
-                DCA_GATHER_Q21_F32(vbase, st[0], st[1], acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+                DCA_GATHER_Q21_F32_SMEM(vbase, sp0, sp1, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
             else if constexpr (Q == 21)
-                DCA_GATHER_Q21_F64(vbase, st[0], st[1], acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
-            else if constexpr (JW == 2 && sizeof(T) == 4)
-                DCA_GATHER_Q5_F32(vbase, st[0], st[1], acc[0].a, acc[0].b, acc[1].a, acc[1].b);
-            else if constexpr (JW == 2)
-                DCA_GATHER_Q5_F64(vbase, st[0], st[1], acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+                DCA_GATHER_Q21_F64_SMEM(vbase, sp0, sp1, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
             else if constexpr (sizeof(T) == 4)
-                DCA_GATHER_Q5_F32_JW5(vbase, st[0], st[1], st[2], st[3], st[4], acc[0].a, acc[0].b, acc[1].a, acc[1].b,
-                                      acc[2].a, acc[2].b, acc[3].a, acc[3].b, acc[4].a, acc[4].b);
+                DCA_GATHER_Q5_F32_SMEM(vbase, sp0, sp1, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
             else
-                DCA_GATHER_Q5_F64_JW5(vbase, st[0], st[1], st[2], st[3], st[4], acc[0].a, acc[0].b, acc[1].a, acc[1].b,
-                                      acc[2].a, acc[2].b, acc[3].a, acc[3].b, acc[4].a, acc[4].b);
+                DCA_GATHER_Q5_F64_SMEM(vbase, sp0, sp1, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
         }
-#pragma unroll
-        for (int jj = 0; jj < JW; ++jj) st[jj] = stn[jj];
     }
 
     T* const Gslab = G + (size_t)blockIdx.y * slabElems;
@@ -978,15 +961,7 @@ struct PlmEngine : PlmEngineBase {
         Cs = (int)round_up(Lq, 128);
         const int JT = jt();
         Wrows = ceil_div(L, JT) * JT * q + 128;     // + over-read margin of the last LDS-DMA tile
-        // sites per wave of the scatter kernel: 2, or 5 for q = 5 when that covers L with fewer
-        // instruction slots (a 5-site block costs ~0.8 of a 2-site block per site; L = 150: 2 x 80 sites
-        // against 5 x 32).  DCA_SCATTER_JW overrides (tuning knob).
-        scatJW = 2;
-        if (q == 5) {
-            const double cost2 = (double)ceil_div(L, 32) * 32, cost5 = 0.8 * ceil_div(L, 80) * 80;
-            if (cost5 < cost2) scatJW = 5;
-            if (const char* e = getenv("DCA_SCATTER_JW")) { const int v = atoi(e); if (v == 2 || v == 5) scatJW = v; }
-        }
+        scatJW = 2;     // sites per wave of the scatter kernel
         const int JG = kScatWavesC * scatJW;
         Grows = ceil_div(L, JG) * JG * q;
         Npad = (int)round_up(N, kLogitSeqPerWG);
@@ -1181,12 +1156,7 @@ struct PlmEngine : PlmEngineBase {
                                    numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs, ablate);
                 return DCA_OK;
             };
-            if constexpr (Q == 5) {
-                if (scatJW == 5) { DCA_TRY(launch(plm_scatter_kernel<T, 5, 5>)); }
-                else { DCA_TRY(launch(plm_scatter_kernel<T, 5, 2>)); }
-            } else {
-                DCA_TRY(launch(plm_scatter_kernel<T, Q, 2>));
-            }
+            DCA_TRY(launch(plm_scatter_kernel<T, Q, 2>));
         }
         {
             ScopedKernelClock kc(ctx, "plm_fold");

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(1024)
 void bench_kernel(const float* __restrict__ tile, const uint16_t* __restrict__ states, float* __restrict__ out, int iters)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int t = tid; t < ROWS * ROWB / 4; t += WAVES * 64) reinterpret_cast<float*>(smem)[t] = tile[t];
     __syncthreads();
     v32f a0, a1; v8f b0, b1; v2f c0, c1;
@@ -29,7 +29,14 @@ void bench_kernel(const float* __restrict__ tile, const uint16_t* __restrict__ s
     const uint32_t vbase = (uint32_t)(uintptr_t)smem + lane * 8;
     const uint32_t* sp = reinterpret_cast<const uint32_t*>(states) + (size_t)(blockIdx.x * WAVES + wave) * 2 * 64;
     const uint32_t st0 = sp[lane], st1 = sp[64 + lane];
+#ifdef USE_SMEM
+    const uint32_t* sp0 = sp;
+    const uint32_t* sp1 = sp + 64;
+    for (int it = 0; it < iters; ++it) GATHER_BLOCK_SMEM(vbase, sp0, sp1, a0, b0, c0, a1, b1, c1);
+    (void)st0; (void)st1;
+#else
     for (int it = 0; it < iters; ++it) GATHER_BLOCK(vbase, st0, st1, a0, b0, c0, a1, b1, c1);
+#endif
     float s = 0;
     for (int i = 0; i < 32; ++i) s += a0[i] + a1[i];
     for (int i = 0; i < 8; ++i) s += b0[i] + b1[i];

@@ -61,6 +61,82 @@ def temp_base(jw):
     return max(T0, S0 + group_words(jw) * jw)
 
 
+SET_A, SET_B = 36, 68          # two sets of 2 x 16 state words (scalar-load variant, two sites per wave)
+
+
+def body_smem(q, f64):
+    """Two sites per wave, state words through scalar loads.  Moving the words to SGPRs with v_readlane
+    costs 0.5 VALU instruction per (row, site) and the VALU is the busiest unit of this block; an
+    s_load_dwordx16 per site and quarter tile costs none.  Quarter k uses SGPR set k % 2; the loads of
+    quarter k+1 are issued at the start of quarter k and the quarter boundary waits lgkmcnt(0) (scalar
+    loads return out of order, so this is the only safe wait; it also drains the eight LDS reads in
+    flight -- a bubble of one LDS latency per 32 rows).  While a scalar load is in flight the per-row
+    `s_waitcnt lgkmcnt(7)` over-counts by up to two, which only makes it wait longer.  Measured in
+    isolation (tools/experiments/gen_variants.py smem): 1.70 clk per (row, site) per CU against 2.15
+    for the v_readlane form.  The saved M0 lives in vcc_lo."""
+    d0, acc = plan(q, 2)
+    add = "v_add_f64" if f64 else "v_pk_add_f32"
+    sets = (SET_A, SET_B)
+    o = ["s_mov_b32 vcc_lo, m0"]
+
+    def ds(r):
+        k = r % DEPTH
+        return "ds_read_b64 v[%d:%d], %%[vbase] offset:%d" % (d0 + 2 * k, d0 + 2 * k + 1, r * ROWBYTES)
+
+    def sload(qk, base):
+        return ["s_load_dwordx16 s[%d:%d], %%[sp%d], 0x%x" % (base + 16 * jj, base + 16 * jj + 15, jj, qk * 64) for jj in range(2)]
+
+    o += sload(0, sets[0])
+    for r in range(DEPTH):
+        o.append(ds(r))
+    quarter = ROWS // 4
+    for r in range(ROWS):
+        if r % quarter == 0:
+            qk = r // quarter
+            if r:
+                o.append("s_set_gpr_idx_off")
+            o.append("s_waitcnt lgkmcnt(0)")
+            if qk + 1 < 4:
+                o += sload(qk + 1, sets[(qk + 1) % 2])
+            o.append("s_set_gpr_idx_on s%d, 0x9" % sets[qk % 2])       # index bits are rewritten before every use
+        o.append("s_waitcnt lgkmcnt(%d)" % min(DEPTH - 1, ROWS - 1 - r))
+        k = r % DEPTH
+        cur = sets[(r // quarter) % 2]
+        for jj in range(2):
+            w = cur + jj * 16 + (r % quarter) // 2
+            if r % 2 == 0:
+                o.append("s_pack_ll_b32_b16 m0, s%d, 0" % w)
+            else:
+                o.append("s_lshr_b32 m0, s%d, 16" % w)
+            o.append("%s v[%d:%d], v[%d:%d], v[%d:%d]" % (add, acc[jj], acc[jj] + 1, acc[jj], acc[jj] + 1,
+                                                         d0 + 2 * k, d0 + 2 * k + 1))
+        if r + DEPTH < ROWS:
+            o.append(ds(r + DEPTH))
+    o.append("s_set_gpr_idx_off")
+    o.append("s_mov_b32 m0, vcc_lo")
+    return o
+
+
+def macro_smem(q, f64):
+    d0, acc = plan(q, 2)
+    names = "ABC"[:len(tuples(q))]
+    params = ["VBASE", "SP0", "SP1"] + ["%s%d" % (n, jj) for jj in range(2) for n in names]
+    lines = ["#define DCA_GATHER_Q%d_%s_SMEM(%s) \\" % (q, "F64" if f64 else "F32", ", ".join(params)), "    asm volatile( \\"]
+    for ln in body_smem(q, f64):
+        lines.append('        "%s\\n" \\' % ln)
+    outs = []
+    for jj, base in enumerate(acc):
+        r = base
+        for n, sz in zip(names, tuples(q)):
+            outs.append('"+{v[%d:%d]}"(%s%d)' % (r, r + sz - 1, n, jj))
+            r += sz
+    lines.append("        : %s \\" % ", ".join(outs))
+    lines.append('        : [vbase] "v"(VBASE), [sp0] "s"(SP0), [sp1] "s"(SP1) \\')
+    clob = ['"memory"', '"vcc"'] + ['"v%d"' % (d0 + i) for i in range(2 * DEPTH)] + ['"s%d"' % i for i in range(SET_A, SET_B + 32)]
+    lines.append("        : %s)" % ", ".join(clob))
+    return "\n".join(lines)
+
+
 def body(q, f64, jw=JW):
     d0, acc = plan(q, jw)
     gw = group_words(jw)
@@ -210,13 +286,12 @@ def main():
     print("wrote", os.path.normpath(lpath))
     out = ["// GENERATED by tools/gen_plm_asm.py -- do not edit by hand.",
            "// Inline-asm gather blocks of plm_scatter_kernel; see the generator for the register plan.", ""]
-    for q in (21, 5):
+    for q in (21, 5):                  # two sites per wave, state words by scalar loads (the product path;
+        # macro() / body() generate the earlier v_readlane form, also with more sites per wave -- kept for
+        # tools/experiments, not emitted)
         for f64 in (0, 1):
-            out.append(macro(q, f64))
+            out.append(macro_smem(q, f64))
             out.append("")
-    for f64 in (0, 1):                 # q = 5: five sites per wave (80 per workgroup) when L makes that the better fit
-        out.append(macro(5, f64, 5))
-        out.append("")
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pydca_amd", "csrc", "scatter_gather_asm.inc")
     with open(path, "w") as fh:
         fh.write("\n".join(out))
