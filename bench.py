@@ -188,7 +188,12 @@ def main():
         "plm_logits": Lq * Lq * esz + n_local * L + n_local * Lq * esz,          # W once, alignment bytes, write S
         "plm_scatter": n_local * Lq * esz + Lq * Lq * esz + n_local * L * 2,     # read R, write G, 16-bit state images
     }
-    lds_bytes = {k: esz * n_local * L * Lq for k in alg_bytes}                     # gathered operand bytes (N L^2 q)
+    # on-chip view.  One unit = one 512-byte row piece added to a running sum; N*L*(Lq*esz/512) units per launch.
+    # LDS bytes actually read per unit: logits fetches the q rows of a site once per wave for its nseq sequences,
+    # scatter reads every row once per wave for its two sites.
+    from tools.gen_plm_asm import LOGITS_CFG
+    units = n_local * L * (Lq * esz / 512.0)
+    lds_bytes = {"plm_logits": units * q * 512.0 / LOGITS_CFG[q][1], "plm_scatter": units * 512.0 / 2}
     dom = max(alg_bytes, key=lambda k: ktimes[k][0])
     ms, launches = ktimes[dom]
     avg_s = ms / max(launches, 1) / 1e3
@@ -202,7 +207,7 @@ def main():
     roofline = {"kernel": dom, "bound": "hbm", "achieved": alg_bytes[dom] / avg_s / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": alg_bytes[dom] / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_kernel_ms": ms / max(launches, 1), "launches": launches,
-                "note": "gather kernels: bound on chip (LDS reads + VALU/SALU issue), not by HBM (DESIGN.md section 4); see onchip",
+                "note": "gather kernels: bound on chip (VALU/SALU issue of the indexed adds, LDS reads), not by HBM (DESIGN.md section 4); see valu / onchip",
                 "onchip": {"bound": "lds", "achieved": lds_bytes[dom] / avg_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                            "frac": lds_bytes[dom] / avg_s / 1e9 / LDS_PEAK_GBS},
                 # the adds themselves: N*L*Lq fp32 (fp64) adds per launch against the vector peak counted in

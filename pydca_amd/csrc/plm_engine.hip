@@ -65,19 +65,36 @@ __global__ void plm_expand_kernel(const T* __restrict__ x, T* __restrict__ W, co
 }
 
 // ------------------------------------------------------------------ logits
-// S[n][c] = sum_j W[j*q + x_nj][c].  The transpose of the scatter kernel: a workgroup owns 512
-// sequences (32 per wave) and one 512-byte column strip (lane = 8 bytes of a row) and walks the
+// S[n][c] = sum_j W[j*q + x_nj][c].  The transpose of the scatter kernel: a workgroup owns a block
+// of sequences (NS per wave) and one 512-byte column strip (lane = 8 bytes of a row) and walks the
 // sites in tiles of JT = 128/q sites whose q rows each are double-buffered in LDS by LDS-DMA.
 // For one site a wave pulls the q rows into q register pairs (ds_read_b64, immediate offsets) and
-// then adds, for each of its 32 sequences, the row of that sequence's state: the SOURCE register
+// then adds, for each of its NS sequences, the row of that sequence's state: the SOURCE register
 // is selected with the VGPR index mode (M0 = 0x2000 | 2 x state, src1 relative), so a
-// (sequence, site) pair costs one SALU write of M0 and one packed add; the 32 running sums are
+// (sequence, site) pair costs one SALU write of M0 and one packed add; the NS running sums are
 // fixed registers.  No per-lane LDS addresses, hence no bank conflicts and no row permutation.
-// Inner block: generated assembly (tools/gen_plm_asm.py -> logits_gather_asm.inc), 64 accumulator
-// + 2q row registers pinned, 128 VGPRs, one 16-wave workgroup per CU.
-constexpr int kLogitSeqPerWave = 32;
-constexpr int kLogitWavesC = 16;
-constexpr int kLogitSeqPerWG = kLogitSeqPerWave * kLogitWavesC;
+// Inner block: generated assembly (tools/gen_plm_asm.py -> logits_gather_asm.inc), accumulator and
+// row registers pinned.  Workgroup shape per q (generator LOGITS_CFG): q=21 runs 12 waves x 56
+// sequences on 168 VGPRs (672 sequences share one staged tile; the fixed per-site cost of fetching
+// the q rows is spread over 56 instead of 32 adds), q=5 runs 16 waves x 32 sequences on 128.
+typedef float dca_v32f __attribute__((ext_vector_type(32)));
+typedef float dca_v16f __attribute__((ext_vector_type(16)));
+typedef float dca_v8f __attribute__((ext_vector_type(8)));
+typedef float dca_v2f __attribute__((ext_vector_type(2)));
+
+#include "logits_gather_asm.inc"
+
+__host__ __device__ constexpr int logits_waves(int q) { return q == 21 ? DCA_LOGITS_WAVES_Q21 : DCA_LOGITS_WAVES_Q5; }
+__host__ __device__ constexpr int logits_nseq(int q) { return q == 21 ? DCA_LOGITS_NSEQ_Q21 : DCA_LOGITS_NSEQ_Q5; }   // per wave
+__host__ __device__ constexpr int logits_seq_per_wg(int q) { return logits_waves(q) * logits_nseq(q); }
+// 64-byte lines that the 2*nseq bytes of one wave's state words of one site can span (their offset
+// is a multiple of 2*nseq)
+__host__ __device__ constexpr int logits_lines_per_site(int nseq)
+{
+    const int bytes = 2 * nseq;
+    const int g = (bytes & -bytes) > 64 ? 64 : (bytes & -bytes);
+    return (64 - g + bytes + 63) / 64;
+}
 __host__ __device__ constexpr int logits_jt(int q) { return q == 21 ? 6 : 25; }   // sites per LDS tile (<= 128 rows)
 
 // XL[j][n] = 0x2000 | 2 * x_nj (M0 image: src1-relative + register-pair offset); state 0 past N and for
@@ -91,37 +108,32 @@ __global__ void plm_build_logit_states_kernel(const uint8_t* __restrict__ X, uin
     XL[(size_t)j * Npad + n] = (uint16_t)(0x2000u | ((n < N && j < L) ? 2u * X[(size_t)n * Ls + j] : 0u));
 }
 
-typedef float dca_v32f __attribute__((ext_vector_type(32)));
-typedef float dca_v8f __attribute__((ext_vector_type(8)));
-typedef float dca_v2f __attribute__((ext_vector_type(2)));
+template <int NP>
+struct LogitsAcc { dca_v16f p[NP]; };          // sequence s of the wave: p[s / 8][2 * (s % 8) .. +1]
 
-#include "logits_gather_asm.inc"
-
-template <int S = 0>
-__device__ __forceinline__ void logits_store(const dca_v32f& a, const dca_v32f& b, unsigned char* rowBase, size_t rowStrideBytes,
-                                             int rowsLeft)
+template <int NSEQ, int S = 0>
+__device__ __forceinline__ void logits_store(const LogitsAcc<NSEQ / 8>& acc, unsigned char* rowBase, size_t rowStrideBytes, int rowsLeft)
 {
-    if constexpr (S < kLogitSeqPerWave) {
-        if (S < rowsLeft) {
-            dca_v2f v;
-            if constexpr (S < 16) v = dca_v2f{a[2 * S], a[2 * S + 1]};
-            else v = dca_v2f{b[2 * (S - 16)], b[2 * (S - 16) + 1]};
-            *reinterpret_cast<dca_v2f*>(rowBase + (size_t)S * rowStrideBytes) = v;
-        }
-        logits_store<S + 1>(a, b, rowBase, rowStrideBytes, rowsLeft);
+    if constexpr (S < NSEQ) {
+        if (S < rowsLeft)
+            *reinterpret_cast<dca_v2f*>(rowBase + (size_t)S * rowStrideBytes) =
+                dca_v2f{acc.p[S / 8][2 * (S % 8)], acc.p[S / 8][2 * (S % 8) + 1]};
+        logits_store<NSEQ, S + 1>(acc, rowBase, rowStrideBytes, rowsLeft);
     }
 }
 
 template <typename T, int Q>
-__global__ __launch_bounds__(kLogitWavesC * 64)
+__global__ __launch_bounds__(logits_waves(Q) * 64)
 void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL, T* __restrict__ S,
-                       int N, int Npad, int L, int Cs, int numColTiles, int numNBlocks)
+                       int N, int Npad, int L, int Cs, int numColTiles, int numNBlocks, int ablate)
 {
-    constexpr int WAVES = kLogitWavesC;
+    constexpr int WAVES = logits_waves(Q);
+    constexpr int NSEQ = logits_nseq(Q);
     constexpr int JT = logits_jt(Q);
     constexpr int CW = 512 / (int)sizeof(T);
     constexpr int TILE = 128 * 512;                 // bytes of one LDS buffer (JT*Q <= 128 rows)
-    constexpr int DMA_PER_WAVE = 128 / 2 / WAVES;
+    constexpr int PIECES = TILE / 1024;             // 1 KiB (two rows) per LDS-DMA instruction
+    constexpr int DMA_PER_WAVE = (PIECES + WAVES - 1) / WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
 
     // XCD-aware decode: all sequence blocks of one column strip run on one XCD so that
@@ -135,24 +147,45 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = nb * kLogitSeqPerWG + wave * kLogitSeqPerWave;
+    const int n0 = nb * (WAVES * NSEQ) + wave * NSEQ;
 
-    dca_v32f accA, accB;
+    LogitsAcc<NSEQ / 8> acc;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { accA[i] = 0.f; accB[i] = 0.f; }
+    for (int i = 0; i < NSEQ / 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc.p[i][e] = 0.f;
 
-    const unsigned char* Wstrip = reinterpret_cast<const unsigned char*>(W + (size_t)ct * CW) + (lane & 31) * 16;
+    const unsigned char* Wbytes = reinterpret_cast<const unsigned char*>(W + (size_t)ct * CW);   // the strip, wave-uniform
     const size_t rowStrideBytes = (size_t)Cs * sizeof(T);
-    // tile jt = rows [jt*JT*Q, +128) of W (the allocation is padded so that the last tile can over-read)
-    auto stage = [&](int jt, int buf) {
+    // LDS-DMA piece p of a tile = rows 2p, 2p+1 (lanes 0-31 / 32-63, 16 bytes per lane); tile jt = rows
+    // [jt*JT*Q, +128) of W (the allocation is padded so that the last tile can over-read)
+    const uint32_t voff = (uint32_t)((lane >> 5) * rowStrideBytes + (lane & 31) * 16);
+    const uint32_t ginc = (uint32_t)(WAVES * 2 * rowStrideBytes);
+    auto stage = [&](int jt, int buf) {       // all pieces of this wave at once: only for tile 0
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
-            const int pairIdx = wave * DMA_PER_WAVE + i;              // wave-uniform
-            const int r = jt * (JT * Q) + pairIdx * 2 + (lane >> 5);
+            const int pairIdx = wave + i * WAVES;                     // wave-uniform
+            if (PIECES % WAVES != 0 && pairIdx >= PIECES) break;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(Wstrip + (size_t)r * rowStrideBytes),
+                (const __attribute__((address_space(1))) void*)(Wbytes + (size_t)(jt * (JT * Q) + pairIdx * 2) * rowStrideBytes + voff),
                 (__attribute__((address_space(3))) void*)(dca_smem + buf * TILE + pairIdx * 1024), 16, 0, 0);
         }
+    };
+
+    // The state words are a stream (N*L*2 bytes per strip, far beyond the L2), so the scalar loads
+    // of the inner block, issued one site ahead, would wait for HBM at every site.  One vector
+    // load per wave and tile touches every 64-byte line of the NEXT tile's state words (lane ->
+    // (site, line)), a whole tile ahead; its data goes to a scratch corner of the LDS and is
+    // never read -- the point is that the scalar loads then hit the L2 (D: 7.98 -> 7.55 ms, E: 0.79 ->
+    // 0.72 ms).  The scatter kernel loads its state words a quarter tile ahead and gains nothing from this.
+    constexpr int LPS = logits_lines_per_site(NSEQ);
+    static_assert(JT * LPS <= 64, "one prefetch lane per (site, line)");
+    const int pfSite = min(lane / LPS, JT - 1);
+    const size_t pfLane = (size_t)pfSite * Npad * 2 + (size_t)n0 * 2 + min((lane % LPS) * 64, NSEQ * 2 - 4);
+    auto prefetch_states = [&](int jt) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(XL) + (size_t)jt * JT * Npad * 2 + pfLane),
+            (__attribute__((address_space(3))) void*)(dca_smem + 2 * TILE + wave * 256), 4, 0, 0);
     };
 
     const int numJT = (L + JT - 1) / JT;
@@ -160,19 +193,23 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
     stage(0, 0);
     for (int jt = 0; jt < numJT; ++jt) {
         const int buf = jt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile jt have landed
-        __syncthreads();                                    // ... everyone's; and tile jt-1 is no longer read
-        if (jt + 1 < numJT) stage(jt + 1, buf ^ 1);
+        if (!(ablate & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile jt have landed
+        if (!(ablate & 1)) __syncthreads();                 // ... everyone's; and tile jt-1 is no longer read  (ablate: timing experiment only)
+        if (jt + 1 < numJT && !(ablate & 8)) prefetch_states(jt + 1);
         const uint16_t* sp = XL + (size_t)jt * JT * Npad + n0;     // wave-uniform
         const uint32_t vbase = ldsBase + buf * TILE;
         const uint32_t strideBytes = (uint32_t)Npad * 2u;
-        if constexpr (Q == 21 && sizeof(T) == 4) DCA_LOGITS_Q21_F32(vbase, sp, strideBytes, accA, accB);
-        else if constexpr (Q == 21) DCA_LOGITS_Q21_F64(vbase, sp, strideBytes, accA, accB);
-        else if constexpr (sizeof(T) == 4) DCA_LOGITS_Q5_F32(vbase, sp, strideBytes, accA, accB);
-        else DCA_LOGITS_Q5_F64(vbase, sp, strideBytes, accA, accB);
+        // the block also issues this wave's LDS-DMA pieces of tile jt+1 (piece i = wave + i*WAVES), spread over its sites
+        const uint32_t npc = __builtin_amdgcn_readfirstlane((jt + 1 < numJT && !(ablate & 2)) ? (uint32_t)((PIECES - wave + WAVES - 1) / WAVES) : 0u);
+        const unsigned char* gbase = Wbytes + (size_t)((jt + 1) * (JT * Q) + wave * 2) * rowStrideBytes;     // wave-uniform
+        const uint32_t ldst = (uint32_t)(uintptr_t)dca_smem + (buf ^ 1) * TILE + wave * 1024;
+        if constexpr (Q == 21 && sizeof(T) == 4) DCA_LOGITS_Q21_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
+        else if constexpr (Q == 21) DCA_LOGITS_Q21_F64(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
+        else if constexpr (sizeof(T) == 4) DCA_LOGITS_Q5_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
+        else DCA_LOGITS_Q5_F64(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
     }
     if (n0 < N)
-        logits_store(accA, accB, reinterpret_cast<unsigned char*>(S + (size_t)n0 * Cs + (size_t)ct * CW) + lane * 8,
+        logits_store<NSEQ>(acc, reinterpret_cast<unsigned char*>(S + (size_t)n0 * Cs + (size_t)ct * CW) + lane * 8,
                      rowStrideBytes, N - n0);
 }
 
@@ -362,7 +399,7 @@ __device__ __forceinline__ void scatter_store_site(const SiteAcc<Q>& acc, unsign
 
 template <typename T, int Q, int JW>
 __global__ __launch_bounds__(kScatWavesC * 64)
-void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT2, const unsigned char* __restrict__ zeros,
+void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT2,
                         T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int NT, int numColTiles,
                         int numJG, int chunksPerSplit, size_t slabElems, int ablate)
 {
@@ -401,21 +438,19 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
         xs[jj] = reinterpret_cast<const uint32_t*>(XT2 + (size_t)min(j0 + jj, L - 1) * NT);
     }
 
-    const unsigned char* Rstrip = reinterpret_cast<const unsigned char*>(R + (size_t)ct * CW) + (lane & 31) * 16;
+    // LDS-DMA piece p of a tile = rows 2p, 2p+1 (lanes 0-31 / 32-63, 16 bytes per lane); a wave stages pieces
+    // 4*wave .. 4*wave+3.  R has kNC zero rows behind row N-1, so the last tile needs no special case.
+    const unsigned char* Rbytes = reinterpret_cast<const unsigned char*>(R + (size_t)ct * CW);    // the strip, wave-uniform
     const size_t rowStrideBytes = (size_t)Cs * sizeof(T);
-
-    // rows past N come from a zero row in global memory
-    auto stage = [&](int c, int buf) {
-        const int n0 = halo + c * kNC;
+    const uint32_t voff = (uint32_t)((lane >> 5) * rowStrideBytes + (lane & 31) * 16);
+    const uint32_t ginc = (uint32_t)(2 * rowStrideBytes);
+    auto tile_src = [&](int c) { return Rbytes + (size_t)(halo + c * kNC + wave * DMA_PER_WAVE * 2) * rowStrideBytes; };
+    auto stage = [&](int c, int buf) {        // all four pieces at once: only for the first tile
 #pragma unroll
-        for (int i = 0; i < DMA_PER_WAVE && !(ablate & 8); ++i) {
-            const int pairIdx = wave * DMA_PER_WAVE + i;              // wave-uniform
-            const int n = n0 + pairIdx * 2 + (lane >> 5);
-            const unsigned char* g = (n < N) ? Rstrip + (size_t)n * rowStrideBytes : zeros + (lane & 31) * 16;
+        for (int i = 0; i < DMA_PER_WAVE && !(ablate & 8); ++i)
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)g,
-                (__attribute__((address_space(3))) void*)(dca_smem + buf * TILE + pairIdx * 1024), 16, 0, 0);
-        }
+                (const __attribute__((address_space(1))) void*)(tile_src(c) + (size_t)i * ginc + voff),
+                (__attribute__((address_space(3))) void*)(dca_smem + buf * TILE + (wave * DMA_PER_WAVE + i) * 1024), 16, 0, 0);
     };
 
     if (cBegin < cEnd) stage(cBegin, 0);
@@ -423,22 +458,24 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
     for (int c = cBegin; c < cEnd; ++c) {
         const int buf = (c - cBegin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile c have landed
-        __syncthreads();                                    // ... everyone's; and tile c-1 is no longer read
-        if (c + 1 < cEnd) stage(c + 1, buf ^ 1);
+        if (!(ablate & 1)) __syncthreads();                 // ... everyone's; and tile c-1 is no longer read
         const uint32_t vbase = ldsBase + buf * TILE;
-        if (!(ablate & 2)) {     // timing knob (DCA_SCATTER_ABLATE): 2 = staging only
-            // two sites per wave: the state words come through scalar loads inside the block
-            const uint32_t* sp0 = xs[0] + c * (kNC / 2);
-            const uint32_t* sp1 = xs[1] + c * (kNC / 2);
-            if constexpr (Q == 21 && sizeof(T) == 4)
-                DCA_GATHER_Q21_F32_SMEM(vbase, sp0, sp1, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
-            else if constexpr (Q == 21)
-                DCA_GATHER_Q21_F64_SMEM(vbase, sp0, sp1, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
-            else if constexpr (sizeof(T) == 4)
-                DCA_GATHER_Q5_F32_SMEM(vbase, sp0, sp1, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
-            else
-                DCA_GATHER_Q5_F64_SMEM(vbase, sp0, sp1, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
-        }
+        // two sites per wave: the state words come through scalar loads inside the block, which also
+        // issues the wave's four LDS-DMA pieces of tile c+1, one per quarter tile
+        const uint32_t* sp0 = xs[0] + c * (kNC / 2);
+        const uint32_t* sp1 = xs[1] + c * (kNC / 2);
+        const uint32_t npc = __builtin_amdgcn_readfirstlane((c + 1 < cEnd && !(ablate & 8)) ? 1u : 0u);
+        const unsigned char* gbase = tile_src(c + 1);
+        const uint32_t ldst = (uint32_t)(uintptr_t)dca_smem + (buf ^ 1) * TILE + wave * DMA_PER_WAVE * 1024;
+        uint32_t vtmp;
+        if constexpr (Q == 21 && sizeof(T) == 4)
+            DCA_GATHER_Q21_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+        else if constexpr (Q == 21)
+            DCA_GATHER_Q21_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+        else if constexpr (sizeof(T) == 4)
+            DCA_GATHER_Q5_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+        else
+            DCA_GATHER_Q5_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
     }
 
     T* const Gslab = G + (size_t)blockIdx.y * slabElems;
@@ -891,7 +928,6 @@ struct PlmEngine : PlmEngineBase {
     uint16_t* dXL = nullptr;
     uint16_t* dXT2 = nullptr;
     int NT = 0;
-    unsigned char* dZeros = nullptr;
     PairIJ* dPairs = nullptr;
     double *dFxPart = nullptr, *dRegPart = nullptr, *dVecPart = nullptr;
     int nFxPart = 0, nRegPart = 0;
@@ -925,7 +961,7 @@ struct PlmEngine : PlmEngineBase {
         hipFree(dx); hipFree(dg); hipFree(dxp); hipFree(dgp); hipFree(dd);
         for (int i = 0; i < 5; ++i) { hipFree(dS[i]); hipFree(dY[i]); }
         hipFree(dWt); hipFree(dSR); hipFree(dG); hipFree(dw); hipFree(dXL); hipFree(dXT2);
-        hipFree(dPairs); hipFree(dZeros); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
+        hipFree(dPairs); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
     }
     ~PlmEngine() override { freeall(); }
 
@@ -951,7 +987,7 @@ struct PlmEngine : PlmEngineBase {
         freeall();
         dx = dg = dxp = dgp = dd = nullptr;
         for (int i = 0; i < 5; ++i) dS[i] = dY[i] = nullptr;
-        dWt = dSR = dG = dw = nullptr; dXL = nullptr; dXT2 = nullptr; dZeros = nullptr; dPairs = nullptr;
+        dWt = dSR = dG = dw = nullptr; dXL = nullptr; dXT2 = nullptr; dPairs = nullptr;
         dFxPart = dRegPart = dVecPart = nullptr;
         lbfgs_alloc = false;
         o = decltype(o)();
@@ -964,11 +1000,12 @@ struct PlmEngine : PlmEngineBase {
         scatJW = 2;     // sites per wave of the scatter kernel
         const int JG = kScatWavesC * scatJW;
         Grows = ceil_div(L, JG) * JG * q;
-        Npad = (int)round_up(N, kLogitSeqPerWG);
+        Npad = (int)round_up(N, logits_seq_per_wg(q));
 
         DCA_TRY(dalloc(&dx, P + kVecPad)); DCA_TRY(dalloc(&dg, P + kVecPad));
         DCA_TRY(dalloc(&dWt, (size_t)Wrows * Cs));
-        DCA_TRY(dalloc(&dSR, (size_t)N * Cs));
+        DCA_TRY(dalloc(&dSR, (size_t)(N + kNC) * Cs));          // + kNC zero rows: the scatter kernel's last tile reads past row N-1
+        HIP_TRY(hipMemsetAsync(dSR + (size_t)N * Cs, 0, (size_t)kNC * Cs * sizeof(T), ctx->stream));
         {
             // Split of the tile range over blockIdx.y.  Aim at ~2048 workgroups (8 rounds of one workgroup
             // per CU) but keep >= 12 tiles per workgroup (prologue + epilogue cost about two tiles), then
@@ -989,8 +1026,6 @@ struct PlmEngine : PlmEngineBase {
             scatSplit = ceil_div(numScatChunks, scatChunksPerSplit);
         }
         DCA_TRY(dalloc(&dG, (size_t)scatSplit * Grows * Cs));
-        DCA_TRY(dalloc(&dZeros, kRowBytes));
-        HIP_TRY(hipMemsetAsync(dZeros, 0, kRowBytes, ctx->stream));
         DCA_TRY(dalloc(&dw, N));
         DCA_TRY(dalloc(&dXL, (size_t)ceil_div(L, JT) * JT * Npad));
         NT = numScatChunks * kNC;
@@ -1125,13 +1160,14 @@ struct PlmEngine : PlmEngineBase {
         {
             constexpr int CW = 512 / (int)sizeof(T);
             const int numCT = ceil_div(Cs, CW);
-            const int numNB = Npad / kLogitSeqPerWG;
+            const int numNB = Npad / logits_seq_per_wg(q);
             const int blocks = kNumXcd * ceil_div(numCT, kNumXcd) * numNB;
-            const size_t lds = (size_t)2 * 128 * 512;
+            const size_t lds = (size_t)2 * 128 * 512 + (size_t)logits_waves(Q) * 256;   // two tiles + prefetch scratch
             auto kern = plm_logits_kernel<T, Q>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ScopedKernelClock kc(ctx, "plm_logits");
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(kLogitWavesC * 64), lds, st, dWt, dXL, dSR, N, Npad, L, Cs, numCT, numNB);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(logits_waves(Q) * 64), lds, st, dWt, dXL, dSR, N, Npad, L, Cs, numCT, numNB,
+                               getenv("DCA_LOGITS_ABLATE") ? atoi(getenv("DCA_LOGITS_ABLATE")) : 0);
         }
         {
             dim3 grid(ceil_div(L, 64), ceil_div(numScanChunks, 4));
@@ -1152,7 +1188,7 @@ struct PlmEngine : PlmEngineBase {
             auto launch = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ScopedKernelClock kc(ctx, "plm_scatter");
-                hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(kScatWavesC * 64), lds, st, dSR, dXT2, dZeros, dG, N, L, Cs, halo,
+                hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(kScatWavesC * 64), lds, st, dSR, dXT2, dG, N, L, Cs, halo,
                                    numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs, ablate);
                 return DCA_OK;
             };

@@ -8,6 +8,9 @@
 #include <cstdint>
 #include "logits_variant.inc"
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+#ifndef NBSEQ
+#define NBSEQ 32
+#endif
 #ifndef NWAVES
 #define NWAVES 16
 #endif
@@ -20,17 +23,19 @@ void bench_kernel(const float* __restrict__ tile, const uint16_t* __restrict__ s
     for (int t = tid; t < ROWS * ROWB / 4; t += WAVES * 64) reinterpret_cast<float*>(smem)[t] = tile[t];
     __syncthreads();
     const uint32_t vbase = (uint32_t)(uintptr_t)smem + lane * 8;
-    const uint16_t* sp = states + ((size_t)blockIdx.x * WAVES + wave) * 32;
+    const uint16_t* sp = states + ((size_t)blockIdx.x * WAVES + wave) * NBSEQ;
     for (int it = 0; it < iters; ++it) {
         LOGITS_BLOCK(vbase, sp, strideBytes);
+#ifndef STATES_CACHED
         sp += (size_t)JT * strideBytes / 2;
+#endif
     }
     out[(size_t)blockIdx.x * WAVES * 64 + tid] = (float)iters;
 }
 int main(int argc, char** argv)
 {
     const int blocks = argc > 1 ? atoi(argv[1]) : 256, iters = argc > 2 ? atoi(argv[2]) : 84;
-    const int seqs = blocks * WAVES * 32;
+    const int seqs = blocks * WAVES * NBSEQ;
     const int strideBytes = seqs * 2;
     std::vector<float> tile(ROWS * 128, 0.25f);
     std::vector<uint16_t> st((size_t)seqs * JT * iters + 4096);
@@ -51,7 +56,7 @@ int main(int argc, char** argv)
         float ms; CHECK(hipEventElapsedTime(&ms, a, b));
         if (ms < best) best = ms;
     }
-    const double units = (double)blocks * WAVES * 32 * JT * iters;
+    const double units = (double)blocks * WAVES * NBSEQ * JT * iters;
     printf("%s waves %d: blocks %d: %.3f ms  %.2f clk per (sequence,site) per CU @2.4GHz\n", VARIANT, WAVES, blocks, best, best * 1e-3 * 2.4e9 / (units / 256));
     fflush(stdout);
     return 0;

@@ -36,6 +36,7 @@ sums, ~100 TB/s aggregate LDS read rate for the single-site form.
 import os
 
 ROWS, ROWBYTES, DEPTH, JW = 128, 512, 8, 2
+STAGE_AT = os.environ.get("DCA_GEN_STAGE_AT", "pre")
 S0, T0 = 40, 72
 
 
@@ -87,6 +88,7 @@ def body_smem(q, f64):
         return ["s_load_dwordx16 s[%d:%d], %%[sp%d], 0x%x" % (base + 16 * jj, base + 16 * jj + 15, jj, qk * 64) for jj in range(2)]
 
     o += sload(0, sets[0])
+    o.append("v_mov_b32 %[vtmp], %[voff]")
     for r in range(DEPTH):
         o.append(ds(r))
     quarter = ROWS // 4
@@ -95,10 +97,28 @@ def body_smem(q, f64):
             qk = r // quarter
             if r:
                 o.append("s_set_gpr_idx_off")
+            # this wave's LDS-DMA piece qk of the NEXT tile (4 pieces per wave and tile), issued here rather
+            # than all 64 pieces of the workgroup at the tile start: no burst of LDS writes in front of everyone's reads
+            dma = ["s_cmp_lg_u32 %[npc], 0",
+                   "s_cbranch_scc0 .Ldca_sc_skip%d_%%=" % qk,
+                   "s_add_u32 m0, %%[ldst], %d" % (qk * 1024),
+                   "s_nop 0",
+                   "global_load_lds_dwordx4 %[vtmp], %[gbase]",
+                   "v_add_u32 %[vtmp], %[ginc], %[vtmp]",
+                   ".Ldca_sc_skip%d_%%=:" % qk]
+            if STAGE_AT == "pre":
+                o += dma
             o.append("s_waitcnt lgkmcnt(0)")
             if qk + 1 < 4:
                 o += sload(qk + 1, sets[(qk + 1) % 2])
+            if STAGE_AT == "post":
+                o += dma
             o.append("s_set_gpr_idx_on s%d, 0x9" % sets[qk % 2])       # index bits are rewritten before every use
+        if STAGE_AT == "mid" and r % quarter == quarter // 2:
+            qk = r // quarter
+            o.append("s_set_gpr_idx_off")
+            o += dma
+            o.append("s_set_gpr_idx_on s%d, 0x9" % sets[qk % 2])
         o.append("s_waitcnt lgkmcnt(%d)" % min(DEPTH - 1, ROWS - 1 - r))
         k = r % DEPTH
         cur = sets[(r // quarter) % 2]
@@ -120,7 +140,7 @@ def body_smem(q, f64):
 def macro_smem(q, f64):
     d0, acc = plan(q, 2)
     names = "ABC"[:len(tuples(q))]
-    params = ["VBASE", "SP0", "SP1"] + ["%s%d" % (n, jj) for jj in range(2) for n in names]
+    params = ["VBASE", "SP0", "SP1", "NPC", "GBASE", "GINC", "VOFF", "LDST", "VTMP"] + ["%s%d" % (n, jj) for jj in range(2) for n in names]
     lines = ["#define DCA_GATHER_Q%d_%s_SMEM(%s) \\" % (q, "F64" if f64 else "F32", ", ".join(params)), "    asm volatile( \\"]
     for ln in body_smem(q, f64):
         lines.append('        "%s\\n" \\' % ln)
@@ -130,9 +150,11 @@ def macro_smem(q, f64):
         for n, sz in zip(names, tuples(q)):
             outs.append('"+{v[%d:%d]}"(%s%d)' % (r, r + sz - 1, n, jj))
             r += sz
+    outs.append('[vtmp] "=&v"(VTMP)')
     lines.append("        : %s \\" % ", ".join(outs))
-    lines.append('        : [vbase] "v"(VBASE), [sp0] "s"(SP0), [sp1] "s"(SP1) \\')
-    clob = ['"memory"', '"vcc"'] + ['"v%d"' % (d0 + i) for i in range(2 * DEPTH)] + ['"s%d"' % i for i in range(SET_A, SET_B + 32)]
+    lines.append('        : [vbase] "v"(VBASE), [sp0] "s"(SP0), [sp1] "s"(SP1), [npc] "s"(NPC), [gbase] "s"(GBASE), [ginc] "s"(GINC), '
+                 '[voff] "v"(VOFF), [ldst] "s"(LDST) \\')
+    clob = ['"memory"', '"vcc"', '"scc"'] + ['"v%d"' % (d0 + i) for i in range(2 * DEPTH)] + ['"s%d"' % i for i in range(SET_A, SET_B + 32)]
     lines.append("        : %s)" % ", ".join(clob))
     return "\n".join(lines)
 
@@ -203,71 +225,138 @@ def macro(q, f64, jw=JW):
 
 
 # ------------------------------------------------------------------------------------------ logits
-# One block = one wave, one LDS tile of JT sites, NB = 32 sequences, one 512-byte column strip.
+# One block = one wave, one LDS tile of JT sites, NS sequences (LOGITS_CFG), one 512-byte column strip.
 # For every site j of the tile:
 #
 #     w[b] = Wtile[(j, b)][lane]  for b in 0..q-1      (q ds_read_b64 with immediate offsets)
-#     for s in 0..31:  acc[s] += w[state(n0 + s, j)]   (source register selected through M0)
+#     for s in 0..NS-1:  acc[s] += w[state(n0 + s, j)] (source register selected through M0)
 #
 # i.e. the transpose of the scatter block: there the destination is indexed, here the source
 # (src1 relative: M0 image 0x2000 | 2 x state).  The q rows of W of the site sit in q register
 # pairs, so a (sequence, site) pair costs one SALU write of M0 and one packed add and no LDS access
-# of its own; the LDS reads are q per 32 pairs.  The 32 M0 images of a site arrive with one
-# s_load_dwordx16 that is issued one site ahead (two SGPR sets, ping-pong), so only the LDS latency
-# of the q row reads is exposed per site -- the other three waves of the SIMD cover it.
+# of its own; the LDS reads are q per NS pairs.  The NS M0 images of a site arrive by scalar loads
+# issued one site ahead (two SGPR sets, ping-pong), so only the LDS latency of the q row reads is
+# exposed per site -- the other waves of the SIMD cover it.
 #
-# Register plan: accumulators v[64:127] (two 32-register tuples), w rows v[64-2q : 63],
-# state words s[40:55] / s[56:71], temporaries s72 (zero), s73 (saved M0), s[74:75] (state pointer).
-NBSEQ = 32
+# Register plan (logits_plan): accumulators at the top of the VGPR budget (128 for 16-wave, 168 for
+# 12-wave workgroups) as 16-register tuples, the q row pairs right below them; state words from s36
+# in two sets, behind them the temporaries: zero, saved M0, state pointer (2), staging source (2) and
+# LDS destination.
 
 
 def logits_jt(q):
     return {21: 6, 5: 25}[q]
 
 
+# (waves per workgroup, sequences per wave) of plm_logits_kernel.  q=21: 12 waves x 56 sequences on
+# 168 VGPRs (3 waves per SIMD) -- per site a wave spends a fixed ~490 clk fetching the q rows and
+# ~15.5 clk per sequence (the M0 write -> indexed add chain), so more sequences per wave amortise
+# the fetch, and 672 instead of 512 sequences per workgroup share one staged tile of W
+# (tools/experiments/gen_logits_variants.py wide: 2.25 -> 2.04 clk per (sequence, site) per CU).
+LOGITS_CFG = {21: (12, 56), 5: (16, 48)}
+LS0 = 36                       # first state-word SGPR
+
+
+def logits_plan(q):
+    """-> (waves, nseq, first row register, first accumulator register, words per SGPR set, first temp SGPR)"""
+    waves, nseq = LOGITS_CFG[q]
+    vg = 128 if waves == 16 else 168
+    acc0 = vg - 2 * nseq
+    nw = (nseq // 2 + 3) // 4 * 4
+    tb = LS0 + 2 * nw
+    assert tb + 7 <= 100 and nseq % 8 == 0
+    return waves, nseq, acc0 - 2 * q, acc0, nw, tb
+
+
+def logits_state_loads(q, sset):
+    """scalar loads of one site's nseq 16-bit M0 images (nseq/2 dwords) into SGPR set sset"""
+    waves, nseq, w0, acc0, nw, tb = logits_plan(q)
+    base = LS0 + sset * nw
+    r, left, at = [], nseq // 2, 0
+    for piece in (16, 8, 4, 2, 1):
+        while left >= piece:
+            reg = "s[%d:%d]" % (base + at, base + at + piece - 1) if piece > 1 else "s%d" % (base + at)
+            r.append("s_load_dword%s %s, s[%d:%d], 0x%x" % ("x%d" % piece if piece > 1 else "", reg, tb + 2, tb + 3, at * 4))
+            at += piece
+            left -= piece
+    return r
+
+
+LOGITS_PIECES = 64             # 1 KiB LDS-DMA pieces per tile (128 rows x 512 bytes)
+
+
+def logits_stage_sites(q):
+    """sites of the tile at whose start a wave issues its i-th LDS-DMA piece of the NEXT tile"""
+    waves = LOGITS_CFG[q][0]
+    ppw = (LOGITS_PIECES + waves - 1) // waves
+    jt = logits_jt(q)
+    return [i * jt // ppw for i in range(ppw)]
+
+
 def logits_body(q, f64):
-    w0 = 64 - 2 * q
+    """One tile.  Besides the adds, the wave issues its share of the LDS-DMA pieces of the next tile, one
+    piece at the start of a site (logits_stage_sites) instead of all of them at the start of the tile:
+    a burst of 64 KiB of LDS writes right after the barrier holds up every wave's row reads at once."""
+    waves, nseq, w0, acc0, nw, tb = logits_plan(q)
     jt = logits_jt(q)
     add = "v_add_f64" if f64 else "v_pk_add_f32"
-    sets = (S0, S0 + 16)
-    o = ["s_mov_b32 s%d, m0" % (T0 + 1),
-         "s_mov_b64 s[74:75], %[sptr]",
-         "s_mov_b32 s%d, 0" % T0,
-         "s_load_dwordx16 s[%d:%d], s[74:75], 0x0" % (sets[0], sets[0] + 15)]
+    gb, ld = tb + 4, tb + 6
+    stage_at = logits_stage_sites(q)
+    o = ["s_mov_b32 s%d, m0" % (tb + 1),
+         "s_mov_b64 s[%d:%d], %%[sptr]" % (tb + 2, tb + 3),
+         "s_mov_b64 s[%d:%d], %%[gbase]" % (gb, gb + 1),
+         "s_mov_b32 s%d, %%[ldst]" % ld,
+         "s_mov_b32 s%d, 0" % tb]
+    o += logits_state_loads(q, 0)
     for jj in range(jt):
-        cur = sets[jj % 2]
-        nxt = sets[(jj + 1) % 2]
+        cur = LS0 + (jj % 2) * nw
         if jj + 1 < jt:
-            o.append("s_add_u32 s74, s74, %[stride]")
-            o.append("s_addc_u32 s75, s75, 0")
+            o.append("s_add_u32 s%d, s%d, %%[stride]" % (tb + 2, tb + 2))
+            o.append("s_addc_u32 s%d, s%d, 0" % (tb + 3, tb + 3))
+        for i, at in enumerate(stage_at):
+            if at == jj:
+                o += ["s_cmp_gt_u32 %%[npc], %d" % i,
+                      "s_cbranch_scc0 .Ldca_lg_skip%d_%%=" % i,
+                      "s_mov_b32 m0, s%d" % ld,
+                      "s_nop 0",
+                      "global_load_lds_dwordx4 %%[voff], s[%d:%d]" % (gb, gb + 1),
+                      "s_add_u32 s%d, s%d, %%[ginc]" % (gb, gb),
+                      "s_addc_u32 s%d, s%d, 0" % (gb + 1, gb + 1),
+                      "s_add_u32 s%d, s%d, %d" % (ld, ld, waves * 1024),
+                      ".Ldca_lg_skip%d_%%=:" % i]
         for b in range(q):
             o.append("ds_read_b64 v[%d:%d], %%[vbase] offset:%d" % (w0 + 2 * b, w0 + 2 * b + 1, (jj * q + b) * ROWBYTES))
         o.append("s_waitcnt lgkmcnt(0)")
         if jj + 1 < jt:
-            o.append("s_load_dwordx16 s[%d:%d], s[74:75], 0x0" % (nxt, nxt + 15))
-        o.append("s_set_gpr_idx_on s%d, 0x2" % T0)
-        for sq in range(NBSEQ):
+            o += logits_state_loads(q, (jj + 1) % 2)
+        o.append("s_set_gpr_idx_on s%d, 0x2" % tb)
+        for sq in range(nseq):
             w = cur + sq // 2
             if sq % 2 == 0:
                 o.append("s_pack_ll_b32_b16 m0, s%d, 0" % w)
             else:
                 o.append("s_lshr_b32 m0, s%d, 16" % w)
-            a = 64 + 2 * sq
+            a = acc0 + 2 * sq
             o.append("%s v[%d:%d], v[%d:%d], v[%d:%d]" % (add, a, a + 1, a, a + 1, w0, w0 + 1))
         o.append("s_set_gpr_idx_off")
-    o.append("s_mov_b32 m0, s%d" % (T0 + 1))
+    o.append("s_mov_b32 m0, s%d" % (tb + 1))
     return o
 
 
 def logits_macro(q, f64):
-    w0 = 64 - 2 * q
-    lines = ["#define DCA_LOGITS_Q%d_%s(VBASE, SPTR, STRIDE, ACCA, ACCB) \\" % (q, "F64" if f64 else "F32"), "    asm volatile( \\"]
+    """VBASE: LDS address of the tile + 8 * lane.  SPTR / STRIDE: the wave's state words of the tile's first
+    site / bytes between sites.  Staging of the next tile: NPC pieces (0: none), piece i copies 1 KiB from
+    GBASE + i * GINC + VOFF (per lane) to LDS address LDST + i * waves * 1024."""
+    waves, nseq, w0, acc0, nw, tb = logits_plan(q)
+    lines = ["#define DCA_LOGITS_Q%d_%s(VBASE, SPTR, STRIDE, NPC, GBASE, GINC, VOFF, LDST, ACC) \\" % (q, "F64" if f64 else "F32"),
+             "    asm volatile( \\"]
     for ln in logits_body(q, f64):
         lines.append('        "%s\\n" \\' % ln)
-    lines.append('        : "+{v[64:95]}"(ACCA), "+{v[96:127]}"(ACCB) \\')
-    lines.append('        : [vbase] "v"(VBASE), [sptr] "s"(SPTR), [stride] "s"(STRIDE) \\')
-    clob = ['"memory"'] + ['"v%d"' % (w0 + i) for i in range(2 * q)] + ['"s%d"' % (S0 + i) for i in range(32)] + \
-           ['"s%d"' % (T0 + i) for i in range(4)]
+    ops = ['"+{v[%d:%d]}"((ACC).p[%d])' % (acc0 + 16 * i, acc0 + 16 * i + 15, i) for i in range(nseq // 8)]
+    lines.append("        : %s \\" % ", ".join(ops))
+    lines.append('        : [vbase] "v"(VBASE), [sptr] "s"(SPTR), [stride] "s"(STRIDE), [npc] "s"(NPC), [gbase] "s"(GBASE), '
+                 '[ginc] "s"(GINC), [voff] "v"(VOFF), [ldst] "s"(LDST) \\')
+    clob = ['"memory"', '"scc"'] + ['"v%d"' % (w0 + i) for i in range(2 * q)] + ['"s%d"' % i for i in range(LS0, tb + 7)]
     lines.append("        : %s)" % ", ".join(clob))
     return "\n".join(lines)
 
@@ -277,6 +366,8 @@ def main():
     lout = ["// GENERATED by tools/gen_plm_asm.py -- do not edit by hand.",
             "// Inline-asm inner blocks of plm_logits_kernel; see the generator for the register plan.", ""]
     for q in (21, 5):
+        lout.append("#define DCA_LOGITS_WAVES_Q%d %d" % (q, LOGITS_CFG[q][0]))
+        lout.append("#define DCA_LOGITS_NSEQ_Q%d %d" % (q, LOGITS_CFG[q][1]))
         for f64 in (0, 1):
             lout.append(logits_macro(q, f64))
             lout.append("")
