@@ -15,6 +15,7 @@
 // All products are of the form C[i][j] = sum_k A[i][k] * B[j][k] ("NT", both operands
 // K-contiguous), which is why X is kept mirrored: X^T rows are then plain rows.
 // The 64x64 diagonal leaves (Cholesky + triangular inverse) run in one workgroup in LDS.
+#include <climits>
 #include "dca_internal.h"
 
 namespace {
@@ -23,8 +24,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 enum { MASK_NONE = 0, MASK_LOWER = 1 /* k <= row */, MASK_UPPER = 2 /* k >= row */ };
 
-constexpr int BM = 64, BN = 64, BK = 16;
-constexpr int LDS_STRIDE = BK + 1;   // doubles; odd stride spreads the 16 fragment rows over banks
+constexpr int BM = 64, BN = 64;
 
 struct GemmArgs {
     const double* A; int lda; int maskA;
@@ -36,11 +36,21 @@ struct GemmArgs {
     int lowerOnly;                 // square output: only tiles with tj <= ti; strict mirror rule on the diagonal
 };
 
+// BK = 16: the throughput form (35 KB of LDS, three workgroups per CU).  BK = 64: for the many products of
+// the recursion that are a handful of tiles on an otherwise empty GPU -- their time is a chain of global
+// round trips, one per k-tile, so a four times deeper tile means four times fewer of them (K = 64: one).
+template <int BK>
+constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BM + BN) * (BK + 1) * sizeof(double); }
+
+template <int BK>
 __global__ __launch_bounds__(256)
 void gemm_nt_f64_kernel(GemmArgs g)
 {
-    __shared__ double As[2][BM * LDS_STRIDE];
-    __shared__ double Bs[2][BN * LDS_STRIDE];
+    constexpr int LDS_STRIDE = BK + 1;   // doubles; odd stride spreads the 16 fragment rows over banks
+    constexpr int PG = BK / 16;          // 16-byte pieces per thread and row: the row's BK/2 pieces over 8 threads
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];
+    double* const As = reinterpret_cast<double*>(dca_gemm_smem);      // [2][BM * LDS_STRIDE]
+    double* const Bs = As + 2 * BM * LDS_STRIDE;                      // [2][BN * LDS_STRIDE]
     const int ti = blockIdx.y, tj = blockIdx.x;
     if (g.lowerOnly && tj > ti) return;
     const int tid = threadIdx.x;
@@ -61,44 +71,69 @@ void gemm_nt_f64_kernel(GemmArgs g)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    // staging role: thread -> (row r, 4 consecutive k)
-    const int sr = tid >> 2, sk = (tid & 3) * 4;
-    const double* Arow = g.A + (size_t)(ti * BM + sr) * g.lda;
-    const double* Brow = g.B + (size_t)(tj * BN + sr) * g.ldb;
-    const int aRowLocal = ti * BM + sr, bRowLocal = tj * BN + sr;
-
-    double ra[4], rb[4];
+    // staging role: 16-byte pieces, thread -> rows sr and sr + 32, doubles sp + 16 * pg, +1 of the k-tile, so that
+    // one wave-wide load covers 8 full 128-byte lines.  global -> registers (raw) -> LDS; the triangular masks are
+    // applied when a tile is WRITTEN to LDS, after the MFMAs of the current tile, so the loads of the next tile
+    // are in flight during those MFMAs instead of being waited for right away.
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    const int sr = tid >> 3, sp = (tid & 7) * 2;
+    const double* Ap = g.A + (size_t)(ti * BM + sr) * g.lda + sp;
+    const double* Bp = g.B + (size_t)(tj * BN + sr) * g.ldb + sp;
+    const size_t aStep = (size_t)32 * g.lda, bStep = (size_t)32 * g.ldb;
+    double2_t ra[2][PG], rb[2][PG];
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + sk + u;
-            double va = Arow[k], vb = Brow[k];
-            if (g.maskA == MASK_LOWER && k > aRowLocal) va = 0.0;
-            if (g.maskA == MASK_UPPER && k < aRowLocal) va = 0.0;
-            if (g.maskB == MASK_LOWER && k > bRowLocal) vb = 0.0;
-            if (g.maskB == MASK_UPPER && k < bRowLocal) vb = 0.0;
-            ra[u] = va; rb[u] = vb;
-        }
-    };
-    auto store_tile = [&](int buf) {
+        for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            As[buf][sr * LDS_STRIDE + sk + u] = ra[u];
-            Bs[buf][sr * LDS_STRIDE + sk + u] = rb[u];
+            for (int pg = 0; pg < PG; ++pg) {
+                const int kp = k0 + 16 * pg;
+                ra[ps][pg] = *reinterpret_cast<const double2_t*>(Ap + ps * aStep + kp);
+                rb[ps][pg] = *reinterpret_cast<const double2_t*>(Bp + ps * bStep + kp);
+            }
+    };
+    auto store_tile = [&](int buf, int k0) {
+        // only k-tiles that cross the diagonal of a triangular operand's row block need masking (wave-uniform test)
+        const bool diagA = g.maskA != MASK_NONE && k0 + BK > ti * BM && k0 < (ti + 1) * BM;
+        const bool diagB = g.maskB != MASK_NONE && k0 + BK > tj * BN && k0 < (tj + 1) * BN;
+        if (diagA || diagB) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                // k range in which the operand row is non-zero: lower k <= row, upper k >= row
+                const int aRow = ti * BM + sr + 32 * ps, bRow = tj * BN + sr + 32 * ps;
+                const int aLo = g.maskA == MASK_UPPER ? aRow : INT_MIN, aHi = g.maskA == MASK_LOWER ? aRow : INT_MAX;
+                const int bLo = g.maskB == MASK_UPPER ? bRow : INT_MIN, bHi = g.maskB == MASK_LOWER ? bRow : INT_MAX;
+#pragma unroll
+                for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int k = k0 + 16 * pg + sp + u;
+                        ra[ps][pg][u] = (k < aLo || k > aHi) ? 0.0 : ra[ps][pg][u];
+                        rb[ps][pg][u] = (k < bLo || k > bHi) ? 0.0 : rb[ps][pg][u];
+                    }
+            }
         }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) {
+                double* ad = As + buf * BM * LDS_STRIDE + (sr + 32 * ps) * LDS_STRIDE + 16 * pg + sp;
+                double* bd = Bs + buf * BN * LDS_STRIDE + (sr + 32 * ps) * LDS_STRIDE + 16 * pg + sp;
+                ad[0] = ra[ps][pg][0]; ad[1] = ra[ps][pg][1];
+                bd[0] = rb[ps][pg][0]; bd[1] = rb[ps][pg][1];
+            }
     };
 
     const int nk = (kHi - kLo + BK - 1) / BK;
     if (nk > 0) {
         load_tile(kLo);
-        store_tile(0);
+        store_tile(0, kLo);
     }
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
         if (t + 1 < nk) load_tile(kLo + (t + 1) * BK);
-        const double* as = As[buf];
-        const double* bs = Bs[buf];
+        const double* as = As + buf * BM * LDS_STRIDE;
+        const double* bs = Bs + buf * BN * LDS_STRIDE;
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             const int kcol = kk * 4 + (lane >> 4);
@@ -111,11 +146,13 @@ void gemm_nt_f64_kernel(GemmArgs g)
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (t + 1 < nk) store_tile(buf ^ 1);
+        if (t + 1 < nk) store_tile(buf ^ 1, kLo + (t + 1) * BK);
         __syncthreads();
     }
 
     // epilogue.  f64 16x16x4 accumulator layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+    // (the mirror stores are 8 bytes at stride ldcm; transposing the block through LDS first made no
+    // measurable difference to the inverse)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -268,7 +305,18 @@ struct Arena {
 int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
 {
     dim3 grid(g.N / BN, g.M / BM);
-    hipLaunchKernelGGL(gemm_nt_f64_kernel, grid, dim3(256), 0, ctx->stream, g);
+    static const int deepMaxTiles = getenv("DCA_GEMM_DEEP_MAX_TILES") ? atoi(getenv("DCA_GEMM_DEEP_MAX_TILES")) : 400;
+    if ((long long)grid.x * grid.y <= deepMaxTiles) {       // under two workgroups per CU: latency bound (measured: 0 -> 37.7, 128 -> 37.0, 400 -> 36.4, 1600 -> 36.9 ms)
+        static bool attr = false;
+        if (!attr) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)gemm_lds_bytes<64>()));
+            attr = true;
+        }
+        hipLaunchKernelGGL(gemm_nt_f64_kernel<64>, grid, dim3(256), gemm_lds_bytes<64>(), ctx->stream, g);
+    } else {
+        hipLaunchKernelGGL(gemm_nt_f64_kernel<16>, grid, dim3(256), gemm_lds_bytes<16>(), ctx->stream, g);
+    }
     return DCA_OK;
 }
 
@@ -294,6 +342,8 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     DCA_TRY(launch_gemm(ctx, GemmArgs{L21, n1, MASK_NONE, L21, n1, MASK_NONE, M22, ld, nullptr, 0, n2, n2, n1, -1.0, 1.0, 1}));
     DCA_TRY(cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo));
     // T^T[j][i] = sum_k X11^T[j][k] * L21[i][k];  X11^T rows are the mirrored upper part of M11 (k >= j)
+    // (running this product on a side stream next to the A22 subtree was tried and gained nothing:
+    // profiles/experiments/cholinv_gemm128_v2_and_overlap.hip.txt)
     DCA_TRY(launch_gemm(ctx, GemmArgs{M11, ld, MASK_UPPER, L21, n1, MASK_NONE, Tt, n2, nullptr, 0, n1, n2, n1, 1.0, 0.0, 0}));
     // X21[i][j] = -sum_k X22[i][k] * T^T[j][k];  X22 lower (k <= i); mirrored into the (1,2) block
     DCA_TRY(launch_gemm(ctx, GemmArgs{M22, ld, MASK_LOWER, Tt, n2, MASK_NONE, M21, ld, M12, ld, n2, n1, n2, -1.0, 0.0, 0}));

@@ -8,6 +8,13 @@
 void dca_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); }
 void dca_flush_clocks(dca_ctx*) {}
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+__global__ void fill_kernel(double* p, size_t n, unsigned seed)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (double)(h & 0xffffff) / 16777216.0 - 0.5;
+    }
+}
 int main(int argc, char** argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 5056;
@@ -15,7 +22,10 @@ int main(int argc, char** argv)
     CHECK(hipStreamCreate(&ctx.stream));
     double *A, *B, *C;
     CHECK(hipMalloc(&A, (size_t)n * n * 8)); CHECK(hipMalloc(&B, (size_t)n * n * 8)); CHECK(hipMalloc(&C, (size_t)n * n * 8));
-    CHECK(hipMemset(A, 0, (size_t)n * n * 8)); CHECK(hipMemset(B, 0, (size_t)n * n * 8));
+    // non-trivial operand values: an all-zero GEMM draws less power and clocks higher than the real thing
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, ctx.stream, A, (size_t)n * n, 1u);
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, ctx.stream, B, (size_t)n * n, 2u);
+    CHECK(hipStreamSynchronize(ctx.stream));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     struct Case { const char* name; int maskA, maskB, lower; double flops; } cases[] = {
         {"plain NT", MASK_NONE, MASK_NONE, 0, 2.0 * n * (double)n * n},
