@@ -23,11 +23,15 @@ for rep in range(a.reps):
     ctx = _lib.Context(0, _lib.DCA_F64)
     t0 = time.perf_counter()
     ctx.set_msa(X, a.q)
+    t1 = time.perf_counter()
     ctx.set_profiling(True)
     ctx.compute_weights(0.8, _lib.DCA_F64)
+    t2 = time.perf_counter()
     scores = ctx.mf_run(0.5, True)
+    t3 = time.perf_counter()
     order = ctx.scores_order()
     dt = time.perf_counter() - t0
     print("rep", rep, "total %.1f ms" % (dt * 1e3), {k: round(ctx.kernel_time(k)[0], 2) for k in ("weights", "mf_counts", "mf_inverse", "scores")},
-          "pairs/s %.0f" % (a.L * (a.L - 1) / 2 / dt))
+          "pairs/s %.0f" % (a.L * (a.L - 1) / 2 / dt),
+          "host ms: set_msa %.1f weights %.1f mf_run %.1f order %.1f" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t0 + dt - t3) * 1e3))
     ctx.close()
