@@ -47,6 +47,9 @@ typedef struct dca_ctx dca_ctx;
 const char* dca_last_error(void);
 int dca_device_count(void);
 const char* dca_version(void);
+/* Device blocks of 1 MiB and more are kept in a process-wide cache when a context releases them and are handed to
+ * later contexts (DCA_POOL_MAX_BYTES, default 64 GiB per process).  This returns them to the driver; result: bytes released. */
+size_t dca_release_cached_memory(void);
 
 /* ------------------------------------------------------------------ drop-in FFI
  * Same symbols, signatures and meaning as the reference's ctypes boundary

@@ -60,6 +60,7 @@ def lib():
         "dca_last_error": (C.c_char_p, []),
         "dca_version": (C.c_char_p, []),
         "dca_device_count": (i, []),
+        "dca_release_cached_memory": (sz, []),
         "dca_read_msa": (i, [C.c_char_p, i, i, vp, i, C.POINTER(i)]),
         "dca_count_msa_lines": (i, [C.c_char_p]),
         "dca_create": (i, [C.POINTER(vp), i, i]),
@@ -116,7 +117,7 @@ def lib():
     return L
 
 
-EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_read_msa", "dca_count_msa_lines", "dca_create",
+EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_num_params", "dca_plm_init_x",
            "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_di_from_arrays", "dca_plm_set_vector_sharding",
@@ -126,6 +127,11 @@ EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_read_msa", 
            "dca_mf_pair_site_freqs", "dca_mf_corr_mat", "dca_mf_couplings", "dca_mf_scores", "dca_mf_run",
            "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_sw_scores", "dca_sw_align", "dca_scores_order", "dca_set_profiling", "dca_get_kernel_time",
            "dca_reset_kernel_times", "plmdcaBackend", "freeFieldsAndCouplings"]
+
+
+def release_cached_memory():
+    """Return the library's cached device blocks (>= 1 MiB, kept across contexts) to the driver -> bytes released."""
+    return int(lib().dca_release_cached_memory())
 
 
 def check(rc):

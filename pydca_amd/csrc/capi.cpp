@@ -27,6 +27,97 @@ void dca_flush_clocks(dca_ctx* ctx)
     }
 }
 
+// ---- device block cache (declared in dca_internal.h)
+#include <mutex>
+#include <unordered_map>
+namespace {
+struct DevBlock { void* p; size_t bytes; int device; };
+struct DevPool {
+    std::mutex mu;
+    std::unordered_map<void*, DevBlock> live;     // blocks handed out that are eligible for caching
+    std::vector<DevBlock> cached;
+    size_t cachedBytes = 0;
+    size_t maxBytes = getenv("DCA_POOL_MAX_BYTES") ? strtoull(getenv("DCA_POOL_MAX_BYTES"), nullptr, 10) : ((size_t)64 << 30);
+    void release_all() {          // caller holds mu
+        for (auto& b : cached) { hipSetDevice(b.device); hipFree(b.p); }
+        cached.clear(); cachedBytes = 0;
+    }
+};
+DevPool& pool() { static DevPool* p = new DevPool(); return *p; }   // never destroyed: the HIP runtime may be gone at exit
+constexpr size_t kPoolMinBytes = (size_t)1 << 20;
+}  // namespace
+
+hipError_t dca_dev_malloc(void** out, size_t bytes)
+{
+    *out = nullptr;
+    if (bytes < kPoolMinBytes) return hipMalloc(out, bytes);
+    int dev = 0;
+    hipGetDevice(&dev);
+    DevPool& P = pool();
+    void* hit = nullptr;
+    size_t hitBytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        int best = -1;
+        for (int i = 0; i < (int)P.cached.size(); ++i) {
+            const DevBlock& b = P.cached[i];
+            if (b.device != dev || b.bytes < bytes || b.bytes > bytes + bytes / 4) continue;
+            if (best < 0 || b.bytes < P.cached[best].bytes) best = i;
+        }
+        if (best >= 0) {
+            hit = P.cached[best].p; hitBytes = P.cached[best].bytes;
+            P.cachedBytes -= hitBytes;
+            P.cached.erase(P.cached.begin() + best);
+            P.live[hit] = DevBlock{hit, hitBytes, dev};
+        }
+    }
+    if (hit) {
+        // a fresh hipMalloc block reads as zeros; keep that for recycled ones (the copy engine fills > 3 TB/s)
+        hipError_t e = hipMemsetAsync(hit, 0, bytes, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) return e;
+        *out = hit;
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {        // out of memory: give the cache back and try once more
+        (void)hipGetLastError();
+        { std::lock_guard<std::mutex> lk(P.mu); P.release_all(); }
+        e = hipMalloc(out, bytes);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.live[*out] = DevBlock{*out, bytes, dev};
+    return hipSuccess;
+}
+
+hipError_t dca_dev_free(void* p)
+{
+    if (!p) return hipSuccess;
+    DevPool& P = pool();
+    DevBlock b{nullptr, 0, 0};
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.live.find(p);
+        if (it != P.live.end()) { b = it->second; P.live.erase(it); }
+    }
+    if (!b.p) return hipFree(p);
+    // same guarantee as hipFree: nothing on the device still uses the block when this returns
+    int cur = 0;
+    hipGetDevice(&cur);
+    if (cur != b.device) hipSetDevice(b.device);
+    hipError_t e = hipDeviceSynchronize();
+    if (cur != b.device) hipSetDevice(cur);
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (e != hipSuccess || P.cachedBytes + b.bytes > P.maxBytes) {
+        hipSetDevice(b.device); hipError_t f = hipFree(b.p); hipSetDevice(cur);
+        return f;
+    }
+    P.cached.push_back(b);
+    P.cachedBytes += b.bytes;
+    return hipSuccess;
+}
+
 #define CHECK_CTX(ctx)                                             \
     do {                                                           \
         if (!(ctx)) { dca_set_error("null context"); return DCA_ERR_ARG; } \
@@ -56,6 +147,18 @@ extern "C" {
 
 const char* dca_last_error(void) { return g_err; }
 const char* dca_version(void) { return "pydca_amd libdca_hip 0.1 (gfx950)"; }
+
+size_t dca_release_cached_memory(void)
+{
+    DevPool& P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    const size_t n = P.cachedBytes;
+    int cur = 0;
+    hipGetDevice(&cur);
+    P.release_all();
+    hipSetDevice(cur);
+    return n;
+}
 
 int dca_device_count(void)
 {
@@ -110,7 +213,7 @@ int dca_create(dca_ctx** out, int device, int precision)
     ctx->device = device;
     ctx->precision = precision;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dScal), 64 * sizeof(double)));
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&ctx->dScal), 64 * sizeof(double)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->hScal), 64 * sizeof(double), hipHostMallocDefault));
     *out = ctx;
     return DCA_OK;
@@ -120,10 +223,10 @@ static void free_msa(dca_ctx* ctx)
 {
     delete ctx->plm; ctx->plm = nullptr;
     if (ctx->mf) { dca_free_mf_engine(ctx->mf); ctx->mf = nullptr; }
-    hipFree(ctx->dX); ctx->dX = nullptr;
-    hipFree(ctx->dCounts); ctx->dCounts = nullptr;
-    hipFree(ctx->dWd); ctx->dWd = nullptr;
-    hipFree(ctx->dLastScores); ctx->dLastScores = nullptr; ctx->nLastScores = 0;
+    dca_dev_free(ctx->dX); ctx->dX = nullptr;
+    dca_dev_free(ctx->dCounts); ctx->dCounts = nullptr;
+    dca_dev_free(ctx->dWd); ctx->dWd = nullptr;
+    dca_dev_free(ctx->dLastScores); ctx->dLastScores = nullptr; ctx->nLastScores = 0;
     ctx->hX.clear();
     ctx->have_weights = ctx->have_counts = false;
 }
@@ -135,13 +238,13 @@ const uint8_t* dca_host_msa(dca_ctx* ctx)
     if (ctx->hX.empty() && ctx->dX) {
         ctx->hX.resize((size_t)ctx->N * ctx->L);
         uint8_t* dTmp = nullptr;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dTmp), ctx->hX.size());
+        hipError_t e = dca_dev_malloc(reinterpret_cast<void**>(&dTmp), ctx->hX.size());
         if (e == hipSuccess) {
             hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((ctx->hX.size() + 255) / 256)), dim3(256), 0, ctx->stream,
                                ctx->dX, dTmp, ctx->N, ctx->L, ctx->Ls);
             e = hipStreamSynchronize(ctx->stream);
             if (e == hipSuccess) e = hipMemcpy(ctx->hX.data(), dTmp, ctx->hX.size(), hipMemcpyDeviceToHost);
-            hipFree(dTmp);
+            dca_dev_free(dTmp);
         }
         if (e != hipSuccess) {
             ctx->hX.clear();
@@ -155,8 +258,8 @@ const uint8_t* dca_host_msa(dca_ctx* ctx)
 int dca_remember_scores(dca_ctx* ctx, const double* dScores, int n)
 {
     if (ctx->nLastScores != n) {
-        hipFree(ctx->dLastScores); ctx->dLastScores = nullptr; ctx->nLastScores = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dLastScores), (size_t)n * sizeof(double)));
+        dca_dev_free(ctx->dLastScores); ctx->dLastScores = nullptr; ctx->nLastScores = 0;
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&ctx->dLastScores), (size_t)n * sizeof(double)));
         ctx->nLastScores = n;
     }
     HIP_TRY(hipMemcpyAsync(ctx->dLastScores, dScores, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -172,7 +275,7 @@ void dca_destroy(dca_ctx* ctx)
     hipStreamSynchronize(ctx->stream);
     dca_flush_clocks(ctx);
     free_msa(ctx);
-    hipFree(ctx->dScal);
+    dca_dev_free(ctx->dScal);
     hipHostFree(ctx->hScal);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -198,21 +301,21 @@ int dca_set_msa(dca_ctx* ctx, const uint8_t* X, int N, int L, int q)
     ctx->Ls = (int)round_up((size_t)L, 128);
     ctx->hX.clear();                                       // host copy is made on demand (dca_host_msa)
     // one contiguous copy + a repack kernel (a pitched hipMemcpy2D of narrow rows takes seconds)
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dX), (size_t)N * ctx->Ls));
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&ctx->dX), (size_t)N * ctx->Ls));
     {
         uint8_t* dTmp = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dTmp), (size_t)N * L));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dTmp), (size_t)N * L));
         hipError_t e = hipMemcpy(dTmp, X, (size_t)N * L, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             const size_t total = (size_t)N * ctx->Ls;
             hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dTmp, ctx->dX, N, L, ctx->Ls);
             e = hipStreamSynchronize(ctx->stream);
         }
-        hipFree(dTmp);
+        dca_dev_free(dTmp);
         if (e != hipSuccess) { dca_set_error("uploading the alignment: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dCounts), (size_t)N * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->dWd), (size_t)N * sizeof(double)));
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&ctx->dCounts), (size_t)N * sizeof(uint32_t)));
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&ctx->dWd), (size_t)N * sizeof(double)));
     return DCA_OK;
 }
 
@@ -373,8 +476,8 @@ int dca_spd_inverse(dca_ctx* ctx, const double* A, int n, double* Ainv_out)
     for (int r = 0; r < n; ++r) memcpy(padded.data() + (size_t)r * np, A + (size_t)r * n, (size_t)n * sizeof(double));
     for (int r = n; r < np; ++r) padded[(size_t)r * np + r] = 1.0;
     double *dA = nullptr, *dWork = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dA), padded.size() * sizeof(double)));
-    if (hipMalloc(reinterpret_cast<void**>(&dWork), 2 * padded.size() * sizeof(double)) != hipSuccess) { hipFree(dA); dca_set_error("out of device memory"); return DCA_ERR_NOMEM; }
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dA), padded.size() * sizeof(double)));
+    if (dca_dev_malloc(reinterpret_cast<void**>(&dWork), 2 * padded.size() * sizeof(double)) != hipSuccess) { dca_dev_free(dA); dca_set_error("out of device memory"); return DCA_ERR_NOMEM; }
     int info = 0;
     int rc = DCA_OK;
     if (hipMemcpy(dA, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = DCA_ERR_HIP;
@@ -384,7 +487,7 @@ int dca_spd_inverse(dca_ctx* ctx, const double* A, int n, double* Ainv_out)
         if (hipMemcpy(padded.data(), dA, padded.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = DCA_ERR_HIP;
         else for (int r = 0; r < n; ++r) memcpy(Ainv_out + (size_t)r * n, padded.data() + (size_t)r * np, (size_t)n * sizeof(double));
     }
-    hipFree(dA); hipFree(dWork);
+    dca_dev_free(dA); dca_dev_free(dWork);
     return rc;
 }
 

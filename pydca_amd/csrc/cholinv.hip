@@ -24,6 +24,8 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 enum { MASK_NONE = 0, MASK_LOWER = 1 /* k <= row */, MASK_UPPER = 2 /* k >= row */ };
 
+enum { WALK_ROWS = 0, WALK_ROWS_REVERSED = 1 /* lower triangular A */, WALK_COLUMNS_REVERSED = 2 /* lower triangular B; grid transposed */ };
+
 constexpr int BM = 64, BN = 64;
 
 struct GemmArgs {
@@ -34,6 +36,8 @@ struct GemmArgs {
     int M, N, K;
     double alpha, beta;
     int lowerOnly;                 // square output: only tiles with tj <= ti; strict mirror rule on the diagonal
+    int walk;                      // order in which the tiles are started, so that with a triangular operand the tiles with the
+                                   // longest k range are not the ones that start last (WALK_*)
 };
 
 // BK = 16: the throughput form (35 KB of LDS, three workgroups per CU).  BK = 64: for the many products of
@@ -51,7 +55,8 @@ void gemm_nt_f64_kernel(GemmArgs g)
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];
     double* const As = reinterpret_cast<double*>(dca_gemm_smem);      // [2][BM * LDS_STRIDE]
     double* const Bs = As + 2 * BM * LDS_STRIDE;                      // [2][BN * LDS_STRIDE]
-    const int ti = blockIdx.y, tj = blockIdx.x;
+    const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int tj = g.walk == WALK_COLUMNS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x;
     if (g.lowerOnly && tj > ti) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -171,116 +176,179 @@ void gemm_nt_f64_kernel(GemmArgs g)
 }
 
 // 64x64 leaf: A (lower triangle valid) -> X = inv(chol(A)), written lower + mirrored upper.
-// One workgroup of 16 x 16 threads; thread (ty, tx) keeps the 4 x 4 block rows 4ty.., columns 4tx..
-// in registers, so a step of either phase is: read one column / row vector from LDS, 16 FMAs on
-// registers, publish the next vector, ONE barrier (the vectors are double buffered).
-//  * Cholesky, right-looking: step k uses the unscaled column a_ik and 1/a_kk
-//    (a_ij -= a_ik a_jk / a_kk); the owners of column k store l_ik = a_ik / sqrt(a_kk) to LDS.
-//  * X = L^-1 by right-looking forward substitution on B = I: row k of X is final before step k
-//    (x_kj = b_kj / l_kk), then b_ij -= l_ik x_kj for the rows below.  X replaces B in registers.
-// The scaling by 1/sqrt(a_kk) is applied to all columns at once after the factorisation loop.
+// One workgroup of 16 x 16 threads; thread (ty, tx) keeps the 4 x 4 block rows 4ty.., columns 4tx.. in
+// registers.  Both phases advance one 4-wide block column / block row per step (16 steps each, two and one
+// barriers per step) instead of one column per step: the time of a leaf is its chain of barriers and LDS
+// round trips, not its flops.
+//  * Cholesky, right-looking by blocks: the thread on the diagonal factors its 4 x 4 block in registers
+//    (reciprocal square roots by v_rsq_f64 + Newton steps) and publishes the inverse of that triangle; the
+//    threads of the block column turn their blocks into L (a product with that inverse), publish the
+//    64 x 4 panel; every thread subtracts the rank-4 update from its block (64 FMAs).
+//  * X = L^-1 by forward substitution on B = I by blocks: block row k of X is the published inverse of the
+//    diagonal triangle times block row k of B; the rows below subtract L(i,k) * X(k,:).
+__device__ __forceinline__ double rsqrt_refined(double a)
+{
+    double y = __builtin_amdgcn_rsq(a);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const double h = 0.5 * y;
+        const double e = __builtin_fma(-a * y, y, 1.0);     // 1 - a y^2
+        y = __builtin_fma(h, e, y);
+    }
+    return y;
+}
+
 __global__ __launch_bounds__(256)
 void cholinv_leaf_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info)
 {
-    constexpr int n = 64, S = 65;
-    __shared__ double Lf[n * S];          // L, row-major; upper triangle and diagonal end up zero
-    __shared__ double vec[2][n];          // column k of A below the diagonal / row k of X, double buffered
-    __shared__ double piv[2];             // a_kk of the published column
-    __shared__ double invd[n];            // a_kk, later 1 / l_kk
+    constexpr int n = 64, S = 66;
+    __shared__ __attribute__((aligned(16))) double Lf[n * S];         // L below the diagonal blocks, row-major
+    __shared__ __attribute__((aligned(16))) double panel[2][n][4];    // block column k of L (zero for rows above it)
+    __shared__ __attribute__((aligned(16))) double xrow[2][4][n];     // block row k of X (zero right of the diagonal block)
+    __shared__ __attribute__((aligned(16))) double dinv[16][16];      // inverse of the diagonal triangles, 4 x 4 row-major
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
     const int r0 = 4 * ty, c0 = 4 * tx;
 
-    // Every step is branch-free on the element level: the published vectors carry zeros where an
-    // update must not happen, so each thread does 4 multiplies + 16 FMAs on its register block.
     double a[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a[r][c] = (c0 + c <= r0 + r) ? M[(size_t)(r0 + r) * ld + c0 + c] : 0.0;
-    if (tx == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vec[0][r0 + r] = (r0 + r > 0) ? a[r][0] : 0.0;
-        if (ty == 0) piv[0] = a[0][0];
-    }
-    __syncthreads();
-    for (int kb = 0; kb < 16; ++kb) {
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            const int k = 4 * kb + kc, cur = k & 1;
-            const double akk = piv[cur];
-            if (tid == 0 && !(akk > 0.0)) atomicCAS(info, 0, pivotBase + k + 1);
-            // 1/a_kk: hardware reciprocal + two Newton steps (a full-precision divide and the sqrt of the
-            // scaling would sit on the critical path of every step; the scaling is applied after the loop)
-            double inv = __builtin_amdgcn_rcp(akk);
-            inv = inv * (2.0 - akk * inv);
-            inv = inv * (2.0 - akk * inv);
-            if (tx == kb) {               // column k is final: keep it unscaled for now
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Lf[(r0 + r) * S + k] = a[r][kc];
-                if (ty == kb) invd[k] = akk;
-            }
-            double ai[4], aj[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ai[r] = vec[cur][r0 + r] * inv;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) aj[c] = vec[cur][c0 + c];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) a[r][c] -= ai[r] * aj[c];
-            if (k + 1 < n && tx == (k + 1) / 4) {
-                const int cc = (k + 1) & 3;   // static after unrolling
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vec[cur ^ 1][r0 + r] = (r0 + r > k + 1) ? a[r][cc] : 0.0;
-                if (ty == (k + 1) / 4) piv[cur ^ 1] = a[cc][cc];
-            }
-            __syncthreads();
-        }
-    }
-    // l_ik = a_ik / sqrt(a_kk) below the diagonal, zero elsewhere; 1 / l_kk
-    if (tid < n) invd[tid] = 1.0 / sqrt(invd[tid]);
-    __syncthreads();
+    // diagonal threads need their full symmetric block, the others their block as stored (lower part of A valid)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const double v = Lf[(r0 + r) * S + c0 + c] * invd[c0 + c];
-            Lf[(r0 + r) * S + c0 + c] = (c0 + c < r0 + r) ? v : 0.0;
+            const int i = r0 + r, j = c0 + c;
+            a[r][c] = (tx < ty) ? M[(size_t)i * ld + j] : (tx == ty) ? M[(size_t)max(i, j) * ld + min(i, j)] : 0.0;
         }
-    __syncthreads();
+
+    for (int kb = 0; kb < 16; ++kb) {
+        const int cur = kb & 1;
+        if (ty == kb && tx == kb) {
+            double l[4][4], xi[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { l[r][c] = 0.0; xi[r][c] = 0.0; }
+            double rs[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double akk = a[k][k];
+                if (!(akk > 0.0)) atomicCAS(info, 0, pivotBase + 4 * kb + k + 1);
+                rs[k] = rsqrt_refined(akk);
+                l[k][k] = akk * rs[k];
+#pragma unroll
+                for (int r = k + 1; r < 4; ++r) l[r][k] = a[r][k] * rs[k];
+#pragma unroll
+                for (int r = k + 1; r < 4; ++r)
+#pragma unroll
+                    for (int c = k + 1; c <= r; ++c) a[r][c] = __builtin_fma(-l[r][k], l[c][k], a[r][c]);
+            }
+            // inverse of the lower triangle l
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                xi[c][c] = rs[c];
+#pragma unroll
+                for (int r = c + 1; r < 4; ++r) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int m = c; m < r; ++m) acc = __builtin_fma(l[r][m], xi[m][c], acc);
+                    xi[r][c] = -rs[r] * acc;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dinv[kb][r * 4 + c] = xi[r][c];
+        }
+        __syncthreads();
+        if (tx == kb) {
+            double lb[4][4];
+            if (ty > kb) {
+                double xi[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xi[r][c] = dinv[kb][r * 4 + c];
+                // L(ty,kb) = A(ty,kb) * inv(L(kb,kb))^T
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int c = 0; c <= m; ++c) acc = __builtin_fma(a[r][c], xi[m][c], acc);
+                        lb[r][m] = acc;
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) lb[r][m] = 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    panel[cur][r0 + r][m] = lb[r][m];
+                    Lf[(r0 + r) * S + 4 * kb + m] = lb[r][m];
+                }
+        }
+        __syncthreads();
+        if (ty > kb && tx > kb) {
+            double pr[4][4], pc[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { pr[r][m] = panel[cur][r0 + r][m]; pc[r][m] = panel[cur][c0 + r][m]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a[r][c] = __builtin_fma(-pr[r][m], pc[c][m], a[r][c]);
+        }
+    }
+
     // ---- X = L^-1
     double b[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) b[r][c] = (r0 + r == c0 + c) ? 1.0 : 0.0;
-    if (ty == 0) {
-        const double id = invd[0];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { b[0][c] *= id; vec[0][c0 + c] = b[0][c]; }
-    }
-    __syncthreads();
     for (int kb = 0; kb < 16; ++kb) {
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            const int k = 4 * kb + kc, cur = k & 1;
-            double li[4], xk[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) li[r] = Lf[(r0 + r) * S + k];       // zero for rows <= k
-#pragma unroll
-            for (int c = 0; c < 4; ++c) xk[c] = vec[cur][c0 + c];           // zero for columns > k
+        const int cur = kb & 1;
+        if (ty == kb) {
+            double xi[4][4], x[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) b[r][c] -= li[r] * xk[c];
-            if (k + 1 < n && ty == (k + 1) / 4) {   // row k+1 of B is final: scale it, publish it
-                const int rr = (k + 1) & 3;
-                const double id = invd[k + 1];
+                for (int c = 0; c < 4; ++c) xi[r][c] = dinv[kb][r * 4 + c];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { b[rr][c] *= id; vec[cur ^ 1][c0 + c] = b[rr][c]; }
-            }
-            __syncthreads();
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int m = 0; m <= r; ++m) acc = __builtin_fma(xi[r][m], b[m][c], acc);
+                    x[r][c] = acc;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { b[r][c] = x[r][c]; xrow[cur][r][c0 + c] = x[r][c]; }
+        }
+        __syncthreads();
+        if (ty > kb && tx <= kb) {
+            double lb[4][4], xr[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { lb[r][m] = Lf[(r0 + r) * S + 4 * kb + m]; xr[r][m] = xrow[cur][r][c0 + m]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) b[r][c] = __builtin_fma(-lb[r][m], xr[m][c], b[r][c]);
         }
     }
     if (tx <= ty) {
@@ -305,6 +373,7 @@ struct Arena {
 int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
 {
     dim3 grid(g.N / BN, g.M / BM);
+    if (g.walk == WALK_COLUMNS_REVERSED) grid = dim3(g.M / BM, g.N / BN);
     static const int deepMaxTiles = getenv("DCA_GEMM_DEEP_MAX_TILES") ? atoi(getenv("DCA_GEMM_DEEP_MAX_TILES")) : 400;
     if ((long long)grid.x * grid.y <= deepMaxTiles) {       // under two workgroups per CU: latency bound (measured: 0 -> 37.7, 128 -> 37.0, 400 -> 36.4, 1600 -> 36.9 ms)
         static bool attr = false;
@@ -337,7 +406,7 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     double* Tt = ws.alloc((size_t)n1 * n2);
     if (!L21 || !Tt) { dca_set_error("cholinv workspace exhausted"); return DCA_ERR_NOMEM; }
     // L21 = A21 * X11^T : C[i][j] = sum_k A21[i][k] * X11[j][k],  X11 lower (k <= j)
-    DCA_TRY(launch_gemm(ctx, GemmArgs{M21, ld, MASK_NONE, M11, ld, MASK_LOWER, L21, n1, nullptr, 0, n2, n1, n1, 1.0, 0.0, 0}));
+    DCA_TRY(launch_gemm(ctx, GemmArgs{M21, ld, MASK_NONE, M11, ld, MASK_LOWER, L21, n1, nullptr, 0, n2, n1, n1, 1.0, 0.0, 0, WALK_COLUMNS_REVERSED}));
     // A22 -= L21 * L21^T (lower tiles)
     DCA_TRY(launch_gemm(ctx, GemmArgs{L21, n1, MASK_NONE, L21, n1, MASK_NONE, M22, ld, nullptr, 0, n2, n2, n1, -1.0, 1.0, 1}));
     DCA_TRY(cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo));
@@ -346,7 +415,7 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     // profiles/experiments/cholinv_gemm128_v2_and_overlap.hip.txt)
     DCA_TRY(launch_gemm(ctx, GemmArgs{M11, ld, MASK_UPPER, L21, n1, MASK_NONE, Tt, n2, nullptr, 0, n1, n2, n1, 1.0, 0.0, 0}));
     // X21[i][j] = -sum_k X22[i][k] * T^T[j][k];  X22 lower (k <= i); mirrored into the (1,2) block
-    DCA_TRY(launch_gemm(ctx, GemmArgs{M22, ld, MASK_LOWER, Tt, n2, MASK_NONE, M21, ld, M12, ld, n2, n1, n2, -1.0, 0.0, 0}));
+    DCA_TRY(launch_gemm(ctx, GemmArgs{M22, ld, MASK_LOWER, Tt, n2, MASK_NONE, M21, ld, M12, ld, n2, n1, n2, -1.0, 0.0, 0, WALK_ROWS_REVERSED}));
     ws.top = mark;
     return DCA_OK;
 }
@@ -358,7 +427,7 @@ int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* 
     if (n % 64 != 0 || n <= 0) { dca_set_error("dca_spd_inverse_device: n must be a positive multiple of 64"); return DCA_ERR_ARG; }
     ScopedKernelClock kc(ctx, "mf_inverse");
     int* dInfo = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dInfo), sizeof(int)));
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dInfo), sizeof(int)));
     HIP_TRY(hipMemsetAsync(dInfo, 0, sizeof(int), ctx->stream));
     Arena ws{dWork, (size_t)n * n};
     int rc = cholinv_rec(ctx, dA, n, n, 0, ws, dInfo);
@@ -374,7 +443,7 @@ int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* 
     int info = 0;
     hipError_t e = hipMemcpyAsync(&info, dInfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(dInfo);
+    dca_dev_free(dInfo);
     if (e != hipSuccess) { dca_set_error("cholinv: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     if (info_out) *info_out = info;
     return rc;

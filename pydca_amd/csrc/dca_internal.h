@@ -30,6 +30,13 @@ void dca_set_error(const char* fmt, ...);
         if (_rc != DCA_OK) return _rc; \
     } while (0)
 
+// ---- capi.cpp : device allocations.  Blocks of at least 1 MiB go back to a process-wide, per-device cache
+// when they are freed and later requests of a similar size are served from it (zero-filled), because
+// hipMalloc / hipFree of GB-sized blocks costs tens of milliseconds per call on some hosts -- more than
+// the whole mfDCA chain.  dca_dev_free waits for the device like hipFree does.
+hipError_t dca_dev_malloc(void** p, size_t bytes);
+hipError_t dca_dev_free(void* p);
+
 static inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

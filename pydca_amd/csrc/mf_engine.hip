@@ -261,7 +261,7 @@ struct MfEngine {
     double* dRegFi = nullptr;
     dca_reduce_hook hook = nullptr;   // sequence sharding: sums Craw and Meff over the shards
     void* hook_user = nullptr;
-    ~MfEngine() { hipFree(dRegFi); hipFree(dPerm); hipFree(dOff); hipFree(dXT); hipFree(dDom); hipFree(dCnt1); hipFree(dCraw); hipFree(dFi); hipFree(dC); hipFree(dJ); hipFree(dWork); }
+    ~MfEngine() { dca_dev_free(dRegFi); dca_dev_free(dPerm); dca_dev_free(dOff); dca_dev_free(dXT); dca_dev_free(dDom); dca_dev_free(dCnt1); dca_dev_free(dCraw); dca_dev_free(dFi); dca_dev_free(dC); dca_dev_free(dJ); dca_dev_free(dWork); }
 };
 
 MfEngine* dca_make_mf_engine(dca_ctx* ctx)
@@ -282,13 +282,13 @@ static int mf_counts(MfEngine* m)
     if (m->q > 32) { dca_set_error("q too large"); return DCA_ERR_ARG; }
     const int Nt = (int)round_up((size_t)m->N, 64);
     if (!m->dPerm) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dPerm), (size_t)m->L * m->N * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dOff), (size_t)m->L * (m->q + 1) * sizeof(int)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dCraw), (size_t)m->Lq * m->Lq * sizeof(double)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dFi), (size_t)m->Lq * sizeof(double)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dXT), (size_t)m->L * Nt));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dDom), (size_t)m->L));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dCnt1), (size_t)m->Lq * sizeof(double)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dPerm), (size_t)m->L * m->N * sizeof(uint32_t)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dOff), (size_t)m->L * (m->q + 1) * sizeof(int)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dCraw), (size_t)m->Lq * m->Lq * sizeof(double)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dFi), (size_t)m->Lq * sizeof(double)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dXT), (size_t)m->L * Nt));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dDom), (size_t)m->L));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dCnt1), (size_t)m->Lq * sizeof(double)));
     }
     {
         ScopedKernelClock kc(ctx, "mf_sort");
@@ -336,11 +336,11 @@ int dca_mf_engine_pair_freqs(MfEngine* m, double* fij_out)
     const int qm = m->q - 1;
     const size_t total = (size_t)m->L * (m->L - 1) / 2 * qm * qm;
     double* dOut = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), total * sizeof(double)));
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dOut), total * sizeof(double)));
     hipLaunchKernelGGL(mf_fij_export_kernel, dim3(m->L, m->L), dim3(64), 0, m->ctx->stream, m->dCraw, dOut, m->L, m->q, m->Lq, m->ctx->meff);
     hipError_t e = hipStreamSynchronize(m->ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(fij_out, dOut, total * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(dOut);
+    dca_dev_free(dOut);
     if (e != hipSuccess) { dca_set_error("pair freqs: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     return DCA_OK;
 }
@@ -358,7 +358,7 @@ int dca_mf_engine_corr(MfEngine* m, double theta, double* corr_out)
 {
     DCA_TRY(mf_counts(m));
     dca_ctx* ctx = m->ctx;
-    if (!m->dC) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dC), (size_t)m->np * m->np * sizeof(double)));
+    if (!m->dC) HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dC), (size_t)m->np * m->np * sizeof(double)));
     dim3 grid(ceil_div(m->np, 256), m->np);
     hipLaunchKernelGGL(mf_corr_kernel, grid, dim3(256), 0, ctx->stream, m->dCraw, m->dC, m->L, m->q, m->Lq, m->np, ctx->meff, theta);
     HIP_TRY(hipGetLastError());
@@ -375,8 +375,8 @@ int dca_mf_engine_couplings(MfEngine* m, double* out)
     dca_ctx* ctx = m->ctx;
     const size_t nn = (size_t)m->np * m->np;
     if (!m->dJ) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dJ), nn * sizeof(double)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dWork), 2 * nn * sizeof(double)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dJ), nn * sizeof(double)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dWork), 2 * nn * sizeof(double)));
     }
     HIP_TRY(hipMemcpyAsync(m->dJ, m->dC, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     int info = 0;
@@ -397,14 +397,14 @@ int dca_mf_engine_scores(MfEngine* m, int apc, double* out)
     if (!m->have_J) { dca_set_error("dca_mf_couplings first"); return DCA_ERR_STATE; }
     const size_t npairs = (size_t)m->L * (m->L - 1) / 2;
     double* dOut = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
     int rc = dca_fn_scores(m->ctx, m->dJ, 1, DCA_F64, m->L, m->q, m->np, apc, dOut);
     if (rc == DCA_OK) {
         hipError_t e = hipStreamSynchronize(m->ctx->stream);
         if (e == hipSuccess) e = hipMemcpy(out, dOut, npairs * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { dca_set_error("scores: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
     }
-    hipFree(dOut);
+    dca_dev_free(dOut);
     return rc;
 }
 
@@ -417,9 +417,9 @@ extern "C" int dca_mf_corr_from_freqs(dca_ctx* ctx, const double* reg_fi, const 
     const size_t nfij = (size_t)L * (L - 1) / 2 * qm * qm;
     double *dFi = nullptr, *dFij = nullptr, *dC = nullptr;
     int rc = DCA_OK;
-    if (hipMalloc(reinterpret_cast<void**>(&dFi), (size_t)L * q * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&dFij), nfij * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&dC), (size_t)n * n * sizeof(double)) != hipSuccess) {
+    if (dca_dev_malloc(reinterpret_cast<void**>(&dFi), (size_t)L * q * sizeof(double)) != hipSuccess ||
+        dca_dev_malloc(reinterpret_cast<void**>(&dFij), nfij * sizeof(double)) != hipSuccess ||
+        dca_dev_malloc(reinterpret_cast<void**>(&dC), (size_t)n * n * sizeof(double)) != hipSuccess) {
         dca_set_error("out of device memory");
         rc = DCA_ERR_NOMEM;
     }
@@ -432,7 +432,7 @@ extern "C" int dca_mf_corr_from_freqs(dca_ctx* ctx, const double* reg_fi, const 
         if (e == hipSuccess) e = hipMemcpy(corr_out, dC, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { dca_set_error("corr_from_freqs: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
     }
-    hipFree(dFi); hipFree(dFij); hipFree(dC);
+    dca_dev_free(dFi); dca_dev_free(dFij); dca_dev_free(dC);
     return rc;
 }
 
@@ -450,18 +450,18 @@ int dca_mf_engine_di(MfEngine* m, int apc, double* out)
 {
     if (!m->have_J) { dca_set_error("dca_mf_couplings first"); return DCA_ERR_STATE; }
     dca_ctx* ctx = m->ctx;
-    if (!m->dRegFi) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dRegFi), (size_t)m->Lq * sizeof(double)));
+    if (!m->dRegFi) HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dRegFi), (size_t)m->Lq * sizeof(double)));
     hipLaunchKernelGGL(mf_regfi_kernel, dim3(ceil_div(m->Lq, 256)), dim3(256), 0, ctx->stream, m->dFi, m->dRegFi, m->Lq, m->q, m->theta);
     const size_t npairs = (size_t)m->L * (m->L - 1) / 2;
     double* dOut = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
     int rc = dca_di_scores(ctx, m->dJ, 1, DCA_F64, m->dRegFi, m->L, m->q, m->np, apc, dOut);
     if (rc == DCA_OK) {
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess) e = hipMemcpy(out, dOut, npairs * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { dca_set_error("DI scores: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
     }
-    hipFree(dOut);
+    dca_dev_free(dOut);
     return rc;
 }
 
@@ -493,15 +493,15 @@ int dca_mf_engine_fields(MfEngine* m, double* out)
 {
     if (!m->have_J) { dca_set_error("dca_mf_couplings first"); return DCA_ERR_STATE; }
     dca_ctx* ctx = m->ctx;
-    if (!m->dRegFi) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->dRegFi), (size_t)m->Lq * sizeof(double)));
+    if (!m->dRegFi) HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dRegFi), (size_t)m->Lq * sizeof(double)));
     hipLaunchKernelGGL(mf_regfi_kernel, dim3(ceil_div(m->Lq, 256)), dim3(256), 0, ctx->stream, m->dFi, m->dRegFi, m->Lq, m->q, m->theta);
     const int n = m->L * (m->q - 1);
     double* dOut = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), (size_t)n * sizeof(double)));
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dOut), (size_t)n * sizeof(double)));
     hipLaunchKernelGGL(mf_fields_kernel, dim3(n), dim3(256), 0, ctx->stream, m->dJ, m->dRegFi, m->L, m->q, m->np, dOut);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, dOut, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(dOut);
+    dca_dev_free(dOut);
     if (e != hipSuccess) { dca_set_error("fields: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     return DCA_OK;
 }

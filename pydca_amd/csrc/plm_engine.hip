@@ -953,15 +953,15 @@ struct PlmEngine : PlmEngineBase {
 
     template <typename U> int dalloc(U** p, size_t n)
     {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(U)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(U)));
         return DCA_OK;
     }
     void freeall()
     {
-        hipFree(dx); hipFree(dg); hipFree(dxp); hipFree(dgp); hipFree(dd);
-        for (int i = 0; i < 5; ++i) { hipFree(dS[i]); hipFree(dY[i]); }
-        hipFree(dWt); hipFree(dSR); hipFree(dG); hipFree(dw); hipFree(dXL); hipFree(dXT2);
-        hipFree(dPairs); hipFree(dFxPart); hipFree(dRegPart); hipFree(dVecPart);
+        dca_dev_free(dx); dca_dev_free(dg); dca_dev_free(dxp); dca_dev_free(dgp); dca_dev_free(dd);
+        for (int i = 0; i < 5; ++i) { dca_dev_free(dS[i]); dca_dev_free(dY[i]); }
+        dca_dev_free(dWt); dca_dev_free(dSR); dca_dev_free(dG); dca_dev_free(dw); dca_dev_free(dXL); dca_dev_free(dXT2);
+        dca_dev_free(dPairs); dca_dev_free(dFxPart); dca_dev_free(dRegPart); dca_dev_free(dVecPart);
     }
     ~PlmEngine() override { freeall(); }
 
@@ -1504,7 +1504,7 @@ struct PlmEngine : PlmEngineBase {
         if (!configured) return DCA_ERR_STATE;
         const size_t npairs = (size_t)L * (L - 1) / 2;
         double* dOut = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
         int rc = dca_fn_scores(ctx, dx, 0, (int)sizeof(T) * 8, L, q, 0, apc, dOut);
         if (rc == DCA_OK) {
             // ctx->stream is non-blocking: the null-stream copy below does not wait for it
@@ -1512,7 +1512,7 @@ struct PlmEngine : PlmEngineBase {
             if (e == hipSuccess) e = hipMemcpy(out, dOut, npairs * sizeof(double), hipMemcpyDeviceToHost);
             if (e != hipSuccess) { dca_set_error("copy scores: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
         }
-        hipFree(dOut);
+        dca_dev_free(dOut);
         return rc;
     }
     // (q-1)x(q-1) blocks of the current x for selected pairs (compute_params, plmdca.py:345-434)
@@ -1528,8 +1528,8 @@ struct PlmEngine : PlmEngineBase {
         if (!configured) return DCA_ERR_STATE;
         const size_t npairs = (size_t)L * (L - 1) / 2;
         double *dOut = nullptr, *dFi = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
-        if (hipMalloc(reinterpret_cast<void**>(&dFi), (size_t)L * q * sizeof(double)) != hipSuccess) { hipFree(dOut); return DCA_ERR_NOMEM; }
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
+        if (dca_dev_malloc(reinterpret_cast<void**>(&dFi), (size_t)L * q * sizeof(double)) != hipSuccess) { dca_dev_free(dOut); return DCA_ERR_NOMEM; }
         int rc = DCA_OK;
         if (hipMemcpy(dFi, reg_fi, (size_t)L * q * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = DCA_ERR_HIP;
         if (rc == DCA_OK) rc = dca_di_scores(ctx, dx, 0, (int)sizeof(T) * 8, dFi, L, q, 0, apc, dOut);
@@ -1538,7 +1538,7 @@ struct PlmEngine : PlmEngineBase {
             if (e == hipSuccess) e = hipMemcpy(out, dOut, npairs * sizeof(double), hipMemcpyDeviceToHost);
             if (e != hipSuccess) { dca_set_error("copy DI scores: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
         }
-        hipFree(dOut); hipFree(dFi);
+        dca_dev_free(dOut); dca_dev_free(dFi);
         return rc;
     }
 };

@@ -25,18 +25,18 @@ int dca_scores_order_device(dca_ctx* ctx, const double* dScores, int n, int32_t*
     void* dTemp = nullptr;
     size_t tempBytes = 0;
     int rc = DCA_OK;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dKeysOut), (size_t)n * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dIdx), (size_t)n * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dIdxOut), (size_t)n * sizeof(int32_t));
+    hipError_t e = dca_dev_malloc(reinterpret_cast<void**>(&dKeysOut), (size_t)n * sizeof(double));
+    if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&dIdx), (size_t)n * sizeof(int32_t));
+    if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&dIdxOut), (size_t)n * sizeof(int32_t));
     if (e == hipSuccess) {
         hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, dIdx, n);
         e = rocprim::radix_sort_pairs_desc(nullptr, tempBytes, dScores, dKeysOut, dIdx, dIdxOut, (size_t)n, 0, 64, ctx->stream);
     }
-    if (e == hipSuccess) e = hipMalloc(&dTemp, std::max<size_t>(tempBytes, 16));
+    if (e == hipSuccess) e = dca_dev_malloc(&dTemp, std::max<size_t>(tempBytes, 16));
     if (e == hipSuccess) e = rocprim::radix_sort_pairs_desc(dTemp, tempBytes, dScores, dKeysOut, dIdx, dIdxOut, (size_t)n, 0, 64, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(order_out, dIdxOut, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { dca_set_error("ranking scores: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
-    hipFree(dKeysOut); hipFree(dIdx); hipFree(dIdxOut); hipFree(dTemp);
+    dca_dev_free(dKeysOut); dca_dev_free(dIdx); dca_dev_free(dIdxOut); dca_dev_free(dTemp);
     return rc;
 }

@@ -257,12 +257,12 @@ int dca_fn_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, int L,
         hipLaunchKernelGGL(fn_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const double*>(src), src_kind, L, q, ld, dOut);
     if (apc) {
         double* dAv = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dAv), (size_t)(L + 1) * sizeof(double)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dAv), (size_t)(L + 1) * sizeof(double)));
         hipLaunchKernelGGL(apc_site_kernel, dim3(L), dim3(256), 0, ctx->stream, dOut, L, dAv);
         hipLaunchKernelGGL(apc_mean_kernel, dim3(1), dim3(256), 0, ctx->stream, dAv, L, dAv + L);
         hipLaunchKernelGGL(apc_apply_kernel, dim3(L - 1), dim3(256), 0, ctx->stream, dOut, dAv, dAv + L, L);
         hipError_t e = hipStreamSynchronize(ctx->stream);
-        hipFree(dAv);
+        dca_dev_free(dAv);
         if (e != hipSuccess) { dca_set_error("apc: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     }
     HIP_TRY(hipGetLastError());
@@ -282,12 +282,12 @@ int dca_di_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, const 
         hipLaunchKernelGGL(di_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const double*>(src), src_kind, dRegFi, L, q, ld, dOut, static_cast<double*>(nullptr));
     if (apc) {
         double* dAv = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dAv), (size_t)(L + 1) * sizeof(double)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dAv), (size_t)(L + 1) * sizeof(double)));
         hipLaunchKernelGGL(apc_site_kernel, dim3(L), dim3(256), 0, ctx->stream, dOut, L, dAv);
         hipLaunchKernelGGL(apc_mean_kernel, dim3(1), dim3(256), 0, ctx->stream, dAv, L, dAv + L);
         hipLaunchKernelGGL(apc_apply_kernel, dim3(L - 1), dim3(256), 0, ctx->stream, dOut, dAv, dAv + L, L);
         hipError_t e = hipStreamSynchronize(ctx->stream);
-        hipFree(dAv);
+        dca_dev_free(dAv);
         if (e != hipSuccess) { dca_set_error("apc: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     }
     HIP_TRY(hipGetLastError());
@@ -305,8 +305,8 @@ int dca_pair_blocks(dca_ctx* ctx, const void* src, int src_kind, int dtype, int 
     const size_t per = (size_t)(q - 1) * (q - 1);
     int* dPairs = nullptr;
     double* dOut = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dPairs), (size_t)npairs * 2 * sizeof(int)));
-    if (hipMalloc(reinterpret_cast<void**>(&dOut), (size_t)npairs * per * sizeof(double)) != hipSuccess) { hipFree(dPairs); return DCA_ERR_NOMEM; }
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dPairs), (size_t)npairs * 2 * sizeof(int)));
+    if (dca_dev_malloc(reinterpret_cast<void**>(&dOut), (size_t)npairs * per * sizeof(double)) != hipSuccess) { dca_dev_free(dPairs); return DCA_ERR_NOMEM; }
     hipError_t e = hipMemcpyAsync(dPairs, pairs, (size_t)npairs * 2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         if (dtype == DCA_F32)
@@ -316,7 +316,7 @@ int dca_pair_blocks(dca_ctx* ctx, const void* src, int src_kind, int dtype, int 
         e = hipStreamSynchronize(ctx->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(out, dOut, (size_t)npairs * per * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(dPairs); hipFree(dOut);
+    dca_dev_free(dPairs); dca_dev_free(dOut);
     if (e != hipSuccess) { dca_set_error("pair blocks: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     return DCA_OK;
 }
@@ -332,10 +332,10 @@ int dca_di_from_arrays_impl(dca_ctx* ctx, const double* couplings, int layout, c
     const size_t npairs = (size_t)L * (L - 1) / 2;
     const size_t nc = layout == 1 ? (size_t)n * n : npairs * qm * qm;
     double *dC = nullptr, *dF = nullptr, *dDi = nullptr, *dFields = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dC), nc * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dF), (size_t)L * q * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dDi), npairs * sizeof(double));
-    if (e == hipSuccess && fields_out) e = hipMalloc(reinterpret_cast<void**>(&dFields), npairs * 2 * q * sizeof(double));
+    hipError_t e = dca_dev_malloc(reinterpret_cast<void**>(&dC), nc * sizeof(double));
+    if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&dF), (size_t)L * q * sizeof(double));
+    if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&dDi), npairs * sizeof(double));
+    if (e == hipSuccess && fields_out) e = dca_dev_malloc(reinterpret_cast<void**>(&dFields), npairs * 2 * q * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(dC, couplings, nc * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dF, reg_fi, (size_t)L * q * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
@@ -344,7 +344,7 @@ int dca_di_from_arrays_impl(dca_ctx* ctx, const double* couplings, int layout, c
     }
     if (e == hipSuccess && di_out) e = hipMemcpy(di_out, dDi, npairs * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess && fields_out) e = hipMemcpy(fields_out, dFields, npairs * 2 * q * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(dC); hipFree(dF); hipFree(dDi); hipFree(dFields);
+    dca_dev_free(dC); dca_dev_free(dF); dca_dev_free(dDi); dca_dev_free(dFields);
     if (e != hipSuccess) { dca_set_error("dca_di_from_arrays: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     return DCA_OK;
 }

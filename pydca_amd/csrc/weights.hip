@@ -195,7 +195,7 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision)
         const bool small = ctx->q <= 8;
         const int PLP = small ? 4 : 6;
         uint32_t* dP = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dP), (size_t)N * G * PLP * sizeof(uint32_t)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dP), (size_t)N * G * PLP * sizeof(uint32_t)));
         const unsigned tb = (unsigned)(((size_t)N * G + 255) / 256);
         const int tilesPerSide = ceil_div(N, kTile);
         const int superPerSide = ceil_div(tilesPerSide, 32);
@@ -208,7 +208,7 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision)
             hipLaunchKernelGGL(weights_count_kernel<5>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide);
         }
         hipError_t e = hipStreamSynchronize(ctx->stream);
-        hipFree(dP);
+        dca_dev_free(dP);
         if (e != hipSuccess) { dca_set_error("weights kernel: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     }
     hipLaunchKernelGGL(weights_finish_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, ctx->stream, ctx->dCounts, ctx->dWd, N);
