@@ -481,10 +481,11 @@ int dca_spd_inverse(dca_ctx* ctx, const double* A, int n, double* Ainv_out)
     int info = 0;
     int rc = DCA_OK;
     if (hipMemcpy(dA, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = DCA_ERR_HIP;
-    if (rc == DCA_OK) rc = dca_spd_inverse_device(ctx, dA, np, dWork, &info);
+    double* dInv = nullptr;
+    if (rc == DCA_OK) rc = dca_spd_inverse_device(ctx, dA, np, dWork, &info, 1.0, &dInv);
     if (rc == DCA_OK && info != 0) { dca_set_error("matrix is not positive definite (pivot %d)", info); rc = DCA_ERR_NOT_SPD; }
     if (rc == DCA_OK) {
-        if (hipMemcpy(padded.data(), dA, padded.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = DCA_ERR_HIP;
+        if (hipMemcpy(padded.data(), dInv, padded.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = DCA_ERR_HIP;
         else for (int r = 0; r < n; ++r) memcpy(Ainv_out + (size_t)r * n, padded.data() + (size_t)r * np, (size_t)n * sizeof(double));
     }
     dca_dev_free(dA); dca_dev_free(dWork);

@@ -422,7 +422,7 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
 
 }  // namespace
 
-int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* info_out)
+int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* info_out, double scale, double** result)
 {
     if (n % 64 != 0 || n <= 0) { dca_set_error("dca_spd_inverse_device: n must be a positive multiple of 64"); return DCA_ERR_ARG; }
     ScopedKernelClock kc(ctx, "mf_inverse");
@@ -433,12 +433,9 @@ int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* 
     int rc = cholinv_rec(ctx, dA, n, n, 0, ws, dInfo);
     if (rc == DCA_OK) {
         double* out = dWork + (size_t)n * n;
-        // inv(A)[i][j] = sum_{k >= max(i,j)} X[k][i] X[k][j] = sum_k Xt[i][k] Xt[j][k]
-        rc = launch_gemm(ctx, GemmArgs{dA, n, MASK_UPPER, dA, n, MASK_UPPER, out, n, out, n, n, n, n, 1.0, 0.0, 1});
-        if (rc == DCA_OK) {
-            hipError_t e = hipMemcpyAsync(dA, out, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
-            if (e != hipSuccess) { dca_set_error("copy inverse: %s", hipGetErrorString(e)); rc = DCA_ERR_HIP; }
-        }
+        // scale * inv(A)[i][j] = scale * sum_{k >= max(i,j)} X[k][i] X[k][j] = scale * sum_k Xt[i][k] Xt[j][k]
+        rc = launch_gemm(ctx, GemmArgs{dA, n, MASK_UPPER, dA, n, MASK_UPPER, out, n, out, n, n, n, n, scale, 0.0, 1});
+        *result = out;
     }
     int info = 0;
     hipError_t e = hipMemcpyAsync(&info, dInfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);

@@ -168,10 +168,11 @@ int dca_mf_engine_fields(MfEngine*, double* out);
 void dca_mf_engine_set_hook(MfEngine*, dca_reduce_hook hook, void* user);
 int dca_mf_engine_pair_couplings(MfEngine*, const int* pairs, int npairs, int shift, double* out);
 
-// ---- cholinv.hip : in-place inverse of an SPD matrix on the device (f64 MFMA)
-// dA: n x n row-major (ld = n), n multiple of 64.  On return dA holds inv(A) (full, symmetric).
-// dWork: >= 2*n*n doubles.  info_out: 0 ok, >0 first non-positive pivot (1-based).
-int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* info_out);
+// ---- cholinv.hip : scale * inverse of an SPD matrix on the device (f64 MFMA)
+// dA: n x n row-major (ld = n), n multiple of 64; destroyed (holds the triangular factor's inverse afterwards).
+// dWork: >= 2*n*n doubles; *result points into it (its second half): scale * inv(A), full and bit-symmetric.
+// info_out: 0 ok, >0 first non-positive pivot (1-based).
+int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* info_out, double scale, double** result);
 
 // ---- host_io.cpp
 int dca_read_msa_impl(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count);

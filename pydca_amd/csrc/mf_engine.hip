@@ -241,10 +241,6 @@ __global__ void mf_corr_from_freqs_kernel(const double* __restrict__ fi, const d
     C[(size_t)row * n + col] = v;
 }
 
-__global__ void negate_kernel(double* __restrict__ A, size_t n)
-{
-    for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) A[k] = -1.0 * A[k];
-}
 
 }  // namespace
 
@@ -257,11 +253,12 @@ struct MfEngine {
     double* dCnt1 = nullptr;
     double *dCraw = nullptr, *dFi = nullptr, *dC = nullptr, *dJ = nullptr, *dWork = nullptr;
     bool have_counts = false, have_corr = false, have_J = false;
+    bool corr_on_device = false;    // dC holds the correlation matrix (the factorisation of dca_mf_engine_couplings destroys it)
     double theta = 0.0;
     double* dRegFi = nullptr;
     dca_reduce_hook hook = nullptr;   // sequence sharding: sums Craw and Meff over the shards
     void* hook_user = nullptr;
-    ~MfEngine() { dca_dev_free(dRegFi); dca_dev_free(dPerm); dca_dev_free(dOff); dca_dev_free(dXT); dca_dev_free(dDom); dca_dev_free(dCnt1); dca_dev_free(dCraw); dca_dev_free(dFi); dca_dev_free(dC); dca_dev_free(dJ); dca_dev_free(dWork); }
+    ~MfEngine() { dca_dev_free(dRegFi); dca_dev_free(dPerm); dca_dev_free(dOff); dca_dev_free(dXT); dca_dev_free(dDom); dca_dev_free(dCnt1); dca_dev_free(dCraw); dca_dev_free(dFi); dca_dev_free(dC); dca_dev_free(dWork); }
 };
 
 MfEngine* dca_make_mf_engine(dca_ctx* ctx)
@@ -354,14 +351,21 @@ static int copy_out_square(MfEngine* m, const double* dSrc, double* out)
     return DCA_OK;
 }
 
-int dca_mf_engine_corr(MfEngine* m, double theta, double* corr_out)
+static int mf_build_corr(MfEngine* m, double theta)
 {
-    DCA_TRY(mf_counts(m));
     dca_ctx* ctx = m->ctx;
     if (!m->dC) HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dC), (size_t)m->np * m->np * sizeof(double)));
     dim3 grid(ceil_div(m->np, 256), m->np);
     hipLaunchKernelGGL(mf_corr_kernel, grid, dim3(256), 0, ctx->stream, m->dCraw, m->dC, m->L, m->q, m->Lq, m->np, ctx->meff, theta);
     HIP_TRY(hipGetLastError());
+    m->corr_on_device = true;
+    return DCA_OK;
+}
+
+int dca_mf_engine_corr(MfEngine* m, double theta, double* corr_out)
+{
+    DCA_TRY(mf_counts(m));
+    DCA_TRY(mf_build_corr(m, theta));
     m->have_corr = true;
     m->have_J = false;
     m->theta = theta;
@@ -374,19 +378,18 @@ int dca_mf_engine_couplings(MfEngine* m, double* out)
     if (!m->have_corr) { dca_set_error("dca_mf_corr_mat first"); return DCA_ERR_STATE; }
     dca_ctx* ctx = m->ctx;
     const size_t nn = (size_t)m->np * m->np;
-    if (!m->dJ) {
-        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dJ), nn * sizeof(double)));
-        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dWork), 2 * nn * sizeof(double)));
-    }
-    HIP_TRY(hipMemcpyAsync(m->dJ, m->dC, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    // The factorisation runs in place on the correlation matrix (1.4 ms to rebuild from the counts if it is asked
+    // for again) and leaves -inv(C) in the second half of the workspace: no copy in, no copy out, no negation pass.
+    if (!m->corr_on_device) DCA_TRY(mf_build_corr(m, m->theta));
+    if (!m->dWork) HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dWork), 2 * nn * sizeof(double)));
     int info = 0;
-    DCA_TRY(dca_spd_inverse_device(ctx, m->dJ, m->np, m->dWork, &info));
+    m->corr_on_device = false;
+    m->have_J = false;
+    DCA_TRY(dca_spd_inverse_device(ctx, m->dC, m->np, m->dWork, &info, -1.0, &m->dJ));
     if (info != 0) {
         dca_set_error("Singular matrix: the correlation matrix is not positive definite (pivot %d)", info);
         return DCA_ERR_NOT_SPD;
     }
-    hipLaunchKernelGGL(negate_kernel, dim3(1024), dim3(256), 0, ctx->stream, m->dJ, nn);
-    HIP_TRY(hipGetLastError());
     m->have_J = true;
     if (out) return copy_out_square(m, m->dJ, out);
     return DCA_OK;
@@ -516,5 +519,5 @@ void dca_mf_engine_set_hook(MfEngine* m, dca_reduce_hook hook, void* user)
 {
     m->hook = hook;
     m->hook_user = user;
-    m->have_counts = m->have_corr = m->have_J = false;
+    m->have_counts = m->have_corr = m->have_J = m->corr_on_device = false;
 }
