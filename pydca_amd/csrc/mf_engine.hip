@@ -95,6 +95,16 @@ void mf_site_sort_kernel(const uint8_t* __restrict__ XT, const double* __restric
 
 constexpr int kCountThreads = 256;
 
+// *p += v on an LDS slot that only this thread touches, as ONE fire-and-forget ds_add_f64 instead of
+// ds_read + v_add_f64 + ds_write: consecutive updates may hit the same slot, so the read-modify-write form is a
+// chain of LDS round trips; the LDS unit applies the adds in issue order, so the sum is the same sequence of
+// IEEE additions.
+__device__ __forceinline__ void lds_add(double* p, double v)
+{
+    typedef __attribute__((address_space(3))) double* lds_ptr;
+    __builtin_amdgcn_ds_atomic_fadd_f64((lds_ptr)p, v);
+}
+
 // One workgroup per (site i, state a): the upper-triangle part of row (i,a) of Craw,
 // Craw[(i,a)][(j,b)] for j > i.  Rows of the site's dominant state are skipped here and
 // completed by mf_complete_kernel from the single-site counts:
@@ -111,7 +121,13 @@ void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ 
     const int k0 = off[i * (q + 1) + a], k1 = off[i * (q + 1) + a + 1];
     const uint32_t* p = perm + (size_t)i * N;
     const int t = threadIdx.x;
-    constexpr int U = 8;      // sequences fetched ahead: the loop is bound by dependent load latency
+#ifndef DCA_COUNTS_U
+#define DCA_COUNTS_U 32
+#endif
+    // List entries fetched per batch.  A batch is two dependent memory round trips (list entry -> weight and alignment
+    // byte) followed by fire-and-forget LDS adds, and a wave has one batch in flight: the loop time is the round trips
+    // divided by the batch size (6.0 / 5.6 / 4.2 ms at config D for 8 / 16 / 32).
+    constexpr int U = DCA_COUNTS_U;
     for (int j0 = i + 1; j0 < L; j0 += kCountThreads) {
         const int j = j0 + t;
         for (int b = 0; b < q; ++b) hist[b * kCountThreads + t] = 0.0;
@@ -127,15 +143,21 @@ void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ 
 #pragma unroll
                 for (int u = 0; u < U; ++u) { wv[u] = w[n[u]]; bb[u] = Xj[(size_t)n[u] * Ls]; }
 #pragma unroll
-                for (int u = 0; u < U; ++u) hist[bb[u] * kCountThreads + t] += wv[u];     // list order: ascending n
+                for (int u = 0; u < U; ++u) lds_add(&hist[bb[u] * kCountThreads + t], wv[u]);     // list order: ascending n
             }
             for (; k < k1; ++k) {
                 const uint32_t n = p[k];
-                hist[Xj[(size_t)n * Ls] * kCountThreads + t] += w[n];
+                lds_add(&hist[Xj[(size_t)n * Ls] * kCountThreads + t], w[n]);
             }
-            double* dst = Craw + (size_t)(i * q + a) * ldc + (size_t)j * q;
-            for (int b = 0; b < q; ++b) dst[b] = hist[b * kCountThreads + t];
         }
+        // the block's part of row (i,a) is one contiguous run of (sites in the block) x q doubles: store it in that
+        // order (thread t's own q values are 8-byte pieces 8q bytes apart -- every store instruction would touch
+        // 64 different lines)
+        __syncthreads();
+        const int nj = min(kCountThreads, L - j0);
+        double* dst = Craw + (size_t)(i * q + a) * ldc + (size_t)j0 * q;
+        for (int e = t; e < nj * q; e += kCountThreads) dst[e] = hist[(e % q) * kCountThreads + e / q];
+        __syncthreads();
     }
 }
 
