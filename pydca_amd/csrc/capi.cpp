@@ -47,7 +47,7 @@ DevPool& pool() { static DevPool* p = new DevPool(); return *p; }   // never des
 constexpr size_t kPoolMinBytes = (size_t)1 << 20;
 }  // namespace
 
-hipError_t dca_dev_malloc(void** out, size_t bytes)
+hipError_t dca_dev_malloc(void** out, size_t bytes, bool zero_recycled)
 {
     *out = nullptr;
     if (bytes < kPoolMinBytes) return hipMalloc(out, bytes);
@@ -73,9 +73,11 @@ hipError_t dca_dev_malloc(void** out, size_t bytes)
     }
     if (hit) {
         // a fresh hipMalloc block reads as zeros; keep that for recycled ones (the copy engine fills > 3 TB/s)
-        hipError_t e = hipMemsetAsync(hit, 0, bytes, nullptr);
-        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-        if (e != hipSuccess) return e;
+        if (zero_recycled) {
+            hipError_t e = hipMemsetAsync(hit, 0, bytes, nullptr);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+            if (e != hipSuccess) return e;
+        }
         *out = hit;
         return hipSuccess;
     }

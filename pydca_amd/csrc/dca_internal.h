@@ -34,7 +34,7 @@ void dca_set_error(const char* fmt, ...);
 // when they are freed and later requests of a similar size are served from it (zero-filled), because
 // hipMalloc / hipFree of GB-sized blocks costs tens of milliseconds per call on some hosts -- more than
 // the whole mfDCA chain.  dca_dev_free waits for the device like hipFree does.
-hipError_t dca_dev_malloc(void** p, size_t bytes);
+hipError_t dca_dev_malloc(void** p, size_t bytes, bool zero_recycled = true);   // false: buffers their first kernel overwrites completely
 hipError_t dca_dev_free(void* p);
 
 static inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }

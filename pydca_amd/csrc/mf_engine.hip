@@ -301,11 +301,11 @@ static int mf_counts(MfEngine* m)
     if (m->q > 32) { dca_set_error("q too large"); return DCA_ERR_ARG; }
     const int Nt = (int)round_up((size_t)m->N, 64);
     if (!m->dPerm) {
-        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dPerm), (size_t)m->L * m->N * sizeof(uint32_t)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dPerm), (size_t)m->L * m->N * sizeof(uint32_t), false));
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dOff), (size_t)m->L * (m->q + 1) * sizeof(int)));
-        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dCraw), (size_t)m->Lq * m->Lq * sizeof(double)));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dCraw), (size_t)m->Lq * m->Lq * sizeof(double), false));
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dFi), (size_t)m->Lq * sizeof(double)));
-        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dXT), (size_t)m->L * Nt));
+        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dXT), (size_t)m->L * Nt, false));
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dDom), (size_t)m->L));
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dCnt1), (size_t)m->Lq * sizeof(double)));
     }
@@ -376,7 +376,7 @@ static int copy_out_square(MfEngine* m, const double* dSrc, double* out)
 static int mf_build_corr(MfEngine* m, double theta)
 {
     dca_ctx* ctx = m->ctx;
-    if (!m->dC) HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dC), (size_t)m->np * m->np * sizeof(double)));
+    if (!m->dC) HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dC), (size_t)m->np * m->np * sizeof(double), false));
     dim3 grid(ceil_div(m->np, 256), m->np);
     hipLaunchKernelGGL(mf_corr_kernel, grid, dim3(256), 0, ctx->stream, m->dCraw, m->dC, m->L, m->q, m->Lq, m->np, ctx->meff, theta);
     HIP_TRY(hipGetLastError());
@@ -403,7 +403,7 @@ int dca_mf_engine_couplings(MfEngine* m, double* out)
     // The factorisation runs in place on the correlation matrix (1.4 ms to rebuild from the counts if it is asked
     // for again) and leaves -inv(C) in the second half of the workspace: no copy in, no copy out, no negation pass.
     if (!m->corr_on_device) DCA_TRY(mf_build_corr(m, m->theta));
-    if (!m->dWork) HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dWork), 2 * nn * sizeof(double)));
+    if (!m->dWork) HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dWork), 2 * nn * sizeof(double), false));
     int info = 0;
     m->corr_on_device = false;
     m->have_J = false;
