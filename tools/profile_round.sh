@@ -15,6 +15,8 @@ cd /tmp && export TMPDIR=/tmp
 B="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- $B > "$out/stats_run.log" 2>&1
 cp "$(ls -t /tmp/p_stats/*/*kernel_stats.csv | head -1)" "$out/D_kernel_stats.csv"
+rocprofv3 --kernel-trace --output-format csv -d /tmp/p_inv -- python "$root/tools/time_mf.py" --reps 2 > /dev/null 2>&1
+python "$root/tools/experiments/inverse_trace.py" "$(ls -t /tmp/p_inv/*/*kernel_trace.csv | head -1)" > "$out/inverse_trace.txt" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- $B > /dev/null 2>&1
 python "$root/tools/pmc_summary.py" "$(ls -t /tmp/p_fetch/*/*counter_collection.csv | head -1)" "$(ls -t /tmp/p_write/*/*counter_collection.csv | head -1)" \
