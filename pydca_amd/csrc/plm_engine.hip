@@ -780,15 +780,14 @@ __global__ void vec_compose_kernel(T* __restrict__ d, const T* __restrict__ g, V
           d[i] = (T)v; })
 }
 
-// out[k] = sum_b partials[k*nb + b], k < nk; one block, fixed tree
+// out[k] = sum_b partials[k*nb + b], k < nk; one block per k, fixed tree
 __global__ void vec_final_kernel(const double* __restrict__ partials, int nb, int nk, double* __restrict__ out)
 {
     __shared__ double red[256];
-    for (int k = 0; k < nk; ++k) {
-        double s = 0;
-        for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partials[(size_t)k * nb + b];
-        block_reduce_store(s, red, out + k);
-    }
+    const int k = blockIdx.x;
+    double s = 0;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partials[(size_t)k * nb + b];
+    block_reduce_store(s, red, out + k);
 }
 // out[0] = (add ? out[0] : 0) + sum partials[0..n)
 __global__ void sum_partials_kernel(const double* __restrict__ partials, int n, double* __restrict__ out, int add)
@@ -1303,7 +1302,7 @@ struct PlmEngine : PlmEngineBase {
     int eval_scalars(double* fx, double* gd, double* xx, double* gg)
     {
         hipLaunchKernelGGL(vec_dot3_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dg + vlo, dd + vlo, dx + vlo, vn, dVecPart);
-        hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 3, ctx->dScal + 1);
+        hipLaunchKernelGGL(vec_final_kernel, dim3(3), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 3, ctx->dScal + 1);
         DCA_TRY(reduce_scalars(0, 4));     // fx (local data term) and the three partial dot products
         DCA_TRY(read_scalars(4));
         *fx = ctx->hScal[0]; *gd = ctx->hScal[1]; *xx = ctx->hScal[2]; *gg = ctx->hScal[3];
@@ -1438,9 +1437,9 @@ struct PlmEngine : PlmEngineBase {
                 ScopedKernelClock kc(ctx, "lbfgs_vec");
                 hipLaunchKernelGGL(vec_diff_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream,
                                    dS[e] + vlo, dY[e] + vlo, dx + vlo, dxp + vlo, dg + vlo, dgp + vlo, vn, dVecPart);
-                hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 2, ctx->dScal + 1);
+                hipLaunchKernelGGL(vec_final_kernel, dim3(2), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 2, ctx->dScal + 1);
                 hipLaunchKernelGGL(vec_gram_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, ptrs, dg + vlo, e, vn, dVecPart);
-                hipLaunchKernelGGL(vec_final_kernel, dim3(1), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 25, ctx->dScal + 3);
+                hipLaunchKernelGGL(vec_final_kernel, dim3(25), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 25, ctx->dScal + 3);
             }
             DCA_TRY(reduce_scalars(1, 27));
             DCA_TRY(read_scalars(28));
