@@ -65,12 +65,36 @@ def _copies_done():
 _D2D = 3  # hipMemcpyDeviceToDevice
 
 
+class _DevArray:
+    """`__cuda_array_interface__` view of `count` elements at a raw device address, so that torch can run a
+    collective directly on the library's buffer (torch.as_tensor does not copy)."""
+
+    def __init__(self, ptr, count, dtype_bits):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4" if dtype_bits == 32 else "<f8",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def wrap_device_buffer(torch, ptr, count, dtype_bits, device):
+    """torch tensor aliasing library memory, or None when this torch build cannot do it (the hooks then stage
+    through their own tensors).  Set DCA_COMM_STAGED=1 to force staging."""
+    import os
+    if os.environ.get("DCA_COMM_STAGED") == "1":
+        return None
+    try:
+        t = torch.as_tensor(_DevArray(ptr, count, dtype_bits), device=device)
+        if t.data_ptr() != int(ptr) or t.numel() != count:
+            return None
+        return t
+    except Exception:
+        return None
+
+
 class TorchAllReduceHook:
     """Reduce hook for `Context.plm_set_reduce_hook`: sums g and fx over the process group.
 
-    The library hands over raw device pointers; they are staged through torch tensors
-    (two device-to-device copies of P elements, negligible next to the evaluation) so that
-    torch.distributed (backend "nccl" = RCCL on ROCm) can run the collective.
+    The library hands over raw device pointers; torch.distributed (backend "nccl" = RCCL on ROCm) runs the
+    collective in place on them through a `__cuda_array_interface__` view (`wrap_device_buffer`), or, where
+    that is not available, on a staging tensor (two device-to-device copies of P elements).
     """
 
     def __init__(self, device, group=None):
@@ -81,6 +105,7 @@ class TorchAllReduceHook:
         self.gbuf = None
         self.fbuf = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.calls = 0
+        self.direct_calls = 0      # calls that ran in place on the library's buffers
         self.seconds = 0.0
 
     def __call__(self, g_dev, count, dtype, fx_dev):
@@ -88,10 +113,21 @@ class TorchAllReduceHook:
         torch, dist = self.torch, self.dist
         t0 = time.perf_counter()
         tdt = torch.float32 if dtype == 32 else torch.float64
-        if self.gbuf is None or self.gbuf.numel() != count or self.gbuf.dtype != tdt:
-            self.gbuf = torch.empty(count, dtype=tdt, device=self.device)
         hip = _hip_rt()
         nbytes = count * (4 if dtype == 32 else 8)
+        direct = wrap_device_buffer(torch, g_dev, count, dtype, self.device)
+        fdirect = wrap_device_buffer(torch, fx_dev, 1, 64, self.device) if direct is not None else None
+        if direct is not None and fdirect is not None:
+            # the collectives run in place on the library's buffers: no staging copies
+            dist.all_reduce(direct, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(fdirect, op=dist.ReduceOp.SUM, group=self.group)
+            torch.cuda.synchronize(self.device)
+            self.calls += 1
+            self.direct_calls += 1
+            self.seconds += time.perf_counter() - t0
+            return 0
+        if self.gbuf is None or self.gbuf.numel() != count or self.gbuf.dtype != tdt:
+            self.gbuf = torch.empty(count, dtype=tdt, device=self.device)
         if hip.hipMemcpy(self.gbuf.data_ptr(), g_dev, nbytes, _D2D) != 0:
             return 1
         if hip.hipMemcpy(self.fbuf.data_ptr(), fx_dev, 8, _D2D) != 0:
@@ -112,8 +148,9 @@ class TorchAllReduceHook:
 
 class TorchVectorComm:
     """Comm hook for `Context.plm_set_vector_sharding` on torch.distributed (backend "nccl" = RCCL):
-    in-place all-reduce / reduce-scatter / all-gather on the library's device buffers, staged through
-    one torch tensor (device-to-device copies, negligible next to the collective)."""
+    in-place all-reduce / reduce-scatter / all-gather on the library's device buffers, which torch sees through a
+    `__cuda_array_interface__` view (only the rank's slice is copied); staged through one torch tensor where that
+    view is not available and for the gloo self-test."""
 
     def __init__(self, device, rank, world, group=None):
         import torch
@@ -128,6 +165,7 @@ class TorchVectorComm:
         self.device = torch.device("cuda", device)
         self.buf = {}
         self.calls = [0, 0, 0]
+        self.direct_calls = 0      # calls that ran in place on the library's buffers
         self.seconds = 0.0
 
     def _tensor(self, count, dtype, slot="full"):
@@ -146,6 +184,27 @@ class TorchVectorComm:
         if self.trace:
             import sys
             print("[comm rank %d] op %d count %d dtype %d" % (self.rank, op, count, dtype), file=sys.stderr, flush=True)
+        direct = None if self.only_all_reduce else wrap_device_buffer(self.torch, dev, count, dtype, self.device)
+        if direct is not None:
+            # in place on the library's buffer: all-reduce as is; reduce-scatter into a slice buffer (its input and
+            # output must not alias) and one slice-sized copy back; all-gather from a copy of the own slice
+            if op == 0:
+                dist.all_reduce(direct, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                ps = count // self.world
+                lo = self.rank * ps
+                mine = self._tensor(ps, dtype, slot="slice")
+                if op == 1:
+                    dist.reduce_scatter_tensor(mine, direct, op=dist.ReduceOp.SUM, group=self.group)
+                    direct[lo:lo + ps].copy_(mine)
+                else:
+                    mine.copy_(direct[lo:lo + ps])
+                    dist.all_gather_into_tensor(direct, mine, group=self.group)
+            self.torch.cuda.synchronize(self.device)
+            self.calls[op] += 1
+            self.direct_calls += 1
+            self.seconds += time.perf_counter() - t0
+            return 0
         t = self._tensor(count, dtype)
         if op == 0:                                         # all-reduce (scalars)
             if hip.hipMemcpy(t.data_ptr(), dev, count * esz, _D2D) != 0:

@@ -203,6 +203,7 @@ def test_reduce_hook_through_torch_distributed():
         fx1 = ctx.plm_gradient()
         g1 = ctx.plm_get_g(np.float32)
         assert hook.calls == 1 and fx1 == fx0 and np.array_equal(g0, g1)
+        assert hook.direct_calls == hook.calls, "the all-reduce should run in place on the library's buffer"
         ctx.plm_lbfgs_begin(5)
         st = ctx.plm_lbfgs_iterate(5)
         assert st.iterations == 5 and hook.calls == 1 + st.evaluations
@@ -221,6 +222,7 @@ def test_reduce_hook_through_torch_distributed():
         st2 = ctx.plm_lbfgs_iterate(5)
         assert (st2.status, st2.iterations, st2.evaluations, st2.fx) == (st.status, st.iterations, st.evaluations, st.fx)
         assert vcomm.calls[1] == 1 + st2.evaluations and vcomm.calls[2] >= st2.evaluations and vcomm.calls[0] > st2.iterations
+        assert vcomm.direct_calls == sum(vcomm.calls)
         ctx.close()
         # the same hook on the mfDCA pair counts (float64 buffer of (L q)^2 counts + Meff)
         M = golden("mf_toy_protein")
