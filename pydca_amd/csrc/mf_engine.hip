@@ -212,7 +212,7 @@ __global__ void mf_fij_export_kernel(const double* __restrict__ Craw, double* __
 }
 
 // correlation matrix from raw counts: regularisation (msa_numerics.py:92-125, :231-267)
-// fused with construct_corr_mat (:270-318).  Entries with i > j are mirrored from (j,i).
+// fused with construct_corr_mat (:270-318).
 // Rows/cols >= n (padding up to np) form an identity block.
 __global__ void mf_corr_kernel(const double* __restrict__ Craw, double* __restrict__ C, int L, int q, int ldc, int np,
                                double meff, double theta)
@@ -225,9 +225,9 @@ __global__ void mf_corr_kernel(const double* __restrict__ Craw, double* __restri
     if (row >= n || col >= n) {
         v = (row == col) ? 1.0 : 0.0;
     } else {
-        int r = row, c = col;
-        if (r > c) { const int t = r; r = c; c = t; }
-        const int i = r / qm, a = r % qm, j = c / qm, b = c % qm;
+        // Craw is bit-symmetric (mf_complete_kernel mirrors it, sums of shards stay symmetric) and the products below
+        // commute, so entry (row, col) is computed from Craw's row `row`: coalesced reads for both triangles
+        const int i = row / qm, a = row % qm, j = col / qm, b = col % qm;
         const double thq = theta / (double)q;
         const double fia = thq + (1.0 - theta) * (Craw[(size_t)(i * q + a) * ldc + i * q + a] / meff);
         const double fjb = thq + (1.0 - theta) * (Craw[(size_t)(j * q + b) * ldc + j * q + b] / meff);
