@@ -804,6 +804,18 @@ __global__ void sum_partials_kernel(const double* __restrict__ partials, int n, 
     if (threadIdx.x == 0) out[0] = (add ? out[0] : 0.0) + red[0];
 }
 
+// first stage for long partial vectors: block b sums its contiguous chunk (fixed tree) into out[b]
+constexpr int kSumStageBlocks = 64;
+__global__ void sum_chunks_kernel(const double* __restrict__ partials, int n, double* __restrict__ out)
+{
+    __shared__ double red[256];
+    const int chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    double s = 0;
+    for (int b = lo + threadIdx.x; b < hi; b += blockDim.x) s += partials[b];
+    block_reduce_store(s, red, out + blockIdx.x);
+}
+
 template <typename T>
 __global__ void cast_weights_kernel(const double* __restrict__ wd, T* __restrict__ w, int N)
 {
@@ -1034,7 +1046,7 @@ struct PlmEngine : PlmEngineBase {
         nFxPart = ceil_div(L, 64) * ceil_div(numScanChunks, 4) * 4;
         nRegPart = (int)npairs + ceil_div(Lq, 256);
         DCA_TRY(dalloc(&dFxPart, nFxPart));
-        DCA_TRY(dalloc(&dRegPart, nRegPart));
+        DCA_TRY(dalloc(&dRegPart, nRegPart + kSumStageBlocks));      // + the first-stage sums of the regulariser partials
         DCA_TRY(dalloc(&dVecPart, 25 * kVecBlocks));
 
         HIP_TRY(hipMemsetAsync(dx, 0, (P + kVecPad) * sizeof(T), ctx->stream));
@@ -1207,7 +1219,9 @@ struct PlmEngine : PlmEngineBase {
                                dRegPart + npairs, Lq, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, foldSlabs);
         }
         // fx = regulariser + data term  -> ctx->dScal[0]
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, st, dRegPart, nRegPart, ctx->dScal, 0);
+        // (one partial per site pair: summed in two stages, a single workgroup needs 28 us for the 125 000 of config D)
+        hipLaunchKernelGGL(sum_chunks_kernel, dim3(kSumStageBlocks), dim3(256), 0, st, dRegPart, nRegPart, dRegPart + nRegPart);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, dRegPart + nRegPart, kSumStageBlocks, ctx->dScal, 0);
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, st, dFxPart, nFxPart, ctx->dScal, 1);
         HIP_TRY(hipGetLastError());
         return DCA_OK;
