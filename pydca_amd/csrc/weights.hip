@@ -73,11 +73,12 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
     const int rowBase = tileY * kTile, colBase = tileX * kTile;
     if (threadIdx.x < kTile) sCol[threadIdx.x] = 0;
     const int rowDwords = G * PLP;
+    // pairs with a sequence index past N start beyond every threshold (they never count and never hold a tile back)
     unsigned mism[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mism[r][c] = 0;
+        for (int c = 0; c < 4; ++c) mism[r][c] = (rowBase + ty + 16 * r < N && colBase + tx + 16 * c < N) ? 0u : 0x40000000u;
 
     // Mismatch counts only grow, so a pair that has passed L - thresh mismatches can no longer reach the
     // identity threshold; once that holds for every pair of the tile the rest of the sites are skipped
@@ -85,20 +86,22 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
     // D (synthetic, Dirichlet(0.3) profiles, founder families of ~5): unrelated pairs pass after 128-256 of
     // the 500 sites, but a third of the tiles hold a same-family pair that needs ~430: 7.3 -> 5.3 ms.  (Walking
     // a strip of column tiles per workgroup to save dispatches and row-tile loads was slower: 7.0 ms.)
-    const int maxMism = L - thresh;
-    bool inRange[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) inRange[r][c] = rowBase + ty + 16 * r < N && colBase + tx + 16 * c < N;
-
-    for (int g0 = 0; g0 < G; g0 += kKG) {
-        bool done = g0 > 0;
+    // The same test per wave and 32-site group: a wave (16 x 64 pairs of the tile) whose pairs have all passed stops
+    // comparing and only keeps staging -- the family pair that holds a tile to the end sits in one of its four waves,
+    // and short alignments (config E: 150 sites, passed after ~64) are over before the first stage of 128 sites ends.
+    const unsigned maxMism = (unsigned)(L - thresh);
+    bool waveDone = false;       // wave-uniform
+    auto all_passed = [&]() {
+        bool d = true;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) done = done && (!inRange[r][c] || (int)mism[r][c] > maxMism);
-        if (__syncthreads_and(done)) break;      // also the barrier that protects sA / sB
+            for (int c = 0; c < 4; ++c) d = d && mism[r][c] > maxMism;
+        return d;
+    };
+
+    for (int g0 = 0; g0 < G; g0 += kKG) {
+        if (__syncthreads_and(waveDone)) break;      // also the barrier that protects sA / sB
         for (int t = threadIdx.x; t < kTile * ROWDW; t += 256) {
             const int r = t / ROWDW, k = t % ROWDW;
             uint32_t a = 0, b = 0;
@@ -112,6 +115,8 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
         __syncthreads();
 #pragma unroll
         for (int gg = 0; gg < kKG; ++gg) {
+            if (g0 + gg > 0 && !waveDone) waveDone = __all(all_passed());
+            if (waveDone) continue;
             uint32_t a[4][PLP], b[4][PLP];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -137,6 +142,7 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
                     mism[r][c] += __popc(d);
                 }
         }
+        if (!waveDone) waveDone = __all(all_passed());
     }
     // ident = L - mismatches (padding sites are state 0 in every row and never mismatch)
 #pragma unroll
