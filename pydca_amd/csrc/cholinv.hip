@@ -176,189 +176,225 @@ void gemm_nt_f64_kernel(GemmArgs g)
 }
 
 // 64x64 leaf: A (lower triangle valid) -> X = inv(chol(A)), written lower + mirrored upper.
-// One workgroup of 16 x 16 threads; thread (ty, tx) keeps the 4 x 4 block rows 4ty.., columns 4tx.. in
-// registers.  Both phases advance one 4-wide block column / block row per step (16 steps each, two and one
-// barriers per step) instead of one column per step: the time of a leaf is its chain of barriers and LDS
-// round trips, not its flops.
-//  * Cholesky, right-looking by blocks: the thread on the diagonal factors its 4 x 4 block in registers
-//    (reciprocal square roots by v_rsq_f64 + Newton steps) and publishes the inverse of that triangle; the
-//    threads of the block column turn their blocks into L (a product with that inverse), publish the
-//    64 x 4 panel; every thread subtracts the rank-4 update from its block (64 FMAs).
-//  * X = L^-1 by forward substitution on B = I by blocks: block row k of X is the published inverse of the
-//    diagonal triangle times block row k of B; the rows below subtract L(i,k) * X(k,:).
+// One workgroup of 16 x 16 threads; thread (ty, tx) keeps ONE 4 x 4 register block c.  The factorisation and the
+// triangular inverse advance together, one 4-wide block column per step, 16 steps of two barriers: the time of a
+// leaf is its chain of barriers, LDS round trips and the serial factorisation of the 4 x 4 diagonal block, not its
+// flops.  With L = chol(A) and D_k the inverse of L's k-th diagonal triangle, step k does
+//   1. thread (k,k): factors its block (LDL^T steps with refined reciprocals on the dependent chain, the reciprocal
+//      square roots beside it), publishes D_k;
+//   2. the threads of block column k below the diagonal: L(i,k) = C(i,k) D_k^T, publish the panel L(:,k) and the
+//      panel L(:,k) D_k; their block then starts over as the zero block of B.  The threads of block row k
+//      publish their blocks of B (unit diagonal block for (k,k));
+//   3. every thread (i,j) with i > k: j > k: C(i,j) -= L(i,k) L(j,k)^T (Cholesky trailing update);
+//      j <= k: B(i,j) -= [L(i,k) D_k] B(k,j)   (forward substitution on B = I with the scaling by D deferred:
+//      X(k,:) = D_k B(k,:), so the rows below subtract L(i,k) X(k,:) = [L(i,k) D_k] B(k,:)).
+// A block holds C until its own column has been the panel and B afterwards, so one register block does for both;
+// at the end X(i,j) = D_i B(i,j).
+#ifndef DCA_RSQ_NEWTON
+#define DCA_RSQ_NEWTON 1        // + the residual step: 7e-16 against LAPACK with 1 as with 2 (tools/experiments/inv_err.py)
+#endif
 __device__ __forceinline__ double rsqrt_refined(double a)
 {
     double y = __builtin_amdgcn_rsq(a);
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < DCA_RSQ_NEWTON; ++it) {
         const double h = 0.5 * y;
         const double e = __builtin_fma(-a * y, y, 1.0);     // 1 - a y^2
         y = __builtin_fma(h, e, y);
     }
+    // last step on the residual of s = a y: one more correct digit than another Newton step on y
+    const double sq = a * y;
+    const double res = __builtin_fma(-sq, sq, a);
+    return __builtin_fma(0.5 * y * y, res * y, y);          // y + y^3 (a - s^2) / 2
+}
+
+__device__ __forceinline__ double rcp_refined(double a)
+{
+    double y = __builtin_amdgcn_rcp(a);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = __builtin_fma(-a, y, 1.0);
+        y = __builtin_fma(y, e, y);
+    }
     return y;
 }
 
+#ifdef DCA_LEAF_TRACE
+__device__ unsigned long long g_leaf_trace[16 * 8];
+#endif
 __global__ __launch_bounds__(256)
 void cholinv_leaf_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info)
 {
-    constexpr int n = 64, S = 66;
-    __shared__ __attribute__((aligned(16))) double Lf[n * S];         // L below the diagonal blocks, row-major
-    __shared__ __attribute__((aligned(16))) double panel[2][n][4];    // block column k of L (zero for rows above it)
-    __shared__ __attribute__((aligned(16))) double xrow[2][4][n];     // block row k of X (zero right of the diagonal block)
-    __shared__ __attribute__((aligned(16))) double dinv[16][16];      // inverse of the diagonal triangles, 4 x 4 row-major
+    constexpr int n = 64;
+    // all three [m][64]: a thread's four values per m are one 32-byte run and neighbouring threads' runs are 32 bytes
+    // apart ([row][4] put the 16 column-side reads of a wave's lanes 128 bytes apart: two banks, 8-way conflicts)
+    __shared__ __attribute__((aligned(16))) double panel[2][4][n];    // L(:,k) transposed, rows of block rows > k valid
+    __shared__ __attribute__((aligned(16))) double panelx[2][4][n];   // L(:,k) D_k transposed
+    __shared__ __attribute__((aligned(16))) double brow[2][4][n];     // block row k of B, columns of block columns <= k valid
+    __shared__ __attribute__((aligned(16))) double dinv[16][16];      // D_k, 4 x 4 row-major (upper part zero)
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
     const int r0 = 4 * ty, c0 = 4 * tx;
 
-    double a[4][4];
+    double c[4][4];
     // diagonal threads need their full symmetric block, the others their block as stored (lower part of A valid)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int i = r0 + r, j = c0 + c;
-            a[r][c] = (tx < ty) ? M[(size_t)i * ld + j] : (tx == ty) ? M[(size_t)max(i, j) * ld + min(i, j)] : 0.0;
+        for (int cc = 0; cc < 4; ++cc) {
+            const int i = r0 + r, j = c0 + cc;
+            c[r][cc] = (tx < ty) ? M[(size_t)i * ld + j] : (tx == ty) ? M[(size_t)max(i, j) * ld + min(i, j)] : 0.0;
         }
 
+#ifdef DCA_LEAF_TRACE
+#define LEAF_T(slot) do { if (tid == DCA_LEAF_TRACE) g_leaf_trace[kb * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define LEAF_T(slot) do { } while (0)
+#endif
     for (int kb = 0; kb < 16; ++kb) {
         const int cur = kb & 1;
-        if (ty == kb && tx == kb) {
-            double l[4][4], xi[4][4];
+        LEAF_T(0);
+#ifndef DCA_LEAF_ABLATE
+#define DCA_LEAF_ABLATE 0       // tools/experiments/leaf_bench.hip: 1 no diagonal factorisation, 2 no panel products, 3 no updates
+#endif
+        if (ty == kb && tx == kb && DCA_LEAF_ABLATE != 1) {
+            double l[4][4], xi[4][4], rs[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { l[r][c] = 0.0; xi[r][c] = 0.0; }
-            double rs[4];
+                for (int cc = 0; cc < 4; ++cc) { l[r][cc] = 0.0; xi[r][cc] = 0.0; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const double akk = a[k][k];
-                if (!(akk > 0.0)) atomicCAS(info, 0, pivotBase + 4 * kb + k + 1);
-                rs[k] = rsqrt_refined(akk);
-                l[k][k] = akk * rs[k];
+                const double dk = c[k][k];
+                if (!(dk > 0.0)) atomicCAS(info, 0, pivotBase + 4 * kb + k + 1);
+                const double ik = k < 3 ? rcp_refined(dk) : 0.0;   // on the chain to the next pivot (the last has none)
+                rs[k] = rsqrt_refined(dk);                      // beside it
+                double t[4];
 #pragma unroll
-                for (int r = k + 1; r < 4; ++r) l[r][k] = a[r][k] * rs[k];
+                for (int r = k + 1; r < 4; ++r) t[r] = c[r][k] * ik;
 #pragma unroll
                 for (int r = k + 1; r < 4; ++r)
 #pragma unroll
-                    for (int c = k + 1; c <= r; ++c) a[r][c] = __builtin_fma(-l[r][k], l[c][k], a[r][c]);
+                    for (int cc = k + 1; cc <= r; ++cc) c[r][cc] = __builtin_fma(-t[r], c[cc][k], c[r][cc]);
+                l[k][k] = dk * rs[k];
+#pragma unroll
+                for (int r = k + 1; r < 4; ++r) l[r][k] = c[r][k] * rs[k];
             }
-            // inverse of the lower triangle l
+            // D = inverse of the lower triangle l
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                xi[c][c] = rs[c];
+            for (int cc = 0; cc < 4; ++cc) {
+                xi[cc][cc] = rs[cc];
 #pragma unroll
-                for (int r = c + 1; r < 4; ++r) {
+                for (int r = cc + 1; r < 4; ++r) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int m = c; m < r; ++m) acc = __builtin_fma(l[r][m], xi[m][c], acc);
-                    xi[r][c] = -rs[r] * acc;
+                    for (int m = cc; m < r; ++m) acc = __builtin_fma(l[r][m], xi[m][cc], acc);
+                    xi[r][cc] = -rs[r] * acc;
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) dinv[kb][r * 4 + c] = xi[r][c];
+                for (int cc = 0; cc < 4; ++cc) {
+                    dinv[kb][r * 4 + cc] = xi[r][cc];
+                    c[r][cc] = (r == cc) ? 1.0 : 0.0;            // B(k,k) = I
+                    brow[cur][r][c0 + cc] = c[r][cc];
+                }
         }
+        LEAF_T(1);
         __syncthreads();
-        if (tx == kb) {
-            double lb[4][4];
-            if (ty > kb) {
-                double xi[4][4];
+        LEAF_T(2);
+        if (tx == kb && ty > kb && DCA_LEAF_ABLATE != 2) {
+            double xi[4][4], lb[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) xi[r][cc] = dinv[kb][r * 4 + cc];
+            // L(ty,kb) = C(ty,kb) * D^T.  Summation index outermost in all the small products of this kernel: a
+            // dependent f64 FMA issues ~30 clocks after its predecessor, 16 independent ones go back to back.
+            double lx[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) lb[r][m] = c[r][0] * xi[m][0];
+#pragma unroll
+            for (int cc = 1; cc < 4; ++cc)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xi[r][c] = dinv[kb][r * 4 + c];
-                // L(ty,kb) = A(ty,kb) * inv(L(kb,kb))^T
+                    for (int m = cc; m < 4; ++m) lb[r][m] = __builtin_fma(c[r][cc], xi[m][cc], lb[r][m]);
+            // (L D)[r][m] = sum_{k >= m} L[r][k] D[k][m]
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) lx[r][m] = lb[r][m] * xi[m][m];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int c = 0; c <= m; ++c) acc = __builtin_fma(a[r][c], xi[m][c], acc);
-                        lb[r][m] = acc;
-                    }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) lb[r][m] = 0.0;
-            }
+                    for (int m = 0; m < k; ++m) lx[r][m] = __builtin_fma(lb[r][k], xi[k][m], lx[r][m]);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    panel[cur][r0 + r][m] = lb[r][m];
-                    Lf[(r0 + r) * S + 4 * kb + m] = lb[r][m];
+                    panel[cur][m][r0 + r] = lb[r][m];
+                    panelx[cur][m][r0 + r] = lx[r][m];
+                    c[r][m] = 0.0;                               // the block starts over as B(ty,kb) = 0
                 }
+        } else if (ty == kb && tx < kb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) brow[cur][r][c0 + cc] = c[r][cc];
         }
+        LEAF_T(3);
         __syncthreads();
-        if (ty > kb && tx > kb) {
-            double pr[4][4], pc[4][4];
+        LEAF_T(4);
+        if (ty > kb && DCA_LEAF_ABLATE != 3) {
+            // one update for both roles: rows from panel / panelx, the other factor from panel (as columns) / brow
+            const bool chol = tx > kb;
+            const double* prow = chol ? &panel[cur][0][r0] : &panelx[cur][0][r0];      // pr(r, m) = prow[m * n + r]
+            const double* qbase = chol ? &panel[cur][0][c0] : &brow[cur][0][c0];       // q(m, cc) = qbase[m * n + cc]
+            double pr[4][4], q[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { pr[r][m] = panel[cur][r0 + r][m]; pc[r][m] = panel[cur][c0 + r][m]; }
+                for (int r = 0; r < 4; ++r) { pr[r][m] = prow[m * n + r]; q[m][r] = qbase[m * n + r]; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) a[r][c] = __builtin_fma(-pr[r][m], pc[c][m], a[r][c]);
+                    for (int cc = 0; cc < 4; ++cc) c[r][cc] = __builtin_fma(-pr[r][m], q[m][cc], c[r][cc]);
         }
+        LEAF_T(5);
     }
-
-    // ---- X = L^-1
-    double b[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) b[r][c] = (r0 + r == c0 + c) ? 1.0 : 0.0;
-    for (int kb = 0; kb < 16; ++kb) {
-        const int cur = kb & 1;
-        if (ty == kb) {
-            double xi[4][4], x[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) xi[r][c] = dinv[kb][r * 4 + c];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int m = 0; m <= r; ++m) acc = __builtin_fma(xi[r][m], b[m][c], acc);
-                    x[r][c] = acc;
-                }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { b[r][c] = x[r][c]; xrow[cur][r][c0 + c] = x[r][c]; }
-        }
-        __syncthreads();
-        if (ty > kb && tx <= kb) {
-            double lb[4][4], xr[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) { lb[r][m] = Lf[(r0 + r) * S + 4 * kb + m]; xr[r][m] = xrow[cur][r][c0 + m]; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) b[r][c] = __builtin_fma(-lb[r][m], xr[m][c], b[r][c]);
-        }
-    }
+    __syncthreads();
     if (tx <= ty) {
+        // X(ty,tx) = D_ty * B(ty,tx)
+        double xi[4][4], x[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c0 + c <= r0 + r) {
-                    M[(size_t)(r0 + r) * ld + c0 + c] = b[r][c];
-                    M[(size_t)(c0 + c) * ld + r0 + r] = b[r][c];
+            for (int cc = 0; cc < 4; ++cc) xi[r][cc] = dinv[ty][r * 4 + cc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) x[r][cc] = xi[r][0] * c[0][cc];
+#pragma unroll
+        for (int m = 1; m < 4; ++m)
+#pragma unroll
+            for (int r = m; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) x[r][cc] = __builtin_fma(xi[r][m], c[m][cc], x[r][cc]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                if (c0 + cc <= r0 + r) {
+                    M[(size_t)(r0 + r) * ld + c0 + cc] = x[r][cc];
+                    M[(size_t)(c0 + cc) * ld + r0 + r] = x[r][cc];
                 }
     }
 }
