@@ -512,25 +512,33 @@ __device__ __forceinline__ T slab_sum(const T* __restrict__ G, size_t off, size_
     return a;
 }
 
+// One WAVE per site pair (four pairs per workgroup): a pair is q*q = 441 elements, and with a workgroup per pair the
+// small configurations were bound by workgroup dispatch and three dependent global round trips per workgroup
+// (config C: 19 900 workgroups, 0.143 ms for 0.35 GB).
+constexpr int kFoldWaves = 4;
 template <typename T>
-__global__ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
-                                      const PairIJ* __restrict__ pairs, double* __restrict__ regPart,
-                                      int L, int q, int Cs, T lambdaJ, int addReg, size_t slabElems, int nsplit)
+__global__ __launch_bounds__(64 * kFoldWaves)
+void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
+                           const PairIJ* __restrict__ pairs, double* __restrict__ regPart,
+                           int L, int q, int Cs, T lambdaJ, int addReg, size_t slabElems, int nsplit, int npairs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
-    T* tile = reinterpret_cast<T*>(dca_smem);                 // G[(j,b)][(i,a)] stored as tile[b*q+a]
-    double* red = reinterpret_cast<double*>(dca_smem + ((size_t)q * q * sizeof(T) + 15) / 16 * 16);
-    const int p = blockIdx.x;
-    const int i = pairs[p].i, j = pairs[p].j;
     const int q2 = q * q;
-    for (int t = threadIdx.x; t < q2; t += blockDim.x) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    T* tile = reinterpret_cast<T*>(dca_smem) + (size_t)wave * ((q2 + 3) / 4 * 4);     // G[(j,b)][(i,a)] stored as tile[b*q+a]
+    const int p = blockIdx.x * kFoldWaves + wave;
+    if (p >= npairs) return;                                   // wave-uniform; no workgroup barriers below
+    const int i = pairs[p].i, j = pairs[p].j;
+    for (int t = lane; t < q2; t += 64) {
         const int b = t / q, a = t % q;
         tile[t] = slab_sum(G, (size_t)(j * q + b) * Cs + i * q + a, slabElems, nsplit);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const size_t base = (size_t)L * q + (size_t)p * q2;
     double reg = 0.0;
-    for (int t = threadIdx.x; t < q2; t += blockDim.x) {
+    for (int t = lane; t < q2; t += 64) {
         const int a = t / q, b = t % q;
         const T xv = x[base + t];
         T gv = addReg ? (T)2 * lambdaJ * xv : (T)0;
@@ -539,13 +547,8 @@ __global__ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restri
         g[base + t] = gv;
         if (addReg) reg += (double)lambdaJ * (double)xv * (double)xv;
     }
-    red[threadIdx.x] = reg;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) regPart[p] = red[0];
+    for (int off = 32; off > 0; off >>= 1) reg += __shfl_down(reg, off);      // fixed tree
+    if (lane == 0) regPart[p] = reg;
 }
 
 // g[h_i(a)] = 2 lambda_h h + sum_n R[n][(i,a)]; the column sum of R is the sum over b of
@@ -1216,9 +1219,9 @@ struct PlmEngine : PlmEngineBase {
                 hipLaunchKernelGGL(plm_sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, st, dG, (size_t)Grows * Cs, scatSplit);
                 foldSlabs = 1;
             }
-            const size_t lds = ((size_t)q * q * sizeof(T) + 15) / 16 * 16 + 256 * sizeof(double);
-            hipLaunchKernelGGL(plm_fold_pairs_kernel<T>, dim3((unsigned)npairs), dim3(256), lds, st, dx, dG, dg, dPairs,
-                               dRegPart, L, q, Cs, (T)lambda_J, add_reg, (size_t)Grows * Cs, foldSlabs);
+            const size_t lds = (size_t)kFoldWaves * ((q * q + 3) / 4 * 4) * sizeof(T);
+            hipLaunchKernelGGL(plm_fold_pairs_kernel<T>, dim3((unsigned)ceil_div((int)npairs, kFoldWaves)), dim3(64 * kFoldWaves), lds, st, dx, dG, dg, dPairs,
+                               dRegPart, L, q, Cs, (T)lambda_J, add_reg, (size_t)Grows * Cs, foldSlabs, (int)npairs);
             hipLaunchKernelGGL(plm_fold_fields_kernel<T>, dim3(ceil_div(Lq, 256)), dim3(256), 0, st, dx, dG, dg,
                                dRegPart + npairs, Lq, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, foldSlabs);
         }
