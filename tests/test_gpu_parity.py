@@ -468,3 +468,32 @@ def test_gradient_edge_shapes(L_, oracle_plm, N, L, q):
         assert abs(fx - fx_o) <= tol * abs(fx_o), (prec, fx, fx_o)
         assert rel_err(g, g_o) < tol, (prec, rel_err(g, g_o))
         ctx.close()
+
+
+def test_device_block_cache_reuse_and_release(L_):
+    """Device blocks of >= 1 MiB are recycled across contexts (csrc/capi.cpp dca_dev_malloc): a second context that
+    gets the first one's (dirty) blocks must produce the same bits, and dca_release_cached_memory hands the cache back."""
+    rng = np.random.default_rng(17)
+    N, L, q = 3000, 120, 21                      # (L q)^2 doubles = 50 MB, L x N list = 1.4 MB: well above the 1 MiB floor
+    X = rng.integers(0, q, size=(N, L), dtype=np.uint8)
+    X[N // 2:] = X[:N - N // 2]                  # duplicates give non-trivial weights
+    X[N // 2:, ::7] = rng.integers(0, q, size=(N - N // 2, len(range(0, L, 7))), dtype=np.uint8)
+    L_.release_cached_memory()
+
+    def run():
+        ctx = L_.Context(0, L_.DCA_F64)
+        ctx.set_msa(X, q)
+        ctx.compute_weights(0.8, L_.DCA_F64)
+        scores, J = ctx.mf_run(0.5, True, want_couplings=True)
+        order = ctx.scores_order()
+        ctx.close()
+        return scores, J, order
+
+    s1, J1, o1 = run()
+    s2, J2, o2 = run()                           # served from the cache
+    assert np.array_equal(s1, s2) and np.array_equal(J1, J2) and np.array_equal(o1, o2)
+    freed = L_.release_cached_memory()
+    assert freed >= (L * q) ** 2 * 8
+    assert L_.release_cached_memory() == 0
+    s3, _, _ = run()                             # fresh blocks again
+    assert np.array_equal(s1, s3)
