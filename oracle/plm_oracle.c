@@ -58,8 +58,8 @@ size_t oracle_num_params(int L, int q) { return plm_num_params(L, q); }
 
 /* residue table of readSequencesFromFile, plmdca_numerics.cpp:699-732.
  * biomolecule: 1 = protein (q=21), 2 = RNA (q=5).  Returns -1 for characters
- * the reference's map lacks (it throws std::out_of_range at :752), notably 'T'
- * in RNA. */
+ * the reference's map lacks (it throws std::out_of_range at :752).  The RNA map
+ * holds all 26 letters: everything but A, C, G, U is the gap state, 'T' too (:729). */
 int oracle_residue_code(int biomolecule, int ch)
 {
     ch = toupper(ch);
@@ -74,7 +74,6 @@ int oracle_residue_code(int biomolecule, int ch)
     switch (ch) {
         case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'U': return 3;
         case '-': case '~': case '.': return 4;
-        case 'T': return -1;
         default: return (ch >= 'A' && ch <= 'Z') ? 4 : -1;
     }
 }
@@ -103,7 +102,7 @@ int oracle_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int 
             if (!fgets(line + len, (int)(cap - len), fp)) break;
             len = strlen(line);
         }
-        while (len && (line[len - 1] == '\n' || line[len - 1] == '\r')) line[--len] = 0;
+        while (len && line[len - 1] == '\n') line[--len] = 0;   /* std::getline: only '\n' ends a line */
         if (!len || line[0] == '>') continue;
         if ((int)len < L) { rc = -2; break; }
         uint64_t h = 1469598103934665603ull;

@@ -186,7 +186,6 @@ int dca_count_msa_lines(const char* path)
     int n = 0, c, first = 1, is_seq = 0, nonempty = 0;
     while ((c = fgetc(fp)) != EOF) {
         if (c == '\n') { if (nonempty && is_seq) ++n; first = 1; nonempty = 0; is_seq = 0; continue; }
-        if (c == '\r') continue;
         if (first) { is_seq = (c != '>'); first = 0; }
         nonempty = 1;
     }

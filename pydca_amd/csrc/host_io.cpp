@@ -13,7 +13,8 @@
 
 namespace {
 
-// residue tables of plmdca_numerics.cpp:708-717 (protein) and :722-731 (RNA; no 'T')
+// residue tables of plmdca_numerics.cpp:708-717 (protein) and :722-731 (RNA: ACGU, the three gap
+// characters and every other capital letter -- 'T' included, :729 -- are the gap state)
 struct CodeTable {
     int8_t protein[256];
     int8_t rna[256];
@@ -24,7 +25,7 @@ struct CodeTable {
         for (int k = 0; aa[k]; ++k) protein[(unsigned char)aa[k]] = (int8_t)k;
         for (const char* p = "-.~BJOUXZ"; *p; ++p) protein[(unsigned char)*p] = 20;
         rna[(unsigned char)'A'] = 0; rna[(unsigned char)'C'] = 1; rna[(unsigned char)'G'] = 2; rna[(unsigned char)'U'] = 3;
-        for (const char* p = "-~.BDEFHIJKLMNOPQRSVWXYZ"; *p; ++p) rna[(unsigned char)*p] = 4;
+        for (const char* p = "-~.BDEFHIJKLMNOPQRSTVWXYZ"; *p; ++p) rna[(unsigned char)*p] = 4;
     }
 };
 const CodeTable kCodes;
@@ -47,7 +48,8 @@ int dca_read_msa_impl(const char* path, int biomolecule, int L, uint8_t* out, in
     std::string line, row((size_t)L, '\0');
     int nuniq = 0, nraw = 0;
     while (std::getline(in, line)) {
-        while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+        // like the reference, only '\n' ends a line (std::getline, :748): a '\r' beyond column L is never
+        // looked at, one inside the first L columns is a character its table lacks
         if (line.empty() || line[0] == '>') continue;
         if ((int)line.size() < L) {
             dca_set_error("sequence line %d of %s is shorter than %d", nraw + 1, path, L);

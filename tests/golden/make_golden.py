@@ -230,12 +230,73 @@ def params_golden(tag, path, bio, pseudocount, seqid):
     print("params_%s: %d default pairs, first %s" % (tag, len(out["default_pairs"]), out["default_pairs"][:1]))
 
 
+def reader_sweep_cases():
+    """Inputs of the reader sweep: every capital and small letter, the three gap characters, a
+    duplicate row, CRLF line ends, a line longer than L -- and the inputs on which the reference throws
+    (a character its table lacks, a line shorter than L, a line holding only a carriage return)."""
+    up = "ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+    body = (">upper\n%s\n>lower\n%s\n>gaps\n%s\n\n>dup of upper\n%s\n>long line\n%sACGU\n>mixed\n%s\n"
+            % (up, up.lower(), ("-.~" * 9)[:26], up, up[::-1], "aCgU-tT.~nNxX" * 2))
+    cases = [("alphabet", 26, body.encode()),
+             ("crlf", 4, b">a\r\nACGU\r\n>b\r\nACGT\r\n>c\r\nacgt\r\n"),
+             ("dna_letters", 8, b">a\nACGTACGT\n>b\nACGUACGU\n>c\nAC-TAC.T\n"),
+             ("err_star", 4, b">a\nACGU\n>b\nAC*U\n"),
+             ("err_digit", 4, b">a\nAC1U\n"),
+             ("err_space", 4, b">a\nAC U\n"),
+             ("err_short", 4, b">a\nACGU\n>b\nACG\n"),
+             ("err_blank_cr", 4, b">a\r\nACGU\r\n\r\n>b\r\nACGA\r\n")]
+    return cases
+
+
+def reader_golden():
+    """Expected rows (or "the reference throws") of PlmDCA::readSequencesFromFile
+    (plmdca_numerics.cpp:685-767) for reader_sweep_cases(), from the compiled reference.  Every case
+    runs in a child process: the reference throws C++ exceptions and an out-of-range read of a short
+    line is undefined behaviour there."""
+    import multiprocessing as mp
+    out = {}
+    names = []
+    for bio, q in ((1, 21), (2, 5)):
+        for name, L, text in reader_sweep_cases():
+            tag = "%s_%s" % ("protein" if bio == 1 else "rna", name)
+            path = os.path.join(tempfile.gettempdir(), "reader_sweep_%s.fa" % tag)
+            with open(path, "wb") as fh:
+                fh.write(text)
+            with mp.get_context("fork").Pool(1) as pool:
+                rows = pool.apply(_reader_child, (path, bio, L, q))
+            os.unlink(path)
+            names.append(tag)
+            out[tag + "_text"] = np.frombuffer(text, dtype=np.uint8)
+            out[tag + "_L"] = L
+            out[tag + "_bio"] = bio
+            out[tag + "_throws"] = rows is None
+            out[tag + "_rows"] = np.zeros((0, L), np.uint8) if rows is None else rows
+            print("reader %-22s %s" % (tag, "throws" if rows is None else "%d rows" % len(rows)))
+    out["cases"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "reader_sweep.npz"), **out)
+
+
+def _reader_child(path, bio, L, q):
+    try:
+        ref = oplm.Reference(path, bio, L, q, 0.8, 1.0, 1.0, threads=1)
+    except RuntimeError:
+        return None
+    rows = ref.seqs()
+    ref.close()
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-slow", action="store_true")
+    ap.add_argument("--only-reader", action="store_true", help="regenerate only reader_sweep.npz")
     ap.add_argument("--only-params", action="store_true", help="regenerate only params_*.npz")
     ap.add_argument("--only-di", action="store_true", help="regenerate only di_*.npz (needs plm_*.npz present)")
     args = ap.parse_args()
+    if args.only_reader:
+        oplm.build(ref=True)
+        reader_golden()
+        return
     if args.only_params:
         tmp = tempfile.mkdtemp(prefix="pydca_stubs_")
         try:
@@ -283,6 +344,7 @@ def main():
     make_toy(toy_prot, "ACDEFGHIKLMNPQRSTVWY-", 40, 8, 11)
 
     # ---- plmDCA via the compiled reference -------------------------------------
+    reader_golden()
     plm_golden("toy_rna", toy_rna, 2, 10, 5, 0.8, 1.8, 1.8, full_run={"a": (100, 1)})
     plm_golden("toy_protein", toy_prot, 1, 8, 21, 0.8, 1.0, 5.0, full_run={"a": (30, 1)})
     plm_golden("rf71", rf71, 2, 71, 5, 0.8, 1.0, 20.0, full_run={"a": (500, 1), "b": (500, 8)})

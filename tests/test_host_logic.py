@@ -68,8 +68,11 @@ def test_cxx_reader_semantics_bit_exact(tag, fname, bio):
 
 def test_cxx_reader_errors(tmp_path):
     from pydca_amd import _lib
-    p = tmp_path / "bad.fa"
-    p.write_text(">a\nACGT\n")            # 'T' is not in the reference's RNA table (it throws)
+    p = tmp_path / "dna.fa"
+    p.write_text(">a\nACGT\n")            # 'T' is the gap state in the reference's RNA table (:729)
+    X, raw = _lib.read_msa(str(p), 2, 4)
+    assert raw == 1 and X.tolist() == [[0, 1, 2, 4]]
+    p.write_text(">a\nAC*U\n")            # a character the table lacks: the reference throws (:752)
     with pytest.raises(_lib.DcaBackendError) as ei:
         _lib.read_msa(str(p), 2, 4)
     assert ei.value.code == -3
@@ -80,6 +83,29 @@ def test_cxx_reader_errors(tmp_path):
     p2.write_text(">a\nacgu-\n\n>b\nACGU-\n>c\nNNNN.\n")   # lower case, duplicate, empty line, unknown letters -> gap
     X, raw = _lib.read_msa(str(p2), 2, 5)
     assert raw == 3 and X.tolist() == [[0, 1, 2, 3, 4], [4, 4, 4, 4, 4]]
+
+
+def _reader_sweep_cases():
+    return [str(c) for c in golden("reader_sweep")["cases"]]
+
+
+@pytest.mark.parametrize("case", _reader_sweep_cases())
+def test_cxx_reader_sweep(case, tmp_path):
+    """dca_read_msa == PlmDCA::readSequencesFromFile on the alphabet sweep (all 26 letters in both
+    cases, the gap characters, duplicates, CRLF, long lines): rows array_equal to what the compiled
+    reference returned, an error code where it throws."""
+    from pydca_amd import _lib
+    G = golden("reader_sweep")
+    p = tmp_path / (case + ".fa")
+    p.write_bytes(G[case + "_text"].tobytes())
+    bio, L = int(G[case + "_bio"]), int(G[case + "_L"])
+    if bool(G[case + "_throws"]):
+        with pytest.raises(_lib.DcaBackendError) as ei:
+            _lib.read_msa(str(p), bio, L)
+        assert ei.value.code == -3
+    else:
+        X, raw = _lib.read_msa(str(p), bio, L)
+        assert np.array_equal(X, G[case + "_rows"])
 
 
 @pytest.mark.parametrize("tag,fname,bio", [("toy_rna", "toy_rna.fa", "rna"), ("toy_protein", "toy_protein.fa", "protein"),

@@ -147,12 +147,33 @@ def test_mf_notebook_kat(oracle_mf):
 
 
 def test_reader_codes(oracle_plm):
-    """plmdca_numerics.cpp:699-732: RNA map lacks 'T' (the reference throws)."""
+    """plmdca_numerics.cpp:699-732: the RNA map holds all 26 letters; everything but ACGU -- 'T' too,
+    :729 -- is the gap state."""
     L = oracle_plm.lib()
-    assert L.oracle_residue_code(2, ord("T")) == -1 and L.oracle_residue_code(2, ord("t")) == -1
+    assert L.oracle_residue_code(2, ord("T")) == 4 and L.oracle_residue_code(2, ord("t")) == 4
     assert L.oracle_residue_code(2, ord("u")) == 3 and L.oracle_residue_code(2, ord("N")) == 4
     assert L.oracle_residue_code(1, ord("X")) == 20 and L.oracle_residue_code(1, ord("y")) == 19
-    assert L.oracle_residue_code(1, ord("*")) == -1
+    assert L.oracle_residue_code(1, ord("*")) == -1 and L.oracle_residue_code(2, ord("*")) == -1
+
+
+def reader_sweep_cases():
+    G = golden("reader_sweep")
+    return [str(c) for c in G["cases"]]
+
+
+@pytest.mark.parametrize("case", reader_sweep_cases())
+def test_reader_sweep_oracle(oracle_plm, case, tmp_path):
+    """oracle_read_msa == PlmDCA::readSequencesFromFile (plmdca_numerics.cpp:685-767) on the alphabet
+    sweep: rows array_equal where the reference returns, an error where it throws."""
+    G = golden("reader_sweep")
+    p = tmp_path / (case + ".fa")
+    p.write_bytes(G[case + "_text"].tobytes())
+    if bool(G[case + "_throws"]):
+        with pytest.raises(RuntimeError):
+            oracle_plm.read_msa(str(p), int(G[case + "_bio"]), int(G[case + "_L"]))
+    else:
+        X, raw = oracle_plm.read_msa(str(p), int(G[case + "_bio"]), int(G[case + "_L"]))
+        assert np.array_equal(X, G[case + "_rows"])
 
 
 DI_CASES = [("toy_rna", "toy_rna.fa", "RNA"), ("toy_protein", "toy_protein.fa", "PROTEIN"),
