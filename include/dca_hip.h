@@ -184,6 +184,12 @@ int dca_plm_pair_couplings(dca_ctx* ctx, const int* pairs, int npairs, int shift
 int dca_di_from_arrays(dca_ctx* ctx, const double* couplings, int layout, const double* reg_fi, int L, int q,
                        double* fields_out, double* di_out);
 
+/* compute_direct_info with the caller's own two-site model fields (its `fields_ij` argument,
+ * meanfield_dca/msa_numerics.py:473-533, plmdca/msa_numerics.py:249-311): fields_ij is [pairs][2][q] HOST doubles
+ * and is used as given -- no fixed-point iteration runs.  di_out: [pairs]. */
+int dca_di_from_fields(dca_ctx* ctx, const double* couplings, int layout, const double* reg_fi, const double* fields_ij,
+                       int L, int q, double* di_out);
+
 /* ------------------------------------------------------------------ ranking
  * Pair indices of the most recent score vector computed on this context (dca_plm_scores,
  * dca_plm_di_scores, dca_mf_scores, dca_mf_di_scores, dca_mf_run) in descending score order,

@@ -230,12 +230,15 @@ def two_site_model_fields(blocks, reg_fi, L, q, tol=1.0e-4):
     return E, hi, hj
 
 
-def direct_info(blocks, reg_fi, L, q):
+def direct_info(blocks, reg_fi, L, q, fields_ij=None):
     """compute_direct_info (meanfield_dca/msa_numerics.py:473-533; plmdca twin :249-311):
-    P_dir = E * h_i h_j^T / sum; DI = sum_{a,b<q-1} (P+eps) log((P+eps)/(f_i f_j+eps))."""
+    P_dir = E * h_i h_j^T / sum; DI = sum_{a,b<q-1} (P+eps) log((P+eps)/(f_i f_j+eps)).
+    fields_ij [pairs, 2, q]: the caller's two-site model fields (the reference uses the array it is given)."""
     eps = 1.0e-20
     iu, ju = np.triu_indices(L, k=1)
     E, hi, hj = two_site_model_fields(blocks, reg_fi, L, q)
+    if fields_ij is not None:
+        hi, hj = np.asarray(fields_ij)[:, 0, :], np.asarray(fields_ij)[:, 1, :]
     pdir = E * hi[:, :, None] * hj[:, None, :]
     pdir /= pdir.sum(axis=(1, 2), keepdims=True)
     pdir += eps

@@ -201,6 +201,24 @@ class Reference:
         fx = self._lib.ref_gradient(self._h, np.ascontiguousarray(x, dtype=np.float32), g)
         return float(fx), g
 
+    def lbfgs_run(self, max_iterations):
+        """The reference's own lbfgs() (lbfgs.cpp:248-644) on its own PlmDCA::gradient with the
+        backend's parameters (plmdcaBackend.cpp:67-77), recorded by oracle/ref_driver.cpp:
+        -> dict(x, fx, status, iterations, evaluations, trace[iterations, 5] = fx, xnorm, gnorm, step, ls)."""
+        f = self._lib.ref_lbfgs_run
+        fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_uint, fp, C.POINTER(C.c_float), C.POINTER(C.c_int),
+                      C.POINTER(C.c_int), fp, C.c_int]
+        P = num_params(self.L, self.q)
+        x = np.zeros(P, dtype=np.float32)
+        cap = max(1, int(max_iterations))
+        trace = np.zeros((cap, 5), dtype=np.float32)
+        fx, it, ev = C.c_float(0), C.c_int(0), C.c_int(0)
+        status = f(self._h, P, int(max_iterations), x, C.byref(fx), C.byref(it), C.byref(ev), trace, cap)
+        return dict(x=x, fx=float(fx.value), status=int(status), iterations=it.value, evaluations=ev.value,
+                    trace=trace[:it.value].copy())
+
     def backend(self, msa_file, biomolecule, seqid, lambda_h, lambda_J, max_iterations, threads=1):
         """Full run through the reference's own extern "C" plmdcaBackend
         (plmdcaBackend.cpp:151-201), bound exactly as plmdca.py:79-89 does."""

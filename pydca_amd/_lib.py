@@ -81,6 +81,7 @@ def lib():
         "dca_plm_set_reduce_hook": (i, [vp, REDUCE_HOOK, vp]),
         "dca_mf_set_reduce_hook": (i, [vp, REDUCE_HOOK, vp]),
         "dca_di_from_arrays": (i, [vp, vp, i, vp, i, i, vp, vp]),
+        "dca_di_from_fields": (i, [vp, vp, i, vp, vp, i, i, vp]),
         "dca_plm_set_vector_sharding": (i, [vp, i, i, COMM_HOOK, vp]),
         "dca_plm_lbfgs_begin": (i, [vp, i, i]),
         "dca_plm_lbfgs_iterate": (i, [vp, i, C.POINTER(PlmStats)]),
@@ -120,7 +121,7 @@ def lib():
 EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_num_params", "dca_plm_init_x",
-           "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_di_from_arrays", "dca_plm_set_vector_sharding",
+           "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_di_from_arrays", "dca_di_from_fields", "dca_plm_set_vector_sharding",
            "dca_plm_lbfgs_begin", "dca_plm_lbfgs_iterate", "dca_plm_scores", "dca_plm_di_scores",
            "dca_mf_di_scores", "dca_plm_pair_couplings", "dca_mf_fields", "dca_mf_pair_couplings",
            "dca_mf_single_site_freqs",
@@ -311,6 +312,18 @@ class Context:
         check(self._l.dca_di_from_arrays(self._h, _ptr(couplings), int(layout), _ptr(reg_fi), int(L), int(q),
                                          _ptr(fields) if want_fields else None, _ptr(di) if want_di else None))
         return fields, di
+
+    def di_from_fields(self, couplings, layout, reg_fi, fields_ij, L, q):
+        """DI from the caller's two-site model fields [pairs, 2, q] (no fixed point is run)."""
+        couplings = np.ascontiguousarray(couplings, dtype=np.float64)
+        reg_fi = np.ascontiguousarray(reg_fi, dtype=np.float64)
+        npairs = L * (L - 1) // 2
+        fields_ij = np.ascontiguousarray(fields_ij, dtype=np.float64)
+        if fields_ij.shape != (npairs, 2, q):
+            raise ValueError("fields_ij must have shape (L(L-1)/2, 2, q)")
+        di = np.zeros(npairs, dtype=np.float64)
+        check(self._l.dca_di_from_fields(self._h, _ptr(couplings), int(layout), _ptr(reg_fi), _ptr(fields_ij), int(L), int(q), _ptr(di)))
+        return di
 
     def scores_order(self):
         """Pair indices of the last score vector, best first (device radix sort, stable)."""

@@ -436,6 +436,13 @@ int dca_di_from_arrays(dca_ctx* ctx, const double* couplings, int layout, const 
     if (!couplings || !reg_fi || (layout != 1 && layout != 2) || (!fields_out && !di_out)) return DCA_ERR_ARG;
     return dca_di_from_arrays_impl(ctx, couplings, layout, reg_fi, L, q, fields_out, di_out);
 }
+int dca_di_from_fields(dca_ctx* ctx, const double* couplings, int layout, const double* reg_fi, const double* fields_ij,
+                       int L, int q, double* di_out)
+{
+    CHECK_CTX(ctx);
+    if (!couplings || !reg_fi || !fields_ij || !di_out || (layout != 1 && layout != 2)) return DCA_ERR_ARG;
+    return dca_di_from_arrays_impl(ctx, couplings, layout, reg_fi, L, q, nullptr, di_out, fields_ij);
+}
 int dca_mf_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user)
 {
     CHECK_CTX(ctx);

@@ -152,7 +152,7 @@ int dca_pair_blocks(dca_ctx* ctx, const void* src, int src_kind, int dtype, int 
                     int shift, double* out /* host */);
 
 int dca_di_from_arrays_impl(dca_ctx* ctx, const double* couplings, int layout, const double* reg_fi, int L, int q,
-                            double* fields_out, double* di_out);
+                            double* fields_out, double* di_out, const double* fields_in = nullptr);
 
 // ---- mf engine
 struct MfEngine;

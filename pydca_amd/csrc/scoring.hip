@@ -124,7 +124,7 @@ __global__ void apc_apply_kernel(double* __restrict__ fn, const double* __restri
 template <typename S>
 __global__ __launch_bounds__(64)
 void di_kernel(const S* __restrict__ src, int kind, const double* __restrict__ regfi, int L, int q, int ld,
-               double* __restrict__ di, double* __restrict__ fields)
+               double* __restrict__ di, double* __restrict__ fields, const double* __restrict__ fields_in = nullptr)
 {
     __shared__ double E[21 * 21];
     __shared__ double fi[21], fj[21], hi[21], hj[21], ni[21], nj[21];
@@ -154,8 +154,12 @@ void di_kernel(const S* __restrict__ src, int kind, const double* __restrict__ r
         E[e] = exp(v);
     }
     if (t < q) { fi[t] = regfi[i * q + t]; fj[t] = regfi[j * q + t]; hi[t] = hj[t] = 1.0 / (double)q; }
+    if (fields_in && t < q) {      // the caller's two-site model fields (compute_direct_info's fields_ij argument)
+        hi[t] = fields_in[(p * 2 + 0) * q + t];
+        hj[t] = fields_in[(p * 2 + 1) * q + t];
+    }
     __syncthreads();
-    for (int iter = 0; iter < 100000; ++iter) {
+    for (int iter = 0; iter < (fields_in ? 0 : 100000); ++iter) {
         if (t < q) {
             double x = 0.0;
             for (int b = 0; b < q; ++b) x += E[t * q + b] * hj[b];
@@ -277,9 +281,9 @@ int dca_di_scores(dca_ctx* ctx, const void* src, int src_kind, int dtype, const 
     const size_t npairs = (size_t)L * (L - 1) / 2;
     ScopedKernelClock kc(ctx, "scores");
     if (dtype == DCA_F32)
-        hipLaunchKernelGGL(di_kernel<float>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const float*>(src), src_kind, dRegFi, L, q, ld, dOut, static_cast<double*>(nullptr));
+        hipLaunchKernelGGL(di_kernel<float>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const float*>(src), src_kind, dRegFi, L, q, ld, dOut, static_cast<double*>(nullptr), static_cast<const double*>(nullptr));
     else
-        hipLaunchKernelGGL(di_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const double*>(src), src_kind, dRegFi, L, q, ld, dOut, static_cast<double*>(nullptr));
+        hipLaunchKernelGGL(di_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, static_cast<const double*>(src), src_kind, dRegFi, L, q, ld, dOut, static_cast<double*>(nullptr), static_cast<const double*>(nullptr));
     if (apc) {
         double* dAv = nullptr;
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dAv), (size_t)(L + 1) * sizeof(double)));
@@ -325,26 +329,28 @@ int dca_pair_blocks(dca_ctx* ctx, const void* src, int src_kind, int dtype, int 
 // reference: compute_two_site_model_fields / compute_direct_info, meanfield_dca/msa_numerics.py:378-533
 // with the n x n couplings matrix, plmdca/msa_numerics.py:156-311 with the gap-stripped 1-D array).
 int dca_di_from_arrays_impl(dca_ctx* ctx, const double* couplings, int layout, const double* reg_fi, int L, int q,
-                            double* fields_out, double* di_out)
+                            double* fields_out, double* di_out, const double* fields_in)
 {
     if (q > 21 || q < 2 || L < 2) { dca_set_error("dca_di_from_arrays: bad L / q"); return DCA_ERR_ARG; }
     const int qm = q - 1, n = L * qm;
     const size_t npairs = (size_t)L * (L - 1) / 2;
     const size_t nc = layout == 1 ? (size_t)n * n : npairs * qm * qm;
-    double *dC = nullptr, *dF = nullptr, *dDi = nullptr, *dFields = nullptr;
+    double *dC = nullptr, *dF = nullptr, *dDi = nullptr, *dFields = nullptr, *dFieldsIn = nullptr;
     hipError_t e = dca_dev_malloc(reinterpret_cast<void**>(&dC), nc * sizeof(double));
+    if (e == hipSuccess && fields_in) e = dca_dev_malloc(reinterpret_cast<void**>(&dFieldsIn), npairs * 2 * q * sizeof(double));
+    if (e == hipSuccess && fields_in) e = hipMemcpy(dFieldsIn, fields_in, npairs * 2 * q * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&dF), (size_t)L * q * sizeof(double));
     if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&dDi), npairs * sizeof(double));
     if (e == hipSuccess && fields_out) e = dca_dev_malloc(reinterpret_cast<void**>(&dFields), npairs * 2 * q * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(dC, couplings, nc * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dF, reg_fi, (size_t)L * q * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(di_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, dC, layout == 1 ? 1 : 2, dF, L, q, n, dDi, dFields);
+        hipLaunchKernelGGL(di_kernel<double>, dim3((unsigned)npairs), dim3(64), 0, ctx->stream, dC, layout == 1 ? 1 : 2, dF, L, q, n, dDi, dFields, dFieldsIn);
         e = hipStreamSynchronize(ctx->stream);
     }
     if (e == hipSuccess && di_out) e = hipMemcpy(di_out, dDi, npairs * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess && fields_out) e = hipMemcpy(fields_out, dFields, npairs * 2 * q * sizeof(double), hipMemcpyDeviceToHost);
-    dca_dev_free(dC); dca_dev_free(dF); dca_dev_free(dDi); dca_dev_free(dFields);
+    dca_dev_free(dC); dca_dev_free(dF); dca_dev_free(dDi); dca_dev_free(dFields); dca_dev_free(dFieldsIn);
     if (e != hipSuccess) { dca_set_error("dca_di_from_arrays: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     return DCA_OK;
 }

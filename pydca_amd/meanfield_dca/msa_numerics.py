@@ -112,10 +112,12 @@ def compute_two_site_model_fields(couplings=None, reg_fi=None, seqs_len=None, nu
 
 
 def compute_direct_info(couplings=None, fields_ij=None, reg_fi=None, seqs_len=None, num_site_states=None):
-    """msa_numerics.py:473-533 -> float64[pairs].  fields_ij is accepted for signature compatibility;
-    the kernel recomputes the fields (they are a function of couplings and reg_fi)."""
+    """msa_numerics.py:473-533 -> float64[pairs].  fields_ij, when given, is used as it is (the reference
+    does); without it the two-site model fields are computed on the device first."""
     ctx = _lib.Context(_DEVICE, _lib.DCA_F64)
     try:
+        if fields_ij is not None:
+            return ctx.di_from_fields(couplings, 1, reg_fi, fields_ij, int(seqs_len), int(num_site_states))
         return ctx.di_from_arrays(couplings, 1, reg_fi, int(seqs_len), int(num_site_states))[1]
     finally:
         ctx.close()

@@ -40,10 +40,13 @@ def compute_two_site_model_fields(couplings=None, reg_fi=None, seqs_len=None, nu
 
 
 def compute_direct_info(couplings=None, fields_ij=None, reg_fi=None, seqs_len=None, num_site_states=None):
-    """plmdca/msa_numerics.py:249-311 -> float64[pairs] (fields_ij accepted, recomputed on the device)."""
+    """plmdca/msa_numerics.py:249-311 -> float64[pairs].  fields_ij, when given, is used as it is (the
+    reference does); without it the two-site model fields are computed on the device first."""
     c = _check(couplings, seqs_len, num_site_states)
     ctx = _lib.Context(_DEVICE, _lib.DCA_F64)
     try:
+        if fields_ij is not None:
+            return ctx.di_from_fields(c, 2, reg_fi, fields_ij, int(seqs_len), int(num_site_states))
         return ctx.di_from_arrays(c, 2, reg_fi, int(seqs_len), int(num_site_states))[1]
     finally:
         ctx.close()

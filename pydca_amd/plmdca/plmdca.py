@@ -257,6 +257,29 @@ class PlmDCA:
         couplings_ranked = [(pair, blocks[k].reshape(-1)) for k, pair in enumerate(names)]
         return tuple(fields_mapped), tuple(couplings_ranked)
 
+    def compute_seqs_weight(self):
+        """plmdca.py:565-591: weights of the PYTHON reader's alignment (float64 comparison,
+        plmdca/msa_numerics.py:13-49), computed on the device; remembered with their sum like the
+        reference remembers them."""
+        from ..fasta_reader import fasta_reader
+        from . import msa_numerics
+        logger.info('\n\tComputing sequences weight with sequence identity {}'.format(self.__seqid))
+        aln = np.array(fasta_reader.get_alignment_int_form(self.__msa_file, biomolecule=self.__biomolecule))
+        seqs_weight = msa_numerics.compute_sequences_weight(alignment_data=aln, sequence_identity=self.__seqid)
+        self.__seqs_weight = seqs_weight
+        self.__eff_num_seqs = np.sum(seqs_weight)
+        logger.info('\n\tEffective number of sequences: {}'.format(self.__eff_num_seqs))
+        return seqs_weight
+
+    def compute_two_site_model_fields(self, couplings):
+        """plmdca.py:652-680: couplings is the gap-stripped 1-D array of get_couplings_no_gap_state;
+        -> float64[L(L-1)/2, 2, q], one workgroup per site pair on the device."""
+        from . import msa_numerics
+        reg_fi = self.get_reg_single_site_freqs()
+        logger.info('\n\tComputing two-site model fields')
+        return msa_numerics.compute_two_site_model_fields(couplings=couplings, reg_fi=reg_fi, seqs_len=self.__seqs_len,
+                                                          num_site_states=self.__num_site_states)
+
     def get_single_site_freqs(self):
         """plmdca.py:590-621: frequencies of the PYTHON reader's alignment (unknown letters -> gap,
         duplicates dropped, fasta_reader.py:122-163) with float64 weights, on the device."""

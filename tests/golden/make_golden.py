@@ -230,6 +230,48 @@ def params_golden(tag, path, bio, pseudocount, seqid):
     print("params_%s: %d default pairs, first %s" % (tag, len(out["default_pairs"]), out["default_pairs"][:1]))
 
 
+def runs_golden():
+    """plm_runs.npz: (a) the reference's own lbfgs() on its own gradient, 1 thread (deterministic), on the
+    three small alignments -- status, iterations, evaluations and the full-precision per-iteration
+    (fx, xnorm, gnorm, step, ls), i.e. what plmdcaBackend.cpp:137-146 prints in verbose mode, plus the
+    final x, checked here to be bit-equal to what `plmdcaBackend` itself returns; (b) the reference's
+    run-to-run spread: three runs (8, 8 and 1 threads) on RF00167 with the default
+    lambda = 0.2 (L-1) and 100 iterations, and on the trimmed 71-column alignment with the notebook's
+    parameters; stored as FN / FN_APC (float64 from the float32 parameters) with status and counts."""
+    from oracle import mf as omf
+    out = {}
+    small = (("toy_rna", "toy_rna.fa", 2, 10, 5, 1.8, 1.8, 100), ("toy_protein", "toy_protein.fa", 1, 8, 21, 1.0, 5.0, 30),
+             ("rf71", "MSA_RF00167_trimmed71.fa", 2, 71, 5, 1.0, 20.0, 500))
+    for tag, fname, bio, L, q, lh, lJ, mit in small:
+        path = os.path.join(DATA, fname)
+        ref = oplm.Reference(path, bio, L, q, 0.8, lh, lJ, threads=1)
+        r = ref.lbfgs_run(mit)
+        xb = ref.backend(path, bio, 0.8, lh, lJ, mit, threads=1)
+        assert np.array_equal(xb, r["x"]), tag           # recorder == the reference's own entry point
+        ref.close()
+        out.update({tag + "_x": r["x"], tag + "_fx": np.float32(r["fx"]), tag + "_status": r["status"],
+                    tag + "_iterations": r["iterations"], tag + "_evaluations": r["evaluations"],
+                    tag + "_trace": r["trace"], tag + "_max_iterations": mit,
+                    tag + "_lambda_h": np.float32(lh), tag + "_lambda_J": np.float32(lJ)})
+        print("runs %-12s status %d iterations %d evaluations %d" % (tag, r["status"], r["iterations"], r["evaluations"]))
+    spread = (("rf00167", "MSA_RF00167.fa", 102, 20.2, 20.2, 100), ("rf71", "MSA_RF00167_trimmed71.fa", 71, 1.0, 20.0, 500))
+    for tag, fname, L, lh, lJ, mit in spread:
+        path = os.path.join(DATA, fname)
+        fn, apc, st = [], [], []
+        for thr in (8, 8, 1):
+            ref = oplm.Reference(path, 2, L, 5, 0.8, lh, lJ, threads=thr)
+            r = ref.lbfgs_run(mit)
+            ref.close()
+            fn.append(omf.plm_fn(r["x"], L, 5, apc_correct=False))
+            apc.append(omf.plm_fn(r["x"], L, 5, apc_correct=True))
+            st.append((r["status"], r["iterations"], r["evaluations"], thr))
+            print("spread %-8s threads %d: status %d iterations %d evaluations %d" % (tag, thr, *st[-1][:3]))
+        out.update({"spread_%s_fn" % tag: np.array(fn), "spread_%s_apc" % tag: np.array(apc),
+                    "spread_%s_stats" % tag: np.array(st, dtype=np.int32), "spread_%s_max_iterations" % tag: mit,
+                    "spread_%s_lambda_h" % tag: np.float32(lh), "spread_%s_lambda_J" % tag: np.float32(lJ)})
+    np.savez_compressed(os.path.join(HERE, "plm_runs.npz"), **out)
+
+
 def reader_sweep_cases():
     """Inputs of the reader sweep: every capital and small letter, the three gap characters, a
     duplicate row, CRLF line ends, a line longer than L -- and the inputs on which the reference throws
@@ -290,12 +332,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-slow", action="store_true")
     ap.add_argument("--only-reader", action="store_true", help="regenerate only reader_sweep.npz")
+    ap.add_argument("--only-runs", action="store_true", help="regenerate only plm_runs.npz (needs data/ present)")
     ap.add_argument("--only-params", action="store_true", help="regenerate only params_*.npz")
     ap.add_argument("--only-di", action="store_true", help="regenerate only di_*.npz (needs plm_*.npz present)")
     args = ap.parse_args()
     if args.only_reader:
         oplm.build(ref=True)
         reader_golden()
+        return
+    if args.only_runs:
+        oplm.build(ref=True)
+        runs_golden()
         return
     if args.only_params:
         tmp = tempfile.mkdtemp(prefix="pydca_stubs_")
@@ -351,6 +398,7 @@ def main():
     plm_golden("rf00167", rf, 2, 102, 5, 0.8, 20.2, 20.2, subsample=97)
     if not args.skip_slow:
         plm_golden("pf02826", pf, 1, 195, 21, 0.8, 1.0, 50.0, subsample=9973)
+    runs_golden()
 
     # ---- mfDCA via the stubbed import of the reference ---------------------------
     tmp = tempfile.mkdtemp(prefix="pydca_stubs_")

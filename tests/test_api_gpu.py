@@ -264,6 +264,12 @@ def test_direct_information_through_the_classes(tmp_path):
     assert [p for p, _ in pdi[:3]] == [(int(iu[k]), int(ju[k])) for k in ref_order[:3]]
     assert abs(pdi[0][1] - T["plm_di"][ref_order[0]]) < 2e-2 * T["plm_di"][ref_order[0]]
     assert len(inst.compute_sorted_DI_APC()) == 45
+    # PlmDCA.compute_seqs_weight (plmdca.py:565-591) and compute_two_site_model_fields (:652-680) against the
+    # reference's own output: weights of the Python reader's alignment, fields of the stored reference run
+    np.testing.assert_array_equal(inst.compute_seqs_weight(), golden("mf_toy_rna")["w"])
+    Lt, qt = int(T["L"]), int(T["q"])
+    blocks = golden("plm_toy_rna")["run_a"][Lt * qt:].reshape(Lt * (Lt - 1) // 2, qt, qt)[:, :qt - 1, :qt - 1].reshape(-1)
+    np.testing.assert_allclose(inst.compute_two_site_model_fields(blocks), T["plm_fields"], rtol=1e-10, atol=1e-13)
     out = mfdca_main.run_meanfield_dca(["compute_di", "rna", data_file("toy_rna.fa"), "--apc", "--output_dir",
                                         str(tmp_path / "m")])
     assert os.path.basename(out) == "MFDCA_apc_di_scores_toy_rna.txt"
@@ -457,6 +463,19 @@ def test_msa_numerics_direct_information_functions():
     np.testing.assert_allclose(f2, D["plm_fields"], rtol=1e-10, atol=1e-13)
     d2 = plm_num.compute_direct_info(couplings=blocks, fields_ij=f2, reg_fi=D["plm_reg_fi"], seqs_len=L, num_site_states=q)
     np.testing.assert_allclose(d2, D["plm_di"], rtol=1e-9, atol=1e-14)
+    # a caller's own fields_ij is used as given, like the reference does (not silently recomputed)
+    from oracle import mf as omf
+    rng = np.random.default_rng(4)
+    other = rng.random(f2.shape) + 0.1
+    other /= other.sum(axis=2, keepdims=True)
+    blk3 = blocks.reshape(-1, q - 1, q - 1).astype(np.float64)
+    want = omf.direct_info(blk3, D["plm_reg_fi"], L, q, fields_ij=other)
+    d3 = plm_num.compute_direct_info(couplings=blocks, fields_ij=other, reg_fi=D["plm_reg_fi"], seqs_len=L, num_site_states=q)
+    np.testing.assert_allclose(d3, want, rtol=1e-10, atol=1e-14)
+    assert not np.allclose(d3, d2, rtol=1e-3)
+    d4 = mf_num.compute_direct_info(couplings=M["couplings"], fields_ij=other, reg_fi=M["reg_fi"], seqs_len=L, num_site_states=q)
+    want4 = omf.direct_info(omf.mf_blocks(M["couplings"], L, q), M["reg_fi"], L, q, fields_ij=other)
+    np.testing.assert_allclose(d4, want4, rtol=1e-10, atol=1e-14)
     X1 = M["X"]
     np.testing.assert_array_equal(plm_num.compute_sequences_weight(alignment_data=X1, sequence_identity=0.8), M["w"])
     with pytest.raises(ValueError):

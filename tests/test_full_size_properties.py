@@ -1,4 +1,5 @@
-"""Full-size checks of the HIP path at BASELINE.json's configurations D (protein L=500 N=50 000 q=21) and
+"""Full-size checks of the HIP path at BASELINE.json's configurations C (protein L=200 N=10 000 q=21; compared
+element-wise with the oracle in tests/test_gpu_configs.py as well), D (protein L=500 N=50 000 q=21) and
 E (RNA L=150 N=200 000 q=5), where the CPU oracle needs about a minute per evaluation even on all host
 cores: size-independent properties of the algorithm instead of element-wise comparison.
 
@@ -27,7 +28,7 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, ROOT)
 from tools.gen_msa import SEEDS, dedup, generate  # noqa: E402
 
-CONFIGS = {"D": (500, 50000, 21, 1.0, 50.0), "E": (150, 200000, 5, 29.8, 29.8)}
+CONFIGS = {"C": (200, 10000, 21, 1.0, 50.0), "D": (500, 50000, 21, 1.0, 50.0), "E": (150, 200000, 5, 29.8, 29.8)}
 
 
 @pytest.fixture(scope="module")
@@ -61,7 +62,7 @@ def perturbed_start(ctx, L, q, dtype):
     return x
 
 
-@pytest.mark.parametrize("tag", ["D", "E"])
+@pytest.mark.parametrize("tag", ["C", "D", "E"])
 def test_plm_gradient_marginals_full_size(L_, tag):
     L, _, q, lh, lJ = CONFIGS[tag]
     X = msa(tag)
@@ -148,7 +149,7 @@ def test_plm_exact_mode_directional_derivative_and_additivity_full_size(L_):
     del fx0
 
 
-@pytest.mark.parametrize("tag", ["D", "E"])
+@pytest.mark.parametrize("tag", ["C", "D", "E"])
 def test_weights_sampled_rows_full_size(L_, tag):
     L, _, q = CONFIGS[tag][:3]
     X = msa(tag)

@@ -1,0 +1,201 @@
+"""BASELINE.json configurations B (mfdca protein, synthetic L=200 N=10k q=21) and C (plmdca compute_fn protein,
+same alignment, lambda_h=1 lambda_J=50, tolerance 1e-4) on the GPU against the CPU oracle, and the P4 report of
+SURVEY 8c4: the shipped float32 / chunked-scan path beside the reference's own run-to-run spread.
+
+The oracle needs seconds per evaluation at these sizes on the GPU box's host cores, so the comparison is direct
+(element-wise), not through properties.  Run on an MI355X:  python -m pytest tests -m gpu -x -q
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, perturbed, rel_err
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, ROOT)
+from tools.gen_msa import SEEDS, dedup, generate  # noqa: E402
+
+L_C, N_C, Q_C = 200, 10000, 21
+LAMBDA_H, LAMBDA_J = 1.0, 50.0
+
+
+@pytest.fixture(scope="module")
+def L_():
+    from pydca_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def msa_C():
+    """seed 12345, the alignment of configs B and C (0-based, gap = 20), de-duplicated."""
+    return dedup(generate(L_C, N_C, Q_C, SEEDS["C"]))
+
+
+def _ctx(L_, X, q, precision, cmp):
+    ctx = L_.Context(0, precision)
+    ctx.set_msa(X, q)
+    ctx.compute_weights(0.8, cmp)
+    return ctx
+
+
+def _top(a, L):
+    return np.argsort(-a, kind="stable")[:L]
+
+
+def test_config_C_weights_and_fixed_x_vs_oracle(L_, oracle_plm, msa_C):
+    """Config C, fixed x (initial point and the perturbed point of the goldens' recipe): float32 kernels <= 1e-5,
+    float64 kernels <= 1e-10 against oracle.plm.gradient (reference semantics, carry-over on); weights bit-exact."""
+    X, q = msa_C, Q_C
+    for prec, wtype, tol_fx, tol_g in ((L_.DCA_F32, np.float32, 2e-6, 1e-5), (L_.DCA_F64, np.float64, 1e-10, 1e-10)):
+        # float32 context: float compare and float32 1/count as plmdca_numerics.cpp:642,669; float64 context: the
+        # double compare and double 1/count of the float64 oracle
+        w = oracle_plm.weights(X, 0.8, wtype)
+        x0 = oracle_plm.init_x(X, w, q)
+        xs = (x0, perturbed(x0, L_C, q))
+        ctx = _ctx(L_, X, q, prec, prec)
+        assert np.array_equal(ctx.weights().astype(wtype), w)
+        ctx.plm_configure(LAMBDA_H, LAMBDA_J)                       # default = chunked scan, the shipped mode
+        ctx.plm_init_x()
+        np.testing.assert_allclose(ctx.plm_get_x(wtype), x0, rtol=2e-6, atol=2e-6)
+        for x in xs:
+            fx_o, g_o = oracle_plm.gradient(X, w.astype(np.float64), q, LAMBDA_H, LAMBDA_J, x.astype(np.float64), carry=True)
+            ctx.plm_set_x(x)
+            fx = ctx.plm_gradient()
+            g = ctx.plm_get_g(np.float64)
+            assert abs(fx - fx_o) <= tol_fx * abs(fx_o), (prec, fx, fx_o)
+            assert rel_err(g, g_o) < tol_g, (prec, rel_err(g, g_o))
+        ctx.close()
+
+
+def test_config_C_lbfgs_P3_chunked_float64(L_, oracle_plm, oracle_mf, msa_C):
+    """P3 at config C (BASELINE.json: "DI/FN score tolerance 1e-4"): 10 L-BFGS iterations, float64, the chunked
+    scan the product ships, against oracle.plm.lbfgs with the same cap => same status / iterations / evaluations,
+    FN and FN_APC <= 1e-4 relative, identical top-L order."""
+    X, q, L, iters = msa_C, Q_C, L_C, 10
+    w64 = oracle_plm.weights(X, 0.8, np.float64)
+    ref = oracle_plm.lbfgs(X, w64, q, LAMBDA_H, LAMBDA_J, iters, oracle_plm.init_x(X, w64, q), carry=True)
+    ctx = _ctx(L_, X, q, L_.DCA_F64, L_.DCA_F64)
+    ctx.plm_configure(LAMBDA_H, LAMBDA_J, L_.CARRY_CHUNKED)
+    ctx.plm_init_x()
+    ctx.plm_lbfgs_begin(iters)
+    st = ctx.plm_lbfgs_iterate(iters)
+    assert (st.status, st.iterations, st.evaluations) == (ref["status"], ref["iterations"], ref["evaluations"])
+    assert abs(st.fx - ref["fx"]) <= 1e-9 * abs(ref["fx"])
+    for apc in (False, True):
+        s_gpu = ctx.plm_scores(apc)
+        s_ref = oracle_mf.plm_fn(ref["x"], L, q, apc_correct=apc)
+        np.testing.assert_allclose(s_gpu, s_ref, rtol=1e-4, atol=1e-9)
+        assert list(_top(s_gpu, L)) == list(_top(s_ref, L))
+    # DI of the same parameters (the other score BASELINE.json's tolerance names)
+    reg_fi = oracle_mf.get_reg_single_site_freqs(oracle_mf.compute_single_site_freqs(X.astype(np.int32) + 1, q, w64), L, q, 0.5)
+    di_gpu = ctx.plm_di_scores(reg_fi, False)
+    di_ref = oracle_mf.plm_di(ref["x"], reg_fi, L, q, apc_correct=False)
+    np.testing.assert_allclose(di_gpu, di_ref, rtol=1e-4, atol=1e-12)
+    assert list(_top(di_gpu, L)) == list(_top(di_ref, L))
+    ctx.close()
+
+
+def test_config_C_shipped_float32_deviation_reported(L_, oracle_plm, oracle_mf, msa_C):
+    """The default product mode at config C (float32 storage, chunked scan -- what `plmdcaBackend` and bench.py run)
+    against the float64 oracle after the same 10 iterations: the deviation is measured, printed and bounded."""
+    X, q, L, iters = msa_C, Q_C, L_C, 10
+    w64 = oracle_plm.weights(X, 0.8, np.float64)
+    ref = oracle_plm.lbfgs(X, w64, q, LAMBDA_H, LAMBDA_J, iters, oracle_plm.init_x(X, w64, q), carry=True)
+    ctx = _ctx(L_, X, q, L_.DCA_F32, L_.DCA_F32)
+    ctx.plm_configure(LAMBDA_H, LAMBDA_J)
+    ctx.plm_init_x()
+    ctx.plm_lbfgs_begin(iters)
+    st = ctx.plm_lbfgs_iterate(iters)
+    s_gpu = ctx.plm_scores(True)
+    s_ref = oracle_mf.plm_fn(ref["x"], L, q)
+    top = _top(s_ref, L)
+    dev_top = float(np.max(np.abs(s_gpu[top] - s_ref[top]) / np.abs(s_ref[top])))
+    overlap = len(set(top) & set(_top(s_gpu, L)))
+    print("\nconfig C float32/chunked vs float64 oracle after %d iterations: status %d (oracle %d), evaluations %d (oracle %d), "
+          "max top-L FN_APC deviation %.3e, top-L overlap %d/%d" % (iters, st.status, ref["status"], st.evaluations,
+                                                                     ref["evaluations"], dev_top, overlap, L))
+    assert (st.status, st.iterations) == (ref["status"], ref["iterations"])
+    assert dev_top < 1e-3 and overlap >= L - 1
+    ctx.close()
+
+
+def test_config_B_mfdca_vs_oracle(L_, oracle_plm, oracle_mf, msa_C):
+    """Config B: mfdca compute_fn on the synthetic L=200 N=10k q=21 alignment (theta = 0.5, seqid = 0.8), n = 4000:
+    FN and FN_APC <= 1e-9 relative against the numpy float64 restatement (LAPACK inverse), identical FULL ranking;
+    the weights are the float64-compare ones (msa_numerics.py:13-50), bit-exact."""
+    X, q, L = msa_C, Q_C, L_C
+    w64 = oracle_plm.weights(X, 0.8, np.float64)
+    X1 = X.astype(np.int32) + 1
+    ctx = _ctx(L_, X, q, L_.DCA_F64, L_.DCA_F64)
+    assert np.array_equal(ctx.weights(), w64)
+    for apc in (False, True):
+        s_ref, J_ref = oracle_mf.mfdca_fn(X1, q, 0.5, 0.8, weights=w64, apc_correct=apc)
+        s_gpu = ctx.mf_run(0.5, apc)
+        np.testing.assert_allclose(s_gpu, s_ref, rtol=1e-9)
+        assert np.array_equal(np.argsort(-s_gpu, kind="stable"), np.argsort(-s_ref, kind="stable"))
+        assert np.array_equal(ctx.scores_order(), np.argsort(-s_ref, kind="stable"))
+    assert rel_err(ctx.mf_couplings(), J_ref) < 1e-9
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------ P4 report
+def _rankdata(a):
+    order = np.argsort(a, kind="stable")
+    r = np.empty(len(a))
+    r[order] = np.arange(len(a))
+    return r
+
+
+def _compare(a, b, L):
+    """top-L set overlap, Spearman rho over all pairs, max relative difference over b's top-L."""
+    ta, tb = _top(a, L), _top(b, L)
+    rho = float(np.corrcoef(_rankdata(a), _rankdata(b))[0, 1])
+    return dict(overlap=len(set(ta) & set(tb)), same_order=bool(list(ta) == list(tb)), spearman=rho,
+                max_rel_topL=float(np.max(np.abs(a[tb] - b[tb]) / np.abs(b[tb]))))
+
+
+P4_CASES = [("rf00167", "plm_rf00167", 102), ("rf71", "plm_rf71", 71)]
+
+
+@pytest.mark.parametrize("tag,gold,L", P4_CASES)
+def test_P4_shipped_path_beside_reference_spread(L_, tag, gold, L):
+    """the shipped path (float32 storage, chunked scan) run to the reference's cap, compared with
+    three as-run reference runs (8, 8, 1 threads; tests/golden/plm_runs.npz) -- top-L overlap, Spearman rho and
+    the largest relative FN_APC difference over the top-L -- printed beside the same figures between the
+    reference's own runs, and bounded by them.  Reference: lbfgs.cpp:815-1004, :1128-1295 (line search)."""
+    R, G = golden("plm_runs"), golden(gold)
+    q = 5
+    mit = int(R["spread_%s_max_iterations" % tag])
+    ctx = _ctx(L_, G["X"], q, L_.DCA_F32, L_.DCA_F32)
+    ctx.plm_configure(float(R["spread_%s_lambda_h" % tag]), float(R["spread_%s_lambda_J" % tag]))
+    ctx.plm_init_x()
+    ctx.plm_lbfgs_begin(mit)
+    st = ctx.plm_lbfgs_iterate(mit)
+    ours = {"fn": ctx.plm_scores(False), "apc": ctx.plm_scores(True)}
+    ctx.close()
+    report = {"case": tag, "max_iterations": mit, "gpu": {"status": st.status, "iterations": st.iterations, "evaluations": st.evaluations},
+              "reference_runs": [dict(status=int(s[0]), iterations=int(s[1]), evaluations=int(s[2]), threads=int(s[3]))
+                                 for s in R["spread_%s_stats" % tag]]}
+    for key in ("fn", "apc"):
+        refs = R["spread_%s_%s" % (tag, key)]
+        ref_ref = [_compare(refs[a], refs[b], L) for a in range(3) for b in range(3) if a != b]
+        gpu_ref = [_compare(ours[key], refs[b], L) for b in range(3)]
+        report[key] = {"reference_vs_reference": ref_ref, "gpu_vs_reference": gpu_ref}
+        worst = lambda rows, k, f: f(r[k] for r in rows)   # noqa: E731
+        print("\nP4 %s %s (L=%d): reference runs among themselves: overlap >= %d/%d, rho >= %.5f, max top-L diff <= %.3e | "
+              "shipped GPU path vs reference runs: overlap >= %d/%d, rho >= %.5f, max top-L diff <= %.3e" % (
+                  tag, key.upper(), L, worst(ref_ref, "overlap", min), L, worst(ref_ref, "spearman", min), worst(ref_ref, "max_rel_topL", max),
+                  worst(gpu_ref, "overlap", min), L, worst(gpu_ref, "spearman", min), worst(gpu_ref, "max_rel_topL", max)))
+        # bounded by the reference's own spread (x3: three runs under-sample it) and SURVEY's "expect ~1 %"
+        assert worst(gpu_ref, "overlap", min) >= worst(ref_ref, "overlap", min) - 2
+        assert worst(gpu_ref, "spearman", min) >= worst(ref_ref, "spearman", min) - 5e-3
+        assert worst(gpu_ref, "max_rel_topL", max) <= max(3.0 * worst(ref_ref, "max_rel_topL", max), 2e-2)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "p4_report_%s.json" % tag), "w") as fh:
+        json.dump(report, fh, indent=1)

@@ -30,7 +30,7 @@ def make_ctx(L_, X, q, precision, seqid=0.8, cmp=None):
     return ctx
 
 
-PLM_TAGS = ["toy_rna", "toy_protein", "rf71", "rf00167"]
+PLM_TAGS = ["toy_rna", "toy_protein", "rf71", "rf00167", "pf02826"]
 
 
 @pytest.mark.parametrize("tag", PLM_TAGS)
@@ -102,6 +102,7 @@ def test_gradient_float32_vs_reference_and_oracle(L_, oracle_plm, tag, mode):
             assert rel_err(g, G[gk]) < 1e-5
         else:
             assert rel_err(g[G["idx"]], G[gk + "_sub"]) < 1e-5
+            assert abs(np.linalg.norm(g.astype(np.float64)) - float(G[gk + "_norm"])) < 1e-5 * float(G[gk + "_norm"])
         assert abs(fx - float(G[fk])) <= 5e-5 * abs(float(G[fk]))
     ctx.close()
 
@@ -181,10 +182,12 @@ def _topL_same(a, b, L):
     return list(np.argsort(-a, kind="stable")[:L]) == list(np.argsort(-b, kind="stable")[:L])
 
 
+@pytest.mark.parametrize("mode", ["serial", "chunked"])
 @pytest.mark.parametrize("tag,iters", [("toy_rna", 60), ("toy_protein", 30), ("rf71", 40)])
-def test_lbfgs_float64_matches_oracle_at_equal_iteration_cap(L_, oracle_plm, oracle_mf, tag, iters):
+def test_lbfgs_float64_matches_oracle_at_equal_iteration_cap(L_, oracle_plm, oracle_mf, tag, iters, mode):
     """P3 of SURVEY 8c4 / north_star: same restated optimiser, same semantics, same cap =>
-    FN and FN_APC within 1e-4 relative and identical top-L order (float64)."""
+    FN and FN_APC within 1e-4 relative and identical top-L order (float64), with the strictly serial
+    carry chain and with the chunk-parallel scan the product ships."""
     G = golden("plm_" + tag)
     L, q = int(G["L"]), int(G["q"])
     lh, lJ = float(G["lambda_h"]), float(G["lambda_J"])
@@ -192,7 +195,7 @@ def test_lbfgs_float64_matches_oracle_at_equal_iteration_cap(L_, oracle_plm, ora
     x0 = oracle_plm.init_x(G["X"], w64, q)
     ref = oracle_plm.lbfgs(G["X"], w64, q, lh, lJ, iters, x0, carry=True)
     ctx = make_ctx(L_, G["X"], q, L_.DCA_F64, 0.8, L_.DCA_F64)
-    ctx.plm_configure(lh, lJ, L_.CARRY_SERIAL)
+    ctx.plm_configure(lh, lJ, L_.CARRY_SERIAL if mode == "serial" else L_.CARRY_CHUNKED)
     ctx.plm_init_x()
     ctx.plm_lbfgs_begin(iters)
     st = ctx.plm_lbfgs_iterate(iters)
@@ -286,7 +289,7 @@ def test_mf_stages_vs_reference(L_, tag):
     ctx.close()
 
 
-@pytest.mark.parametrize("tag", ["toy_rna", "toy_protein", "toy_rna_theta02_seqid1", "rf71", "rf00167"])
+@pytest.mark.parametrize("tag", ["toy_rna", "toy_protein", "toy_rna_theta02_seqid1", "rf71", "rf00167", "pf02826"])
 def test_mf_scores_and_full_ranking_vs_reference(L_, oracle_mf, tag):
     """mfdca compute_fn: FN and FN_APC <= 1e-9 relative, identical full ranking
     (SURVEY 8c5); rf71 also covers the notebook's published top-5."""

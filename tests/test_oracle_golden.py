@@ -12,6 +12,7 @@ PLM_CASES = [
     ("toy_protein", "toy_protein.fa", 1, True),
     ("rf71", "MSA_RF00167_trimmed71.fa", 2, True),
     ("rf00167", "MSA_RF00167.fa", 2, False),
+    ("pf02826", "PF02826.faa", 1, False),       # the reference's own protein test input (q = 21, L = 195, N' = 2012)
 ]
 
 
@@ -64,20 +65,24 @@ def test_carry_over_is_what_the_reference_does(oracle_plm):
     assert rel_err(g_exact, G["g1"]) > 1e-2
 
 
-@pytest.mark.parametrize("tag,bio", [("toy_rna", 2), ("toy_protein", 1)])
-def test_plm_lbfgs_float32_tracks_reference_run(oracle_plm, oracle_mf, tag, bio):
-    """End-to-end plmdcaBackend run of the reference (1 thread => deterministic) vs the
-    restated optimiser in float32.  Trajectories are chaotic in the last digits, so the
-    bar is on scores, not bits."""
+@pytest.mark.parametrize("tag,threads", [("toy_rna", 1), ("toy_rna", 3), ("toy_protein", 1), ("toy_protein", 2), ("rf71", 4)])
+def test_plm_lbfgs_float32_equals_reference_run_exactly(oracle_plm, tag, threads):
+    """The restated optimiser (lbfgs.cpp:248-644, Moré-Thuente :815-1004, update_trial_interval :1128-1295) in
+    float32 reproduces the reference's own 1-thread run BIT FOR BIT: exit status, iterations, evaluations, the
+    per-iteration (fx, xnorm, gnorm, step) the backend's verbose mode prints (plmdcaBackend.cpp:137-146) and the
+    final parameter vector.  The oracle's gradient sums in a fixed order, so its thread count does not matter."""
+    R = golden("plm_runs")
     G = golden("plm_" + tag)
     L, q = int(G["L"]), int(G["q"])
-    res = oracle_plm.lbfgs(G["X"], G["w"], q, float(G["lambda_h"]), float(G["lambda_J"]),
-                           int(G["run_a_max_iterations"]), oracle_plm.init_x(G["X"], G["w"], q), threads=2)
-    fn_ref = oracle_mf.plm_fn(G["run_a"], L, q)
-    fn_our = oracle_mf.plm_fn(res["x"], L, q)
-    assert rel_err(fn_our, fn_ref) < 2e-2
-    top = np.argsort(-fn_ref, kind="stable")[:3]
-    assert set(top) == set(np.argsort(-fn_our, kind="stable")[:3])
+    mit = int(R[tag + "_max_iterations"])
+    res = oracle_plm.lbfgs(G["X"], G["w"], q, float(R[tag + "_lambda_h"]), float(R[tag + "_lambda_J"]), mit,
+                           oracle_plm.init_x(G["X"], G["w"], q), threads=threads, trace_cap=mit)
+    assert (res["status"], res["iterations"], res["evaluations"]) == \
+        (int(R[tag + "_status"]), int(R[tag + "_iterations"]), int(R[tag + "_evaluations"]))
+    assert np.array_equal(res["trace"], R[tag + "_trace"][:, :4])
+    assert np.array_equal(res["x"], R[tag + "_x"])
+    assert np.array_equal(R[tag + "_x"], G["run_a"])          # == what `plmdcaBackend` itself returned
+    assert np.float32(res["fx"]) == R[tag + "_fx"]
 
 
 def test_plm_notebook_kat_rf71(oracle_plm, oracle_mf):
@@ -123,7 +128,7 @@ def test_mf_stages_match_reference(oracle_mf, tag):
     np.testing.assert_allclose(J, G["couplings"], rtol=1e-8, atol=1e-10)
 
 
-@pytest.mark.parametrize("tag", MF_STAGE_CASES + ["rf71", "rf00167"])
+@pytest.mark.parametrize("tag", MF_STAGE_CASES + ["rf71", "rf00167", "pf02826"])
 def test_mf_scores_and_ranking_match_reference(oracle_mf, tag):
     G = golden("mf_" + tag)
     X, q = G["X"], int(G["q"])
