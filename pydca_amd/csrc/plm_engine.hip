@@ -220,7 +220,9 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
 // starts `warm` sequences early from a zero carry: the carry enters the logits with
 // weight <= 1 and d softmax has 1-norm <= 1/2, so the start-up error shrinks by >= 2x
 // per step (2^-40 after the default 40) -- far below float/double rounding.
-// In: SR = S (logit sums).  Out: SR = R = w_n (p - delta), fxPart[wave] = -sum w_n log p(x_ni).
+// In: S (logit sums).  Out: R = w_n (p - delta) in a SEPARATE array, fxPart[wave] = -sum w_n log p(x_ni).
+// (Not in place: a chunk's warm-up rows belong to its predecessors, which would be overwriting them with R at
+// the same time -- chunk 0 has no warm-up and writes row t at its step t while chunk 1 reads it at its step t.)
 //
 // Memory access: the 64 sites of a wave are one contiguous 64*q*sizeof(T)-byte span of a row.
 // It is fetched with 16-byte loads (prefetched DEPTH rows ahead into registers), transposed
@@ -230,7 +232,7 @@ typedef uint4 __attribute__((may_alias)) dca_u4a;
 
 template <typename T, int Q>
 __global__ __launch_bounds__(256)
-void plm_softmax_kernel(T* __restrict__ SR, const T* __restrict__ x, const uint8_t* __restrict__ X,
+void plm_softmax_kernel(const T* __restrict__ SR, T* __restrict__ Rout, const T* __restrict__ x, const uint8_t* __restrict__ X,
                         const T* __restrict__ w, double* __restrict__ fxPart,
                         int N, int L, int Ls, int Cs, int halo, int chunk, int warm, int carry, int numChunks)
 {
@@ -310,7 +312,7 @@ void plm_softmax_kernel(T* __restrict__ SR, const T* __restrict__ x, const uint8
                             reinterpret_cast<T*>(sOut)[lane * Q + a] = r;
                         }
                         __builtin_amdgcn_wave_barrier();
-                        unsigned char* row = reinterpret_cast<unsigned char*>(SR + (size_t)n * Cs + (size_t)i0 * Q);
+                        unsigned char* row = reinterpret_cast<unsigned char*>(Rout + (size_t)n * Cs + (size_t)i0 * Q);
 #pragma unroll
                         for (int pc = 0; pc < NP; ++pc) {
                             const int off = pc * 1024 + lane * 16;
@@ -938,7 +940,7 @@ struct PlmEngine : PlmEngineBase {
     T *dx = nullptr, *dg = nullptr, *dxp = nullptr, *dgp = nullptr, *dd = nullptr;
     T* dS[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     T* dY[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    T *dWt = nullptr, *dSR = nullptr, *dG = nullptr, *dw = nullptr;
+    T *dWt = nullptr, *dSR = nullptr, *dR = nullptr, *dG = nullptr, *dw = nullptr;
     uint16_t* dXL = nullptr;
     uint16_t* dXT2 = nullptr;
     int NT = 0;
@@ -974,7 +976,7 @@ struct PlmEngine : PlmEngineBase {
     {
         dca_dev_free(dx); dca_dev_free(dg); dca_dev_free(dxp); dca_dev_free(dgp); dca_dev_free(dd);
         for (int i = 0; i < 5; ++i) { dca_dev_free(dS[i]); dca_dev_free(dY[i]); }
-        dca_dev_free(dWt); dca_dev_free(dSR); dca_dev_free(dG); dca_dev_free(dw); dca_dev_free(dXL); dca_dev_free(dXT2);
+        dca_dev_free(dWt); dca_dev_free(dSR); dca_dev_free(dR); dca_dev_free(dG); dca_dev_free(dw); dca_dev_free(dXL); dca_dev_free(dXT2);
         dca_dev_free(dPairs); dca_dev_free(dFxPart); dca_dev_free(dRegPart); dca_dev_free(dVecPart);
     }
     ~PlmEngine() override { freeall(); }
@@ -1005,7 +1007,7 @@ struct PlmEngine : PlmEngineBase {
         freeall();
         dx = dg = dxp = dgp = dd = nullptr;
         for (int i = 0; i < 5; ++i) dS[i] = dY[i] = nullptr;
-        dWt = dSR = dG = dw = nullptr; dXL = nullptr; dXT2 = nullptr; dPairs = nullptr;
+        dWt = dSR = dR = dG = dw = nullptr; dXL = nullptr; dXT2 = nullptr; dPairs = nullptr;
         dFxPart = dRegPart = dVecPart = nullptr;
         lbfgs_alloc = false;
         o = decltype(o)();
@@ -1022,8 +1024,9 @@ struct PlmEngine : PlmEngineBase {
 
         DCA_TRY(dalloc(&dx, P + kVecPad)); DCA_TRY(dalloc(&dg, P + kVecPad));
         DCA_TRY(dalloc(&dWt, (size_t)Wrows * Cs));
-        DCA_TRY(dalloc(&dSR, (size_t)(N + kNC) * Cs));          // + kNC zero rows: the scatter kernel's last tile reads past row N-1
-        HIP_TRY(hipMemsetAsync(dSR + (size_t)N * Cs, 0, (size_t)kNC * Cs * sizeof(T), ctx->stream));
+        DCA_TRY(dalloc(&dSR, (size_t)N * Cs));                  // S: logit sums
+        DCA_TRY(dalloc(&dR, (size_t)(N + kNC) * Cs));           // R = w (p - delta); + kNC zero rows: the scatter kernel's last tile reads past row N-1
+        HIP_TRY(hipMemsetAsync(dR, 0, (size_t)(N + kNC) * Cs * sizeof(T), ctx->stream));    // pad columns and halo rows stay zero
         {
             // Split of the tile range over blockIdx.y.  Aim at ~2048 workgroups (8 rounds of one workgroup
             // per CU) but keep >= 12 tiles per workgroup (prologue + epilogue cost about two tiles), then
@@ -1193,7 +1196,7 @@ struct PlmEngine : PlmEngineBase {
             constexpr int softNP = (64 * Q * (int)sizeof(T) + 1023) / 1024;
             const size_t softLds = (size_t)4 * 2 * softNP * 1024;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plm_softmax_kernel<T, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)softLds));
-            hipLaunchKernelGGL((plm_softmax_kernel<T, Q>), grid, dim3(256), softLds, st, dSR, dx, ctx->dX, dw, dFxPart,
+            hipLaunchKernelGGL((plm_softmax_kernel<T, Q>), grid, dim3(256), softLds, st, dSR, dR, dx, ctx->dX, dw, dFxPart,
                                N, L, Ls, Cs, halo, chunk, warm, carry_mode != DCA_CARRY_EXACT ? 1 : 0, numScanChunks);
         }
         {
@@ -1206,7 +1209,7 @@ struct PlmEngine : PlmEngineBase {
             auto launch = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ScopedKernelClock kc(ctx, "plm_scatter");
-                hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(kScatWavesC * 64), lds, st, dSR, dXT2, dG, N, L, Cs, halo,
+                hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG, N, L, Cs, halo,
                                    numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs, ablate);
                 return DCA_OK;
             };

@@ -136,7 +136,7 @@ def test_config_B_mfdca_vs_oracle(L_, oracle_plm, oracle_mf, msa_C):
     for apc in (False, True):
         s_ref, J_ref = oracle_mf.mfdca_fn(X1, q, 0.5, 0.8, weights=w64, apc_correct=apc)
         s_gpu = ctx.mf_run(0.5, apc)
-        np.testing.assert_allclose(s_gpu, s_ref, rtol=1e-9)
+        np.testing.assert_allclose(s_gpu, s_ref, rtol=1e-9, atol=1e-12)      # atol: an APC score is a difference of O(1) numbers
         assert np.array_equal(np.argsort(-s_gpu, kind="stable"), np.argsort(-s_ref, kind="stable"))
         assert np.array_equal(ctx.scores_order(), np.argsort(-s_ref, kind="stable"))
     assert rel_err(ctx.mf_couplings(), J_ref) < 1e-9
