@@ -188,11 +188,27 @@ def main():
     full = _lib.Context(local_rank, _lib.DCA_F32)
     full.set_msa(X, q)
     full.set_profiling(True)
-    full.compute_weights(0.8, _lib.DCA_F32)
+    # exchange scheme of a multi-GPU run: the library's own RCCL communicator on its stream (default), or the
+    # torch.distributed hooks (DCA_BENCH_TORCH_COMM=1; always in the gloo self-test, where RCCL cannot run)
+    native = world > 1 and not selftest and os.environ.get("DCA_BENCH_TORCH_COMM") != "1"
+    uid = None
+    if world == 1:
+        full.compute_weights(0.8, _lib.DCA_F32)
+    elif native:
+        # every rank counts 1/world of the identity comparisons, ONE all-reduce of the N integer counts
+        uid = parallel.init_native_comm(full, _lib, rank, world, dist)
+        full.compute_weights_sharded(0.8, _lib.DCA_F32)
+    else:
+        part = torch.from_numpy(full.weights_partial_counts(0.8, _lib.DCA_F32, rank, world).astype(np.int64))
+        if not selftest:
+            part = part.cuda()
+        dist.all_reduce(part, op=dist.ReduceOp.SUM)
+        full.set_weight_counts(part.cpu().numpy().astype(np.uint32))
     counts = full.weight_counts()
     w32 = (np.float32(1.0) / counts.astype(np.float32)).astype(np.float32)
     t_weights_ms, _ = full.kernel_time("weights")
     hook = None
+    scheme = "1 GPU"
     if world == 1:
         ctx = full
         ctx.plm_configure(lh, lJ, _lib.CARRY_CHUNKED)
@@ -205,14 +221,21 @@ def main():
         # sequences AND optimiser vectors sharded: reduce-scatter(g) + all-gather(x) per evaluation
         # (DCA_BENCH_ALLREDUCE=1 selects the plain all-reduce of g with replicated vectors instead)
         # Small parameter vectors (config E: 1.1 MB) are latency-bound: one all-reduce per evaluation beats
-        # four hook calls per iteration, so vector sharding is used from 16 MB of parameters on.
+        # four collectives per iteration, so vector sharding is used from 16 MB of parameters on.
         small = ctx.num_params() * (4 if args.precision == 32 else 8) < (16 << 20)
-        if os.environ.get("DCA_BENCH_ALLREDUCE") == "1" or (small and os.environ.get("DCA_BENCH_VECTORS") != "1"):
+        allreduce = os.environ.get("DCA_BENCH_ALLREDUCE") == "1" or (small and os.environ.get("DCA_BENCH_VECTORS") != "1")
+        if native:
+            parallel.init_native_comm(ctx, _lib, rank, world, dist)
+            ctx.plm_set_native_comm(1 if allreduce else 2)
+        elif allreduce:
             hook = parallel.TorchAllReduceHook(local_rank)
             ctx.plm_set_reduce_hook(hook)
         else:
             hook = parallel.TorchVectorComm(local_rank, rank, world)
             ctx.plm_set_vector_sharding(rank, world, hook)
+        scheme = ("sequences sharded x%d, all-reduce(g) over RCCL" % world if allreduce else
+                  "sequences sharded x%d, reduce-scatter(g) + all-gather(x) over RCCL, L-BFGS vectors sharded x%d" % (world, world))
+        scheme += ", native collectives on the library's stream" if native else ", torch.distributed hooks"
     t_setup = time.perf_counter() - t0
 
     # ---- warm-up iterations, then exactly K timed iterations
@@ -292,8 +315,7 @@ def main():
         "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
         "config": {"workload": "plmdca compute_fn protein, synthetic MSA L=%d N=%d q=%d, lambda_h=%g lambda_J=%g seqid=0.8, "
                                "reference carry-over semantics (chunked scan)" % (L, N, q, lh, lJ),
-                   "config_id": args.workload, "num_params": P, "parallelism": ("1 GPU" if world == 1 else ("sequences sharded x%d, all-reduce(g) over RCCL" % world) if isinstance(hook, parallel.TorchAllReduceHook)
-                                   else "sequences sharded x%d, reduce-scatter(g) + all-gather(x) over RCCL, L-BFGS vectors sharded x%d" % (world, world))},
+                   "config_id": args.workload, "num_params": P, "parallelism": scheme},
         "evaluations_per_iteration": evals / max(steps_done, 1), "evaluations_per_s": evals / dt,
         "lbfgs_status": st.status, "fx": st.fx,
         "setup_s": {"generate_msa": t_gen, "weights_kernel": t_weights_ms / 1e3, "total_setup": t_setup},

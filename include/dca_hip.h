@@ -120,6 +120,39 @@ int dca_plm_get_x(dca_ctx* ctx, void* x_out, int dtype);
 int dca_plm_gradient(dca_ctx* ctx, double* fx_out);
 int dca_plm_get_g(dca_ctx* ctx, void* g_out, int dtype);
 
+/* ------------------------------------------------------------------ native collectives (RCCL over xGMI)
+ * One process per GPU; every context owns one RCCL communicator whose collectives are enqueued on the context's own
+ * stream, in place on the library's buffers: with it an objective evaluation has no host callback and no device
+ * synchronisation around its exchange step.  librccl.so is opened with dlopen (rccl_path, else $DCA_RCCL_PATH, else the
+ * default search path; pass the copy the process already uses, e.g. torch/lib/librccl.so under PyTorch).
+ *   rank 0:      dca_comm_unique_id(path, id)           128 bytes; hand them to every rank (store, MPI, file ...)
+ *   every rank:  dca_comm_init(ctx, path, id, world, rank)   collective: returns when all ranks have called it
+ * No reference counterpart (pydca is single-process); the partition is the one BASELINE.json's north_star names. */
+int dca_comm_unique_id(const char* rccl_path, void* id128);
+int dca_comm_init(dca_ctx* ctx, const char* rccl_path, const void* id128, int world, int rank);
+int dca_comm_destroy(dca_ctx* ctx);
+
+/* Exchange step of the sharded plmDCA evaluation through the context's communicator (after dca_plm_configure):
+ *   mode 1: all-reduce(sum) of the gradient and of fx after every evaluation, optimiser vectors replicated;
+ *   mode 2: sharded optimiser vectors -- reduce-scatter(g) per evaluation, all-gather(x) per step, scalar all-reduces
+ *           (the scheme of dca_plm_set_vector_sharding; rank / world are the communicator's);
+ *   mode 0: off.  Replaces any hook set with dca_plm_set_reduce_hook / dca_plm_set_vector_sharding. */
+int dca_plm_set_native_comm(dca_ctx* ctx, int mode);
+
+/* mfDCA pair counts summed over the shards through the communicator (instead of dca_mf_set_reduce_hook). */
+int dca_mf_set_native_comm(dca_ctx* ctx, int on);
+
+/* Sequence weights with the N^2 L / 2 comparisons divided over the ranks (every rank holds the whole alignment --
+ * tens of MB -- and counts every world-th tile pair of the upper triangle of the identity matrix; the symmetric
+ * half-loop of plmdca_numerics.cpp:646-666, split evenly), then ONE all-reduce(sum) of the N integer counts
+ * through the communicator: exact, the same counts on every rank as dca_compute_weights gives. */
+int dca_compute_weights_sharded(dca_ctx* ctx, double seqid, int compare_precision);
+
+/* The same split without a communicator: part `part` of `parts` of the comparisons -> partial counts (host array of N,
+ * optional); the caller sums the parts by any means and hands the totals back with dca_set_weight_counts. */
+int dca_weights_partial_counts(dca_ctx* ctx, double seqid, int compare_precision, int part, int parts, uint32_t* counts_out);
+int dca_set_weight_counts(dca_ctx* ctx, const uint32_t* counts);
+
 /* Optional reduction hook for sequence sharding: called after the local data term is
  * on the device, before the optimiser sees it.  g_dev/fx_dev are DEVICE pointers
  * (count elements of dtype / one double); the hook must sum them over all shards in

@@ -67,6 +67,14 @@ def lib():
         "dca_destroy": (None, [vp]),
         "dca_set_msa": (i, [vp, vp, i, i, i]),
         "dca_compute_weights": (i, [vp, d, i]),
+        "dca_compute_weights_sharded": (i, [vp, d, i]),
+        "dca_weights_partial_counts": (i, [vp, d, i, i, i, vp]),
+        "dca_set_weight_counts": (i, [vp, vp]),
+        "dca_comm_unique_id": (i, [C.c_char_p, vp]),
+        "dca_comm_init": (i, [vp, C.c_char_p, vp, i, i]),
+        "dca_comm_destroy": (i, [vp]),
+        "dca_plm_set_native_comm": (i, [vp, i]),
+        "dca_mf_set_native_comm": (i, [vp, i]),
         "dca_set_weights": (i, [vp, vp]),
         "dca_get_weights": (i, [vp, vp]),
         "dca_get_weight_counts": (i, [vp, vp]),
@@ -118,7 +126,9 @@ def lib():
     return L
 
 
-EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_create",
+EXPORTS = ["dca_compute_weights_sharded", "dca_weights_partial_counts", "dca_set_weight_counts", "dca_comm_unique_id",
+           "dca_comm_init", "dca_comm_destroy", "dca_plm_set_native_comm", "dca_mf_set_native_comm",
+           "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_num_params", "dca_plm_init_x",
            "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_di_from_arrays", "dca_di_from_fields", "dca_plm_set_vector_sharding",
@@ -128,6 +138,13 @@ EXPORTS = ["dca_last_error", "dca_version", "dca_device_count", "dca_release_cac
            "dca_mf_pair_site_freqs", "dca_mf_corr_mat", "dca_mf_couplings", "dca_mf_scores", "dca_mf_run",
            "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_sw_scores", "dca_sw_align", "dca_scores_order", "dca_set_profiling", "dca_get_kernel_time",
            "dca_reset_kernel_times", "plmdcaBackend", "freeFieldsAndCouplings"]
+
+
+def comm_unique_id(rccl_path=None):
+    """128-byte RCCL unique id (rank 0 makes it, every rank passes it to Context.comm_init)."""
+    buf = C.create_string_buffer(128)
+    check(lib().dca_comm_unique_id(os.fsencode(rccl_path) if rccl_path else None, buf))
+    return buf.raw
 
 
 def release_cached_memory():
@@ -194,6 +211,39 @@ class Context:
         w = np.ascontiguousarray(w, dtype=np.float64)
         assert w.shape == (self.N,)
         check(self._l.dca_set_weights(self._h, _ptr(w)))
+
+    def compute_weights_sharded(self, seqid, compare_precision=None):
+        """Weights with the comparisons divided over the ranks of the context's communicator (comm_init first)."""
+        cp = self.precision if compare_precision is None else compare_precision
+        check(self._l.dca_compute_weights_sharded(self._h, float(seqid), int(cp)))
+        return self.weights()
+
+    def weights_partial_counts(self, seqid, compare_precision, part, parts):
+        """Part `part` of `parts` of the identity comparisons -> partial integer counts (sum the parts, then set_weight_counts)."""
+        c = np.zeros(self.N, dtype=np.uint32)
+        check(self._l.dca_weights_partial_counts(self._h, float(seqid), int(compare_precision), int(part), int(parts), _ptr(c)))
+        return c
+
+    def set_weight_counts(self, counts):
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        if counts.shape != (self.N,):
+            raise ValueError("counts must have one entry per sequence")
+        check(self._l.dca_set_weight_counts(self._h, _ptr(counts)))
+
+    # ---- native collectives (RCCL on the context's stream)
+    def comm_init(self, unique_id, world, rank, rccl_path=None):
+        self._comm_id = bytes(unique_id)
+        check(self._l.dca_comm_init(self._h, os.fsencode(rccl_path) if rccl_path else None, self._comm_id, int(world), int(rank)))
+
+    def comm_destroy(self):
+        check(self._l.dca_comm_destroy(self._h))
+
+    def plm_set_native_comm(self, mode):
+        """0 off, 1 all-reduce of g and fx per evaluation, 2 sharded optimiser vectors."""
+        check(self._l.dca_plm_set_native_comm(self._h, int(mode)))
+
+    def mf_set_native_comm(self, on=True):
+        check(self._l.dca_mf_set_native_comm(self._h, int(bool(on))))
 
     def weights(self):
         w = np.zeros(self.N, dtype=np.float64)

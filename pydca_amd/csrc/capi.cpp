@@ -213,9 +213,14 @@ int dca_create(dca_ctx** out, int device, int precision)
     dca_ctx* ctx = new dca_ctx();
     ctx->device = device;
     ctx->precision = precision;
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&ctx->dScal), 64 * sizeof(double)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->hScal), 64 * sizeof(double), hipHostMallocDefault));
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&ctx->dScal), 64 * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->hScal), 64 * sizeof(double), hipHostMallocDefault);
+    if (e != hipSuccess) {                       // nothing half-built is handed out or left behind
+        dca_set_error("dca_create: %s", hipGetErrorString(e));
+        dca_destroy(ctx);
+        return DCA_ERR_HIP;
+    }
     *out = ctx;
     return DCA_OK;
 }
@@ -273,12 +278,13 @@ void dca_destroy(dca_ctx* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    dca_comm_destroy_impl(ctx);
     dca_flush_clocks(ctx);
     free_msa(ctx);
     dca_dev_free(ctx->dScal);
-    hipHostFree(ctx->hScal);
-    hipStreamDestroy(ctx->stream);
+    if (ctx->hScal) hipHostFree(ctx->hScal);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -298,26 +304,37 @@ int dca_set_msa(dca_ctx* ctx, const uint8_t* X, int N, int L, int q)
         }
     }
     free_msa(ctx);
-    ctx->N = N; ctx->L = L; ctx->q = q;
-    ctx->Ls = (int)round_up((size_t)L, 128);
+    ctx->N = ctx->L = ctx->q = ctx->Ls = 0;                // the context holds no alignment until everything below succeeded
+    const int Ls = (int)round_up((size_t)L, 128);
     ctx->hX.clear();                                       // host copy is made on demand (dca_host_msa)
     // one contiguous copy + a repack kernel (a pitched hipMemcpy2D of narrow rows takes seconds)
-    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&ctx->dX), (size_t)N * ctx->Ls));
-    {
-        uint8_t* dTmp = nullptr;
-        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dTmp), (size_t)N * L));
-        hipError_t e = hipMemcpy(dTmp, X, (size_t)N * L, hipMemcpyHostToDevice);
-        if (e == hipSuccess) {
-            const size_t total = (size_t)N * ctx->Ls;
-            hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dTmp, ctx->dX, N, L, ctx->Ls);
-            e = hipStreamSynchronize(ctx->stream);
-        }
-        dca_dev_free(dTmp);
-        if (e != hipSuccess) { dca_set_error("uploading the alignment: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
+    uint8_t* dTmp = nullptr;
+    hipError_t e = dca_dev_malloc(reinterpret_cast<void**>(&ctx->dX), (size_t)N * Ls);
+    if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&dTmp), (size_t)N * L);
+    if (e == hipSuccess) e = hipMemcpy(dTmp, X, (size_t)N * L, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const size_t total = (size_t)N * Ls;
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dTmp, ctx->dX, N, L, Ls);
+        e = hipStreamSynchronize(ctx->stream);
     }
-    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&ctx->dCounts), (size_t)N * sizeof(uint32_t)));
-    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&ctx->dWd), (size_t)N * sizeof(double)));
+    dca_dev_free(dTmp);
+    if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&ctx->dCounts), (size_t)N * sizeof(uint32_t));
+    if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&ctx->dWd), (size_t)N * sizeof(double));
+    if (e != hipSuccess) {
+        free_msa(ctx);
+        dca_set_error("uploading the alignment: %s", hipGetErrorString(e));
+        return DCA_ERR_HIP;
+    }
+    ctx->N = N; ctx->L = L; ctx->q = q; ctx->Ls = Ls;
     return DCA_OK;
+}
+
+// Everything the engines derived from the weights (the plmDCA engine's copy, frequencies, counts, correlation matrix,
+// couplings) is dropped when the weights change: the next call recomputes it instead of answering for the old weights.
+static void weights_changed(dca_ctx* ctx)
+{
+    delete ctx->plm; ctx->plm = nullptr;
+    if (ctx->mf) { dca_free_mf_engine(ctx->mf); ctx->mf = nullptr; }
 }
 
 int dca_compute_weights(dca_ctx* ctx, double seqid, int compare_precision)
@@ -325,13 +342,49 @@ int dca_compute_weights(dca_ctx* ctx, double seqid, int compare_precision)
     CHECK_CTX(ctx);
     if (!ctx->dX) { dca_set_error("dca_set_msa first"); return DCA_ERR_STATE; }
     if (compare_precision != DCA_F32 && compare_precision != DCA_F64) return DCA_ERR_ARG;
+    weights_changed(ctx);
     return dca_weights_compute(ctx, seqid, compare_precision);
+}
+
+int dca_weights_partial_counts(dca_ctx* ctx, double seqid, int compare_precision, int part, int parts, uint32_t* counts_out)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->dX) { dca_set_error("dca_set_msa first"); return DCA_ERR_STATE; }
+    if (compare_precision != DCA_F32 && compare_precision != DCA_F64) return DCA_ERR_ARG;
+    weights_changed(ctx);
+    DCA_TRY(dca_weights_compute(ctx, seqid, compare_precision, part, parts, false));
+    if (counts_out) HIP_TRY(hipMemcpy(counts_out, ctx->dCounts, (size_t)ctx->N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return DCA_OK;
+}
+
+int dca_set_weight_counts(dca_ctx* ctx, const uint32_t* counts)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->dX || !counts) { dca_set_error("dca_set_msa first"); return DCA_ERR_STATE; }
+    for (int n = 0; n < ctx->N; ++n)
+        if (counts[n] == 0) { dca_set_error("dca_set_weight_counts: count of sequence %d is zero (every sequence counts itself)", n); return DCA_ERR_ARG; }
+    weights_changed(ctx);
+    HIP_TRY(hipMemcpy(ctx->dCounts, counts, (size_t)ctx->N * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return dca_weights_finish(ctx);
+}
+
+int dca_compute_weights_sharded(dca_ctx* ctx, double seqid, int compare_precision)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->dX) { dca_set_error("dca_set_msa first"); return DCA_ERR_STATE; }
+    if (compare_precision != DCA_F32 && compare_precision != DCA_F64) return DCA_ERR_ARG;
+    if (!ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
+    weights_changed(ctx);
+    DCA_TRY(dca_weights_compute(ctx, seqid, compare_precision, ctx->comm_rank, ctx->comm_world, false));
+    DCA_TRY(dca_comm_native_sum_u32(ctx, ctx->dCounts, (size_t)ctx->N));       // integer sums: exact, order-free
+    return dca_weights_finish(ctx);
 }
 
 int dca_set_weights(dca_ctx* ctx, const double* w)
 {
     CHECK_CTX(ctx);
     if (!ctx->dX || !w) { dca_set_error("dca_set_msa first"); return DCA_ERR_STATE; }
+    weights_changed(ctx);
     HIP_TRY(hipMemcpy(ctx->dWd, w, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice));
     double s = 0;
     for (int n = 0; n < ctx->N; ++n) s += w[n];
@@ -396,6 +449,7 @@ int dca_plm_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user)
     DCA_TRY(need_plm(ctx));
     ctx->plm->hook = hook;
     ctx->plm->hook_user = user;
+    if (hook && ctx->plm->native_mode == 1) ctx->plm->native_mode = 0;      // the hook replaces the native all-reduce
     return DCA_OK;
 }
 int dca_plm_lbfgs_begin(dca_ctx* ctx, int max_iterations, int verbose) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->lbfgs_begin(max_iterations, verbose); }
@@ -442,6 +496,40 @@ int dca_di_from_fields(dca_ctx* ctx, const double* couplings, int layout, const 
     CHECK_CTX(ctx);
     if (!couplings || !reg_fi || !fields_ij || !di_out || (layout != 1 && layout != 2)) return DCA_ERR_ARG;
     return dca_di_from_arrays_impl(ctx, couplings, layout, reg_fi, L, q, nullptr, di_out, fields_ij);
+}
+int dca_comm_unique_id(const char* rccl_path, void* id128)
+{
+    if (!id128) return DCA_ERR_ARG;
+    return dca_comm_unique_id_impl(rccl_path, id128);
+}
+int dca_comm_init(dca_ctx* ctx, const char* rccl_path, const void* id128, int world, int rank)
+{
+    CHECK_CTX(ctx);
+    if (!id128) return DCA_ERR_ARG;
+    return dca_comm_init_impl(ctx, rccl_path, id128, world, rank);
+}
+int dca_comm_destroy(dca_ctx* ctx)
+{
+    CHECK_CTX(ctx);
+    if (ctx->plm) ctx->plm->set_native_comm(0);
+    if (ctx->mf) dca_mf_engine_set_native(ctx->mf, false);
+    dca_comm_destroy_impl(ctx);
+    return DCA_OK;
+}
+int dca_plm_set_native_comm(dca_ctx* ctx, int mode)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->plm) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
+    ctx->plm->hook = nullptr; ctx->plm->hook_user = nullptr;
+    return ctx->plm->set_native_comm(mode);
+}
+int dca_mf_set_native_comm(dca_ctx* ctx, int on)
+{
+    CHECK_CTX(ctx);
+    DCA_TRY(need_mf(ctx));
+    if (on && !ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
+    dca_mf_engine_set_native(ctx->mf, on != 0);
+    return DCA_OK;
 }
 int dca_mf_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user)
 {

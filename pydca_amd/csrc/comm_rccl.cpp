@@ -1,0 +1,139 @@
+// Native collectives for the sharded paths: RCCL (librccl.so, the library behind torch.distributed's "nccl" backend on
+// ROCm) is opened with dlopen and its collectives are enqueued on the context's own stream, in place on the library's
+// device buffers -- an evaluation then has no host callback and no device synchronisation around its exchange step.
+// One communicator per context (= one per process / GPU): rank 0 makes a 128-byte unique id (dca_comm_unique_id), the
+// caller distributes it by any means it has (torch.distributed store, MPI, a file), every rank calls dca_comm_init.
+// No reference counterpart: pydca is single-process.
+#include <dlfcn.h>
+
+#include "dca_internal.h"
+
+namespace {
+
+// the part of rccl.h's ABI that is used here (stable since NCCL 2.x; RCCL keeps it)
+struct RcclUniqueId { char internal[128]; };
+typedef void* RcclComm;
+enum { kRcclUint32 = 3, kRcclFloat32 = 7, kRcclFloat64 = 8, kRcclSum = 0 };
+
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+    int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+};
+RcclApi g_api;
+
+template <typename F> bool bind(F& fn, const char* name)
+{
+    fn = reinterpret_cast<F>(dlsym(g_api.handle, name));
+    if (!fn) dca_set_error("librccl lacks %s", name);
+    return fn != nullptr;
+}
+
+int load_api(const char* path)
+{
+    if (g_api.handle) return DCA_OK;
+    const char* candidates[] = {path, getenv("DCA_RCCL_PATH"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* c : candidates) {
+        if (!c || !*c) continue;
+        g_api.handle = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        if (g_api.handle) break;
+    }
+    if (!g_api.handle) { dca_set_error("cannot open librccl.so (%s)", dlerror()); return DCA_ERR_IO; }
+    bool ok = bind(g_api.GetUniqueId, "ncclGetUniqueId") && bind(g_api.CommInitRank, "ncclCommInitRank") &&
+              bind(g_api.CommDestroy, "ncclCommDestroy") && bind(g_api.GetErrorString, "ncclGetErrorString") &&
+              bind(g_api.AllReduce, "ncclAllReduce") && bind(g_api.ReduceScatter, "ncclReduceScatter") &&
+              bind(g_api.AllGather, "ncclAllGather") && bind(g_api.GroupStart, "ncclGroupStart") && bind(g_api.GroupEnd, "ncclGroupEnd");
+    if (!ok) { dlclose(g_api.handle); g_api = RcclApi(); return DCA_ERR_IO; }
+    return DCA_OK;
+}
+
+int rccl_type(int dtype) { return dtype == DCA_F32 ? kRcclFloat32 : kRcclFloat64; }
+
+#define RCCL_TRY(expr)                                                                  \
+    do {                                                                                \
+        int _r = (expr);                                                                \
+        if (_r != 0) { dca_set_error("%s failed: %s", #expr, g_api.GetErrorString(_r)); return DCA_ERR_HIP; } \
+    } while (0)
+
+}  // namespace
+
+int dca_comm_unique_id_impl(const char* rccl_path, void* id128)
+{
+    DCA_TRY(load_api(rccl_path));
+    RcclUniqueId id;
+    RCCL_TRY(g_api.GetUniqueId(&id));
+    memcpy(id128, id.internal, sizeof(id.internal));
+    return DCA_OK;
+}
+
+int dca_comm_init_impl(dca_ctx* ctx, const char* rccl_path, const void* id128, int world, int rank)
+{
+    if (world < 1 || rank < 0 || rank >= world) { dca_set_error("dca_comm_init: bad rank / world"); return DCA_ERR_ARG; }
+    DCA_TRY(load_api(rccl_path));
+    if (ctx->comm) { g_api.CommDestroy(static_cast<RcclComm>(ctx->comm)); ctx->comm = nullptr; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    RcclUniqueId id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    RcclComm comm = nullptr;
+    RCCL_TRY(g_api.CommInitRank(&comm, world, id, rank));
+    ctx->comm = comm;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return DCA_OK;
+}
+
+void dca_comm_destroy_impl(dca_ctx* ctx)
+{
+    if (ctx->comm && g_api.CommDestroy) {
+        hipStreamSynchronize(ctx->stream);
+        g_api.CommDestroy(static_cast<RcclComm>(ctx->comm));
+    }
+    ctx->comm = nullptr;
+    ctx->comm_world = 0;
+}
+
+// ---- the three collectives of the sharded optimiser, enqueued on ctx->stream (dca_comm_hook semantics: in place,
+// `count` = whole vector; slices are count / world elements, rank r owns [r * slice, (r + 1) * slice))
+int dca_comm_native(dca_ctx* ctx, int op, void* buf, size_t count, int dtype)
+{
+    if (!ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
+    RcclComm comm = static_cast<RcclComm>(ctx->comm);
+    const size_t esz = dtype == DCA_F32 ? 4 : 8;
+    if (op == DCA_COMM_ALL_REDUCE) {
+        RCCL_TRY(g_api.AllReduce(buf, buf, count, rccl_type(dtype), kRcclSum, comm, ctx->stream));
+        return DCA_OK;
+    }
+    const size_t slice = count / (size_t)ctx->comm_world;
+    char* mine = static_cast<char*>(buf) + (size_t)ctx->comm_rank * slice * esz;      // the in-place forms of both collectives
+    if (op == DCA_COMM_REDUCE_SCATTER) RCCL_TRY(g_api.ReduceScatter(buf, mine, slice, rccl_type(dtype), kRcclSum, comm, ctx->stream));
+    else RCCL_TRY(g_api.AllGather(mine, buf, slice, rccl_type(dtype), comm, ctx->stream));
+    return DCA_OK;
+}
+
+// all-reduce of a vector and of one double (gradient + objective, pair counts + Meff) as one group
+int dca_comm_native_reduce(dca_ctx* ctx, void* vec, size_t count, int dtype, double* scalar_dev)
+{
+    if (!ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
+    RcclComm comm = static_cast<RcclComm>(ctx->comm);
+    RCCL_TRY(g_api.GroupStart());
+    int r1 = g_api.AllReduce(vec, vec, count, rccl_type(dtype), kRcclSum, comm, ctx->stream);
+    int r2 = scalar_dev ? g_api.AllReduce(scalar_dev, scalar_dev, 1, kRcclFloat64, kRcclSum, comm, ctx->stream) : 0;
+    RCCL_TRY(g_api.GroupEnd());
+    RCCL_TRY(r1);
+    RCCL_TRY(r2);
+    return DCA_OK;
+}
+
+int dca_comm_native_sum_u32(dca_ctx* ctx, uint32_t* buf, size_t count)
+{
+    if (!ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
+    RCCL_TRY(g_api.AllReduce(buf, buf, count, kRcclUint32, kRcclSum, static_cast<RcclComm>(ctx->comm), ctx->stream));
+    return DCA_OK;
+}

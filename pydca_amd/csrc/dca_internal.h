@@ -79,6 +79,10 @@ struct dca_ctx {
     PlmEngineBase* plm = nullptr;
     MfEngine* mf = nullptr;
 
+    // native communicator (comm_rccl.cpp): an RCCL communicator whose collectives run on `stream`
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+
     bool profiling = false;
     std::map<std::string, KernelClock> clocks;
 };
@@ -111,7 +115,18 @@ int dca_remember_scores(dca_ctx* ctx, const double* dScores, int n);
 int dca_scores_order_device(dca_ctx* ctx, const double* dScores, int n, int32_t* order_out /* host */);
 
 // ---- weights.hip
-int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision);
+// part / parts: this context counts the tile pairs  t % parts == part  of the upper triangle (1 / parts of the N^2 L / 2
+// comparisons, evenly spread); finish = false leaves the partial counts in ctx->dCounts for the caller to sum
+int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int part = 0, int parts = 1, bool finish = true);
+int dca_weights_finish(dca_ctx* ctx);     // w = 1 / count, Meff from ctx->dCounts
+
+// ---- comm_rccl.cpp
+int dca_comm_unique_id_impl(const char* rccl_path, void* id128);
+int dca_comm_init_impl(dca_ctx* ctx, const char* rccl_path, const void* id128, int world, int rank);
+void dca_comm_destroy_impl(dca_ctx* ctx);
+int dca_comm_native(dca_ctx* ctx, int op, void* buf, size_t count, int dtype);
+int dca_comm_native_reduce(dca_ctx* ctx, void* vec, size_t count, int dtype, double* scalar_dev);
+int dca_comm_native_sum_u32(dca_ctx* ctx, uint32_t* buf, size_t count);
 
 // ---- reductions.hip : deterministic device reductions
 // out[slot] = sum(partials[0..n)) ; single block, fixed tree
@@ -136,6 +151,8 @@ struct PlmEngineBase {
     virtual int set_vector_sharding(int rank, int world, dca_comm_hook hook, void* user) = 0;
     dca_reduce_hook hook = nullptr;
     void* hook_user = nullptr;
+    virtual int set_native_comm(int mode) = 0;     // 0 off, 1 all-reduce of g and fx, 2 sharded optimiser vectors
+    int native_mode = 0;                           // ... through ctx->comm (RCCL) on the context's stream
 };
 PlmEngineBase* dca_make_plm_engine(dca_ctx* ctx);
 
@@ -166,6 +183,7 @@ int dca_mf_engine_scores(MfEngine*, int apc, double* out);
 int dca_mf_engine_di(MfEngine*, int apc, double* out);
 int dca_mf_engine_fields(MfEngine*, double* out);
 void dca_mf_engine_set_hook(MfEngine*, dca_reduce_hook hook, void* user);
+void dca_mf_engine_set_native(MfEngine*, bool on);
 int dca_mf_engine_pair_couplings(MfEngine*, const int* pairs, int npairs, int shift, double* out);
 
 // ---- cholinv.hip : scale * inverse of an SPD matrix on the device (f64 MFMA)

@@ -280,6 +280,7 @@ struct MfEngine {
     double* dRegFi = nullptr;
     dca_reduce_hook hook = nullptr;   // sequence sharding: sums Craw and Meff over the shards
     void* hook_user = nullptr;
+    bool native_reduce = false;       // the same sum through ctx->comm (RCCL on the context's stream)
     ~MfEngine() { dca_dev_free(dRegFi); dca_dev_free(dPerm); dca_dev_free(dOff); dca_dev_free(dXT); dca_dev_free(dDom); dca_dev_free(dCnt1); dca_dev_free(dCraw); dca_dev_free(dFi); dca_dev_free(dC); dca_dev_free(dWork); }
 };
 
@@ -324,16 +325,21 @@ static int mf_counts(MfEngine* m)
         hipLaunchKernelGGL(mf_complete_kernel, dim3(m->L, m->L), dim3(64), 0, ctx->stream, m->dCraw, m->dCnt1, m->dDom,
                            m->L, m->q, m->Lq);
     }
-    if (m->hook) {
+    if (m->hook || m->native_reduce) {
         // the counts are linear in the sequences: shards hold contiguous blocks of the alignment with the
         // GLOBAL weights, the hook sums the Lq x Lq raw counts and the effective sequence number in place
         HIP_TRY(hipMemcpyAsync(ctx->dScal, &ctx->meff, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (m->hook(m->hook_user, m->dCraw, (size_t)m->Lq * m->Lq, DCA_F64, ctx->dScal) != 0) {
-            dca_set_error("reduce hook failed");
-            return DCA_ERR_ARG;
+        if (m->native_reduce) {
+            DCA_TRY(dca_comm_native_reduce(ctx, m->dCraw, (size_t)m->Lq * m->Lq, DCA_F64, ctx->dScal));
+        } else {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (m->hook(m->hook_user, m->dCraw, (size_t)m->Lq * m->Lq, DCA_F64, ctx->dScal) != 0) {
+                dca_set_error("reduce hook failed");
+                return DCA_ERR_ARG;
+            }
         }
-        HIP_TRY(hipMemcpy(&ctx->meff, ctx->dScal, sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(&ctx->meff, ctx->dScal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));      // Meff is a kernel argument below
     }
     hipLaunchKernelGGL(mf_fi_kernel, dim3(ceil_div(m->Lq, 256)), dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->Lq, m->Lq, ctx->meff);
     HIP_TRY(hipGetLastError());
@@ -537,9 +543,11 @@ int dca_mf_engine_pair_couplings(MfEngine* m, const int* pairs, int npairs, int 
     return dca_pair_blocks(m->ctx, m->dJ, 1, DCA_F64, m->L, m->q, m->np, pairs, npairs, shift, out);
 }
 
+void dca_mf_engine_set_native(MfEngine* m, bool on) { m->native_reduce = on; if (on) { m->hook = nullptr; m->hook_user = nullptr; } }
 void dca_mf_engine_set_hook(MfEngine* m, dca_reduce_hook hook, void* user)
 {
     m->hook = hook;
     m->hook_user = user;
+    m->native_reduce = false;
     m->have_counts = m->have_corr = m->have_J = m->corr_on_device = false;
 }

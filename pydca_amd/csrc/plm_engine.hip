@@ -1244,11 +1244,12 @@ struct PlmEngine : PlmEngineBase {
         int rc = (q == 21) ? launch_eval<21>() : launch_eval<5>();
         if (rc != DCA_OK) return rc;
         o.evals += 1;
-        if (comm) {
+        if (comm || native_mode == 2) {
             // sharded vectors: sum the shards' gradients, keep this rank's slice; fx is summed with the
             // scalars of the caller (eval_scalars / gradient)
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            if (comm(comm_user, DCA_COMM_REDUCE_SCATTER, dg, Ppad, (int)sizeof(T) * 8) != 0) { dca_set_error("comm hook failed (reduce-scatter)"); return DCA_ERR_ARG; }
+            DCA_TRY(do_comm(DCA_COMM_REDUCE_SCATTER, dg, Ppad, (int)sizeof(T) * 8, "reduce-scatter"));
+        } else if (native_mode == 1) {
+            DCA_TRY(dca_comm_native_reduce(ctx, dg, P, (int)sizeof(T) * 8, ctx->dScal));      // on the stream: no host round trip
         } else if (hook) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             if (hook(hook_user, dg, P, (int)sizeof(T) * 8, ctx->dScal) != 0) {
@@ -1260,33 +1261,56 @@ struct PlmEngine : PlmEngineBase {
     }
 
     // sum `count` device doubles ctx->dScal[first..] over the ranks (no-op when vectors are not sharded)
+    // one collective of the sharded optimiser: through the native communicator on the stream (no host round trip),
+    // or through the caller's hook (the stream is drained first: the hook works outside it)
+    int do_comm(int op, void* buf, size_t count, int dtype, const char* what)
+    {
+        if (native_mode == 2) return dca_comm_native(ctx, op, buf, count, dtype);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (comm(comm_user, op, buf, count, dtype) != 0) { dca_set_error("comm hook failed (%s)", what); return DCA_ERR_ARG; }
+        return DCA_OK;
+    }
     int reduce_scalars(int first, int count)
     {
-        if (!comm) return DCA_OK;
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (comm(comm_user, DCA_COMM_ALL_REDUCE, ctx->dScal + first, (size_t)count, DCA_F64) != 0) { dca_set_error("comm hook failed (all-reduce)"); return DCA_ERR_ARG; }
-        return DCA_OK;
+        if (!comm && native_mode != 2) return DCA_OK;
+        return do_comm(DCA_COMM_ALL_REDUCE, ctx->dScal + first, (size_t)count, DCA_F64, "all-reduce");
     }
     // make a P-vector whose slices are valid on their owners valid everywhere
     int gather_vector(T* v)
     {
-        if (!comm) return DCA_OK;
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (comm(comm_user, DCA_COMM_ALL_GATHER, v, Ppad, (int)sizeof(T) * 8) != 0) { dca_set_error("comm hook failed (all-gather)"); return DCA_ERR_ARG; }
-        return DCA_OK;
+        if (!comm && native_mode != 2) return DCA_OK;
+        return do_comm(DCA_COMM_ALL_GATHER, v, Ppad, (int)sizeof(T) * 8, "all-gather");
     }
     int set_vector_sharding(int rank, int world, dca_comm_hook h, void* user) override
     {
         if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
         if (o.begun && !o.finished) { dca_set_error("vector sharding cannot change during an optimisation"); return DCA_ERR_STATE; }
+        if (native_mode == 2) native_mode = 0;
         if (!h || world < 1) { vlo = 0; vn = P; Ppad = P; comm = nullptr; comm_user = nullptr; return DCA_OK; }
+        DCA_TRY(set_slices(rank, world));
+        comm = h; comm_user = user;
+        return DCA_OK;
+    }
+    int set_slices(int rank, int world)
+    {
         if (rank < 0 || rank >= world || world > 64) { dca_set_error("bad rank / world"); return DCA_ERR_ARG; }
         const size_t slice = (P + (size_t)world * 4 - 1) / ((size_t)world * 4) * 4;    // multiple of 4 elements: 16-byte aligned slices
         if (slice * world > P + kVecPad) { dca_set_error("world too large for the vector padding"); return DCA_ERR_ARG; }
         Ppad = slice * world;
         vlo = slice * rank;
         vn = vlo >= P ? 0 : std::min(slice, P - vlo);
-        comm = h; comm_user = user;
+        return DCA_OK;
+    }
+    int set_native_comm(int mode) override
+    {
+        if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
+        if (o.begun && !o.finished) { dca_set_error("the exchange scheme cannot change during an optimisation"); return DCA_ERR_STATE; }
+        if (mode != 0 && !ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
+        if (mode < 0 || mode > 2) return DCA_ERR_ARG;
+        comm = nullptr; comm_user = nullptr;
+        vlo = 0; vn = P; Ppad = P;
+        if (mode == 2) DCA_TRY(set_slices(ctx->comm_rank, ctx->comm_world));
+        native_mode = mode;
         return DCA_OK;
     }
 

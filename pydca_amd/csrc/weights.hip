@@ -49,7 +49,7 @@ __global__ void weights_bitplanes_kernel(const uint8_t* __restrict__ X, uint32_t
 template <int PL>
 __global__ __launch_bounds__(256)
 void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__ counts, int N, int L, int G, int thresh,
-                          int tilesPerSide)
+                          int tilesPerSide, int part, int parts)
 {
     constexpr int PLP = (PL + 1) & ~1;
     constexpr int ROWDW = kKG * PLP;
@@ -62,9 +62,13 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
     // The 1-D grid walks the tile-pair matrix in 32 x 32 super-tiles so that the workgroups in flight
     // share row and column tiles in L2 (a row-major walk streams the whole plane array per tile row:
     // 6 GB of fabric traffic at config D for 16 MB of planes).
+    // Sharded (parts > 1): this launch covers the virtual workgroups  v = blockIdx.x * parts + part, i.e. every
+    // parts-th tile pair of every super-tile -- 1 / parts of the comparisons, spread evenly over the triangle.
     constexpr int S = 32;
     const int superPerSide = (tilesPerSide + S - 1) / S;
-    const int sid = blockIdx.x / (S * S), within = blockIdx.x % (S * S);
+    const unsigned vb = blockIdx.x * (unsigned)parts + (unsigned)part;
+    if (vb >= (unsigned)(superPerSide * superPerSide * S * S)) return;
+    const int sid = vb / (S * S), within = vb % (S * S);
     const int tileY = (sid / superPerSide) * S + within / S;
     const int tileX = (sid % superPerSide) * S + within % S;
     if (tileY >= tilesPerSide || tileX >= tilesPerSide || tileX < tileY) return;
@@ -183,8 +187,9 @@ __global__ void weights_finish_kernel(const uint32_t* __restrict__ counts, doubl
 
 }  // namespace
 
-int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision)
+int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int part, int parts, bool finish)
 {
+    if (parts < 1 || part < 0 || part >= parts) { dca_set_error("weights: bad part / parts"); return DCA_ERR_ARG; }
     const int N = ctx->N, L = ctx->L;
     // smallest ident for which the reference's test is true, evaluated in its precision
     int thresh = L + 1;
@@ -205,18 +210,26 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision)
         const unsigned tb = (unsigned)(((size_t)N * G + 255) / 256);
         const int tilesPerSide = ceil_div(N, kTile);
         const int superPerSide = ceil_div(tilesPerSide, 32);
-        dim3 grid((unsigned)(superPerSide * superPerSide * 32 * 32));
+        dim3 grid((unsigned)ceil_div(superPerSide * superPerSide * 32 * 32, parts));
         if (small) {
             hipLaunchKernelGGL(weights_bitplanes_kernel<3>, dim3(tb), dim3(256), 0, ctx->stream, ctx->dX, dP, N, ctx->Ls);
-            hipLaunchKernelGGL(weights_count_kernel<3>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide);
+            hipLaunchKernelGGL(weights_count_kernel<3>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide, part, parts);
         } else {
             hipLaunchKernelGGL(weights_bitplanes_kernel<5>, dim3(tb), dim3(256), 0, ctx->stream, ctx->dX, dP, N, ctx->Ls);
-            hipLaunchKernelGGL(weights_count_kernel<5>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide);
+            hipLaunchKernelGGL(weights_count_kernel<5>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide, part, parts);
         }
         hipError_t e = hipStreamSynchronize(ctx->stream);
         dca_dev_free(dP);
         if (e != hipSuccess) { dca_set_error("weights kernel: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     }
+    ctx->have_weights = false;
+    ctx->have_counts = true;           // (partial) counts are in ctx->dCounts
+    return finish ? dca_weights_finish(ctx) : DCA_OK;
+}
+
+int dca_weights_finish(dca_ctx* ctx)
+{
+    const int N = ctx->N;
     hipLaunchKernelGGL(weights_finish_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, ctx->stream, ctx->dCounts, ctx->dWd, N);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));

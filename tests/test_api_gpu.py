@@ -240,6 +240,108 @@ def test_reduce_hook_through_torch_distributed():
         dist.destroy_process_group()
 
 
+def test_native_rccl_communicator_single_rank():
+    """The library's own RCCL communicator (csrc/comm_rccl.cpp) with one rank: every collective runs on the context's
+    stream and is an identity, so all-reduce mode, sharded-vector mode, the sharded weights and the mfDCA count
+    reduction must reproduce the unsharded results bit for bit -- and no Python hook is involved."""
+    from pydca_amd import _lib, parallel
+    G = golden("plm_toy_protein")
+    X, q = G["X"], int(G["q"])
+    ref = _lib.Context(0, _lib.DCA_F32)
+    ref.set_msa(X, q)
+    w_ref = ref.compute_weights(0.8, _lib.DCA_F32)
+    ref.plm_configure(1.0, 5.0)
+    ref.plm_init_x()
+    fx0 = ref.plm_gradient()
+    g0 = ref.plm_get_g(np.float32)
+    ref.plm_lbfgs_begin(6)
+    st0 = ref.plm_lbfgs_iterate(6)
+    x0 = ref.plm_get_x(np.float32)
+    ref.close()
+    for mode in (1, 2):
+        ctx = _lib.Context(0, _lib.DCA_F32)
+        ctx.set_msa(X, q)
+        with pytest.raises(_lib.DcaBackendError):
+            ctx.compute_weights_sharded(0.8, _lib.DCA_F32)           # no communicator yet: loud
+        parallel.init_native_comm(ctx, _lib, 0, 1)
+        w = ctx.compute_weights_sharded(0.8, _lib.DCA_F32)
+        assert np.array_equal(w, w_ref)
+        ctx.plm_configure(1.0, 5.0)
+        ctx.plm_init_x()
+        ctx.plm_set_native_comm(mode)
+        assert ctx.plm_gradient() == fx0 and np.array_equal(ctx.plm_get_g(np.float32), g0)
+        ctx.plm_lbfgs_begin(6)
+        st = ctx.plm_lbfgs_iterate(6)
+        assert (st.status, st.iterations, st.evaluations, st.fx) == (st0.status, st0.iterations, st0.evaluations, st0.fx)
+        assert np.array_equal(ctx.plm_get_x(np.float32), x0)
+        ctx.plm_set_native_comm(0)
+        ctx.comm_destroy()
+        with pytest.raises(_lib.DcaBackendError):
+            ctx.plm_set_native_comm(mode)                            # communicator gone
+        ctx.close()
+    M = golden("mf_toy_protein")
+    mctx = _lib.Context(0, _lib.DCA_F64)
+    mctx.set_msa((M["X"] - 1).astype(np.uint8), int(M["q"]))
+    parallel.init_native_comm(mctx, _lib, 0, 1)
+    mctx.compute_weights_sharded(float(M["seqid"]), _lib.DCA_F64)
+    np.testing.assert_array_equal(mctx.weights(), M["w"])
+    mctx.mf_set_native_comm(True)
+    scores = mctx.mf_run(float(M["pseudocount"]), True)
+    ranked = sorted(zip(scores, range(len(scores))), key=lambda t: (-t[0], t[1]))
+    np.testing.assert_allclose([s for s, _ in ranked], M["apc_scores"], rtol=1e-9, atol=1e-12)
+    mctx.close()
+
+
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_weights_partial_counts_sum_to_full(parts):
+    """SURVEY 8 e2: the identity comparisons divided over `parts` ranks (every parts-th tile pair of the upper triangle);
+    the integer partial counts sum to the counts of the unsharded kernel, and set_weight_counts gives the same weights."""
+    from pydca_amd import _lib
+    sys.path.insert(0, ROOT)
+    from tools.gen_msa import dedup, generate
+    X = dedup(generate(70, 3000, 21, 3))
+    ctx = _lib.Context(0, _lib.DCA_F32)
+    ctx.set_msa(X, 21)
+    w = ctx.compute_weights(0.8, _lib.DCA_F32)
+    full = ctx.weight_counts()
+    total = np.zeros_like(full, dtype=np.uint64)
+    for r in range(parts):
+        part = ctx.weights_partial_counts(0.8, _lib.DCA_F32, r, parts)
+        assert part.sum() < full.sum()
+        total += part
+    assert np.array_equal(total, full)
+    ctx.set_weight_counts(total.astype(np.uint32))
+    assert np.array_equal(ctx.weights(), w) and np.array_equal(ctx.weight_counts(), full)
+    with pytest.raises(_lib.DcaBackendError):
+        ctx.set_weight_counts(np.zeros_like(full))
+    ctx.close()
+
+
+def test_changed_weights_invalidate_derived_state():
+    """Weights set after an engine was built must not be answered from the old weights: the engines are
+    dropped, the mfDCA chain recomputes, the plmDCA engine asks for a new configure."""
+    from pydca_amd import _lib
+    M = golden("mf_toy_rna")
+    X = (M["X"] - 1).astype(np.uint8)
+    ctx = _lib.Context(0, _lib.DCA_F64)
+    ctx.set_msa(X, 5)
+    ctx.compute_weights(0.8, _lib.DCA_F64)
+    s_w = ctx.mf_run(0.5, True)
+    ctx.set_weights(np.ones(X.shape[0]))
+    s_1 = ctx.mf_run(0.5, True)
+    fresh = _lib.Context(0, _lib.DCA_F64)
+    fresh.set_msa(X, 5)
+    fresh.set_weights(np.ones(X.shape[0]))
+    assert np.array_equal(s_1, fresh.mf_run(0.5, True)) and not np.array_equal(s_1, s_w)
+    fresh.close()
+    ctx.plm_configure(1.0, 1.0)
+    ctx.plm_init_x()
+    ctx.compute_weights(0.8, _lib.DCA_F64)
+    with pytest.raises(_lib.DcaBackendError):
+        ctx.plm_gradient()                                           # configure again after the weights changed
+    ctx.close()
+
+
 def test_direct_information_through_the_classes(tmp_path):
     """compute_sorted_DI[_APC] of both classes and the compute_di sub-commands."""
     from pydca_amd import mfdca_main, plmdca_main
