@@ -57,41 +57,51 @@ class MSATrimmer:
     def alignment_data(self):
         return self.__alignment_data
 
-    def compute_msa_columns_gap_size(self):
-        """msa_trimmer.py:60-95: fraction of '.' / '-' per column."""
+    def _gap_mask(self):
+        """bool[N, L]: True where a record has '.' or '-'."""
         chars = np.array([np.frombuffer(r.seq.encode('latin-1'), dtype=np.uint8) for r in self.__alignment_data])
-        num_seqs = len(self.__alignment_data)
-        gaps = ((chars == ord('.')) | (chars == ord('-'))).sum(axis=0)
-        return tuple(float(g) / float(num_seqs) for g in gaps)
+        return (chars == ord('.')) | (chars == ord('-'))
+
+    def compute_msa_columns_gap_size(self):
+        """Fraction of gap characters in every column (msa_trimmer.py:60-95), as a tuple of floats."""
+        gaps = self._gap_mask().sum(axis=0)
+        num_seqs = float(len(self.__alignment_data))
+        return tuple(float(g) / num_seqs for g in gaps)
 
     def msa_columns_beyond_max_gap(self):
-        """msa_trimmer.py:98-119."""
-        columns_gap_size = self.compute_msa_columns_gap_size()
-        return tuple(i for i in range(len(columns_gap_size)) if columns_gap_size[i] > self.__max_gap)
+        """Columns whose gap fraction exceeds max_gap, ascending (msa_trimmer.py:98-119)."""
+        fractions = np.array(self.compute_msa_columns_gap_size())
+        return tuple(int(c) for c in np.flatnonzero(fractions > self.__max_gap))
 
     def trim_by_gap_size(self):
-        """msa_trimmer.py:122-137."""
-        return tuple(self.msa_columns_beyond_max_gap())
+        """Columns to drop when trimming by gap fraction alone (msa_trimmer.py:122-137)."""
+        return self.msa_columns_beyond_max_gap()
 
     def trim_by_refseq(self, remove_all_gaps=False):
-        """msa_trimmer.py:140-194."""
-        seqbackmapper = SequenceBackmapper(msa_file=self.__msa_file, refseq_file=self.__refseq_file,
-                                           biomolecule=self.__biomolecule)
-        first_matching_seq = seqbackmapper.find_matching_seqs_from_alignment()[0]
-        gap_symbols = ['-', '.']
+        """Columns to drop with respect to the row that matches the reference sequence (msa_trimmer.py:140-194): the
+        columns where that row has a gap -- all of them with remove_all_gaps, otherwise only those that are also beyond
+        the gap-fraction threshold."""
+        backmapper = SequenceBackmapper(msa_file=self.__msa_file, refseq_file=self.__refseq_file, biomolecule=self.__biomolecule)
+        row = backmapper.find_matching_seqs_from_alignment()[0]
+        logger.info('\n\tRow of the alignment taken as the reference sequence:\n\t{}'.format(row))
+        gapped = np.frombuffer(row.encode('latin-1'), dtype=np.uint8)
+        gapped = (gapped == ord('-')) | (gapped == ord('.'))
         if not remove_all_gaps:
-            candidates = self.msa_columns_beyond_max_gap()
-            columns_to_remove = [i for i in candidates if first_matching_seq[i] in gap_symbols]
-        else:
-            seqs_len = len(self.__alignment_data[0].seq)
-            columns_to_remove = [i for i in range(seqs_len) if first_matching_seq[i] in gap_symbols]
-        return tuple(columns_to_remove)
+            keep_candidates = np.zeros(gapped.size, dtype=bool)
+            keep_candidates[list(self.msa_columns_beyond_max_gap())] = True
+            gapped &= keep_candidates
+        columns = tuple(int(c) for c in np.flatnonzero(gapped))
+        logger.info('\n\t{} columns are removed'.format(len(columns)))
+        return columns
 
     def get_msa_trimmed_by_refseq(self, remove_all_gaps=False):
-        """msa_trimmer.py:197-207."""
-        columns_to_remove = set(self.trim_by_refseq(remove_all_gaps=remove_all_gaps))
-        trimmed_msa = list()
+        """[(id, sequence without the trim_by_refseq columns)] for every record (msa_trimmer.py:197-207)."""
+        length = len(self.__alignment_data[0].seq)
+        keep = np.ones(length, dtype=bool)
+        keep[list(self.trim_by_refseq(remove_all_gaps=remove_all_gaps))] = False
+        kept = np.flatnonzero(keep)
+        out = []
         for record in self.__alignment_data:
-            trimmed_seq = [record.seq[i] for i in range(len(record.seq)) if i not in columns_to_remove]
-            trimmed_msa.append((record.id, ''.join(trimmed_seq)))
-        return trimmed_msa
+            chars = np.frombuffer(record.seq.encode('latin-1'), dtype=np.uint8)
+            out.append((record.id, chars[kept].tobytes().decode('latin-1')))
+        return out

@@ -125,61 +125,70 @@ class SequenceBackmapper:
         return best
 
     @staticmethod
-    def align_subsequences(ref_middle_subseq=None, template_subseq_in_msa=None, num_res_middle_template=None):
-        """sequence_backmapper.py:286-336: copy the template's MSA gaps into the reference part."""
-        mapped_ref_subseq = []
-        res_count = 0
-        pos = 0
-        for site in template_subseq_in_msa:
-            if res_count == num_res_middle_template:
+    def _thread_through_row(aligned_ref, row_tail, n_template):
+        """Lays the reference side of a pairwise alignment (`aligned_ref`: residues and '-') along a stretch of the
+        template's MSA row (`row_tail`) and yields one character per produced column: the reference residue that
+        falls on that column, or '-'.
+
+        The rule is the reference implementation's (sequence_backmapper.py:286-336), kept with its corner cases
+        because the mapping is defined by it (pinned by tests/golden/backmap_cases.json, which the reference itself
+        produced): a residue column of the row takes the next alignment column whatever it holds; a gap column of the
+        row swallows one alignment column only if that column is a gap on the reference side; the walk stops once
+        `n_template` residues of the row or the whole alignment have been used, and whatever is left of the
+        alignment is emitted unchanged.  An alignment exhausted by a swallowed gap raises IndexError, as there."""
+        cursor, used = 0, 0
+        for site in row_tail:
+            if used == n_template:
                 break
-            if site != '-':
-                mapped_ref_subseq.append(ref_middle_subseq[pos])
-                pos += 1
-                res_count += 1
-                if pos == len(ref_middle_subseq):
-                    break
-            else:
-                if ref_middle_subseq[pos] != '-':
-                    mapped_ref_subseq.append('-')
-                else:
-                    mapped_ref_subseq.append(ref_middle_subseq[pos])
-                    pos += 1
-        mapped_ref_subseq.extend(list(ref_middle_subseq[pos:]))
-        return ''.join(mapped_ref_subseq)
+            here = aligned_ref[cursor]                  # IndexError when a swallowed gap exhausted the alignment
+            if site == '-':
+                yield '-'
+                cursor += here == '-'
+                continue
+            yield here
+            cursor += 1
+            used += 1
+            if cursor == len(aligned_ref):
+                break
+        yield from aligned_ref[cursor:]
+
+    @staticmethod
+    def align_subsequences(ref_middle_subseq=None, template_subseq_in_msa=None, num_res_middle_template=None):
+        """Public helper of the reference class (sequence_backmapper.py:286-336): the reference part of the local
+        alignment re-spaced with the MSA gaps of the template row, as a string."""
+        return ''.join(SequenceBackmapper._thread_through_row(ref_middle_subseq, template_subseq_in_msa,
+                                                              num_res_middle_template))
+
+    @staticmethod
+    def _column_after_residues(row, count):
+        """First column of `row` at which `count` residues lie to the left (0 when the row has no such column --
+        the reference's loop leaves its start index at 0 then, sequence_backmapper.py:403-412)."""
+        seen = 0
+        for column, site in enumerate(row):
+            if seen == count:
+                return column
+            seen += site != '-'
+        return 0
 
     def map_to_reference_sequence(self):
-        """sequence_backmapper.py:339-466 -> {MSA column: reference position}."""
-        logger.info('\n\tBackmapping reference sequence to MSA')
-        template_seq_in_msa = self.find_matching_seqs_from_alignment()[0]
-        template_gaps_removed = template_seq_in_msa.replace('-', '')
-        ref_aligned, template_aligned, _score, start_indx, end_indx = self.align_pairs_local(
-            self.__ref_sequence, template_gaps_removed)[0]
-        ref_middle_subseq = ref_aligned[start_indx:end_indx]
-        template_middle_subseq = template_aligned[start_indx:end_indx]
-        num_leading_res_template = len(template_aligned[:start_indx].replace('-', ''))
-        num_leading_res_ref = len(ref_aligned[:start_indx].replace('-', ''))
-        num_res_middle_template = len(template_middle_subseq.replace('-', ''))
-        res_count = 0
-        start_indx_in_msa = 0
-        for k, site in enumerate(template_seq_in_msa):
-            if res_count == num_leading_res_template:
-                start_indx_in_msa = k
-                break
-            if site != '-':
-                res_count += 1
-        template_subseq_in_msa = template_seq_in_msa[start_indx_in_msa:]
-        backmapped_ref_subseq = self.align_subsequences(
-            ref_middle_subseq=ref_middle_subseq, template_subseq_in_msa=template_subseq_in_msa,
-            num_res_middle_template=num_res_middle_template)
-        mapped_sites = dict()
-        mapped_res_count = 0
-        for k, site in enumerate(backmapped_ref_subseq):
-            if k == len(template_seq_in_msa) - start_indx_in_msa:
-                break
-            if site != '-':
-                mapped_sites[mapped_res_count + num_leading_res_ref] = start_indx_in_msa + k
-                mapped_res_count += 1
-        logger.info('\n\tNumber of residues mapped: {}\n\tNumber of residues in the (original) reference sequence: {}'.format(
-            len(mapped_sites), len(self.__ref_sequence)))
-        return {value: key for key, value in mapped_sites.items()}
+        """-> {MSA column: position in the reference sequence} (sequence_backmapper.py:339-466).
+
+        The row of the alignment that matches the reference best is aligned locally against the reference; the columns
+        of that local alignment are then laid along the row (`_thread_through_row`) starting at the first column
+        that has all of the row's unaligned leading residues to its left, and every column that received a reference
+        residue is mapped to that residue's position, counted from the first aligned one."""
+        logger.info('\n\tMapping the reference sequence onto the alignment columns')
+        row = self.find_matching_seqs_from_alignment()[0]
+        ref_full, template_full, _score, begin, end = self.align_pairs_local(self.__ref_sequence, row.replace('-', ''))[0]
+        residues = lambda text: len(text) - text.count('-')            # noqa: E731
+        first_column = self._column_after_residues(row, residues(template_full[:begin]))
+        ref_position = residues(ref_full[:begin])
+        placed = list(self._thread_through_row(ref_full[begin:end], row[first_column:], residues(template_full[begin:end])))
+        column_to_position = {}
+        for column, char in zip(range(first_column, len(row)), placed):
+            if char != '-':
+                column_to_position[column] = ref_position
+                ref_position += 1
+        logger.info('\n\t{} of the {} residues of the reference sequence have a column'.format(
+            len(column_to_position), len(self.__ref_sequence)))
+        return column_to_position

@@ -272,6 +272,132 @@ def runs_golden():
     np.savez_compressed(os.path.join(HERE, "plm_runs.npz"), **out)
 
 
+def _random_backmap_case(rng, alphabet):
+    """A reference sequence, an MSA row (with '-') of a related template and SOME gapped local alignment of the
+    reference against the gap-free template in Bio.pairwise2's layout (both sequences in full, unaligned ends padded
+    with '-', [begin, end) the aligned columns).  Optimality is irrelevant: this feeds the post-alignment logic."""
+    n = int(rng.integers(6, 40))
+    ref = "".join(rng.choice(list(alphabet), n))
+    t = list(ref[int(rng.integers(0, 4)):n - int(rng.integers(0, 4))])
+    for _ in range(int(rng.integers(0, 5))):
+        if not t:
+            break
+        pos = int(rng.integers(0, len(t)))
+        op = int(rng.integers(0, 3))
+        if op == 0:
+            t[pos] = str(rng.choice(list(alphabet)))
+        elif op == 1:
+            t[pos:pos] = list(rng.choice(list(alphabet), int(rng.integers(1, 3))))
+        else:
+            del t[pos:pos + int(rng.integers(1, 3))]
+    t = "".join(t) or str(rng.choice(list(alphabet)))
+    row = []
+    for ch in t:                                    # the template as an MSA row: gaps sprinkled in
+        row.extend("-" * int(rng.integers(0, 3) if rng.random() < 0.3 else 0))
+        row.append(ch)
+    row.extend("-" * int(rng.integers(0, 3)))
+    row = "".join(row)
+    sa, sb = int(rng.integers(0, min(4, len(ref)))), int(rng.integers(0, min(4, len(t))))
+    ia, ib, ma, mb = sa, sb, [], []
+    while ia < len(ref) and ib < len(t) and rng.random() < 0.97:
+        r = rng.random()
+        if r < 0.8 or not ma:
+            ma.append(ref[ia]); mb.append(t[ib]); ia += 1; ib += 1
+        elif r < 0.9:
+            ma.append("-"); mb.append(t[ib]); ib += 1
+        else:
+            ma.append(ref[ia]); mb.append("-"); ia += 1
+    pre = max(sa, sb)
+    ta, tb = ref[ia:], t[ib:]
+    post = max(len(ta), len(tb))
+    full_a = "-" * (pre - sa) + ref[:sa] + "".join(ma) + ta + "-" * (post - len(ta))
+    full_b = "-" * (pre - sb) + t[:sb] + "".join(mb) + tb + "-" * (post - len(tb))
+    return dict(ref=ref, row=row, aligned_ref=full_a, aligned_template=full_b, begin=pre, end=pre + len(ma))
+
+
+def backmap_golden():
+    """backmap_cases.json: the reference's own post-alignment logic (SequenceBackmapper.align_subsequences and
+    map_to_reference_sequence, sequence_backmapper.py:286-466) on random inputs, and MSATrimmer's column selections
+    (msa_trimmer.py:98-207) on a small alignment.  Bio.pairwise2 / Bio.SubsMat are not installed: they are stubbed
+    only far enough for the imports to succeed, and the pairwise alignment itself is INJECTED (align_pairs_local and
+    find_matching_seqs_from_alignment are replaced per case), so what is pinned is everything downstream of it."""
+    import json
+    import types
+    from pydca.sequence_backmapper import sequence_backmapper as ref_bm
+    rng = np.random.default_rng(2024)
+    cases = []
+    for k in range(300):
+        c = _random_backmap_case(rng, "ACGU" if k % 2 else "ARNDCQEGHILKMFPSTWYV")
+        obj = object.__new__(ref_bm.SequenceBackmapper)
+        obj._SequenceBackmapper__alignment = [c["row"]]
+        obj._SequenceBackmapper__ref_sequence = c["ref"]
+        obj._SequenceBackmapper__biomolecule = "RNA" if k % 2 else "PROTEIN"
+        aln = [(c["aligned_ref"], c["aligned_template"], 0.0, c["begin"], c["end"])]
+        obj.align_pairs_local = types.MethodType(lambda self, a, b, score_only=False, _aln=aln: _aln, obj)
+        obj.find_matching_seqs_from_alignment = types.MethodType(lambda self, _row=c["row"]: [_row], obj)
+        try:
+            mapping = obj.map_to_reference_sequence()
+            c["mapping"] = sorted([int(a), int(b)] for a, b in mapping.items())
+            c["raises"] = None
+        except Exception as exc:                      # the reference's walk can run off its input; pinned as such
+            c["mapping"] = None
+            c["raises"] = type(exc).__name__
+        mid_ref = c["aligned_ref"][c["begin"]:c["end"]]
+        nmid = len(c["aligned_template"][c["begin"]:c["end"]].replace("-", ""))
+        try:
+            c["align_subsequences"] = ref_bm.SequenceBackmapper.align_subsequences(
+                ref_middle_subseq=mid_ref, template_subseq_in_msa=c["row"], num_res_middle_template=nmid)
+        except Exception as exc:
+            c["align_subsequences"] = "!" + type(exc).__name__
+        cases.append(c)
+    with open(os.path.join(HERE, "backmap_cases.json"), "w") as fh:
+        json.dump(cases, fh, indent=0)
+    print("backmap_cases: %d cases, %d raise" % (len(cases), sum(1 for c in cases if c["raises"])))
+
+
+def trimmer_golden():
+    """trimmer_cases.json: MSATrimmer (msa_trimmer.py:15-207) of the reference on the bundled RF00167 alignment and its
+    reference sequence (the matching row is found without pairwise2 only when the first row matches, so the matching
+    row is injected as in backmap_golden) -- column selections for several max_gap values and both refseq modes."""
+    import json
+    import types
+    from pydca.msa_trimmer import msa_trimmer as ref_tr
+    from pydca.sequence_backmapper import sequence_backmapper as ref_bm
+    msa = os.path.join(DATA, "MSA_RF00167.fa")
+    refseq = os.path.join(DATA, "ref_RF00167.fa")
+    recs = read_records(msa)
+    target = read_records(refseq)[0][1].upper()
+    match = [s for _n, s in recs if s.replace("-", "").replace(".", "").upper() == target][0]
+    orig = ref_bm.SequenceBackmapper.find_matching_seqs_from_alignment
+    ref_bm.SequenceBackmapper.find_matching_seqs_from_alignment = lambda self: [match]
+    out = {"matching_row": match, "cases": []}
+    try:
+        for max_gap in (0.0, 0.1, 0.5, 0.9, 1.0):
+            tr = ref_tr.MSATrimmer(msa, biomolecule="rna", max_gap=max_gap, refseq_file=refseq)
+            gaps = tr.compute_msa_columns_gap_size()
+            trimmed = tr.get_msa_trimmed_by_refseq(remove_all_gaps=False)
+            out["cases"].append(dict(max_gap=max_gap, gap_size_first=list(gaps[:12]), beyond=list(tr.msa_columns_beyond_max_gap()),
+                                     by_gap=list(tr.trim_by_gap_size()), by_refseq=list(tr.trim_by_refseq()),
+                                     by_refseq_all=list(tr.trim_by_refseq(remove_all_gaps=True)),
+                                     trimmed_first=[list(trimmed[0]), list(trimmed[-1])], trimmed_len=len(trimmed[0][1])))
+    finally:
+        ref_bm.SequenceBackmapper.find_matching_seqs_from_alignment = orig
+    with open(os.path.join(HERE, "trimmer_cases.json"), "w") as fh:
+        json.dump(out, fh, indent=0)
+    print("trimmer_cases: %d cases" % len(out["cases"]))
+
+
+def install_bio_alignment_stubs(tmp):
+    """Bio.pairwise2 and Bio.SubsMat.MatrixInfo far enough for `import` to succeed (their functions are never reached:
+    the callers are replaced per case); Bio.AlignIO records get the attributes MSATrimmer reads (.id, .seq)."""
+    with open(os.path.join(tmp, "Bio", "pairwise2.py"), "w") as fh:
+        fh.write("class _A:\n    def localds(self, *a, **k):\n        raise NotImplementedError('pairwise2 is not installed')\nalign = _A()\n")
+    os.makedirs(os.path.join(tmp, "Bio", "SubsMat"))
+    open(os.path.join(tmp, "Bio", "SubsMat", "__init__.py"), "w").close()
+    with open(os.path.join(tmp, "Bio", "SubsMat", "MatrixInfo.py"), "w") as fh:
+        fh.write("blosum62 = {}\n")
+
+
 def reader_sweep_cases():
     """Inputs of the reader sweep: every capital and small letter, the three gap characters, a
     duplicate row, CRLF line ends, a line longer than L -- and the inputs on which the reference throws
@@ -333,6 +459,7 @@ def main():
     ap.add_argument("--skip-slow", action="store_true")
     ap.add_argument("--only-reader", action="store_true", help="regenerate only reader_sweep.npz")
     ap.add_argument("--only-runs", action="store_true", help="regenerate only plm_runs.npz (needs data/ present)")
+    ap.add_argument("--only-backmap", action="store_true", help="regenerate only backmap_cases.json / trimmer_cases.json")
     ap.add_argument("--only-params", action="store_true", help="regenerate only params_*.npz")
     ap.add_argument("--only-di", action="store_true", help="regenerate only di_*.npz (needs plm_*.npz present)")
     args = ap.parse_args()
@@ -343,6 +470,16 @@ def main():
     if args.only_runs:
         oplm.build(ref=True)
         runs_golden()
+        return
+    if args.only_backmap:
+        tmp = tempfile.mkdtemp(prefix="pydca_stubs_")
+        try:
+            install_stubs(tmp)
+            install_bio_alignment_stubs(tmp)
+            backmap_golden()
+            trimmer_golden()
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
         return
     if args.only_params:
         tmp = tempfile.mkdtemp(prefix="pydca_stubs_")
@@ -419,6 +556,9 @@ def main():
         params_golden("toy_protein", toy_prot, "protein", 0.5, 0.8)
         if not args.skip_slow:
             mf_golden("pf02826", pf, "protein", 0.5, 0.8, stages=False)
+        install_bio_alignment_stubs(tmp)
+        backmap_golden()
+        trimmer_golden()
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     np.savez(os.path.join(HERE, "kat_notebook.npz"),

@@ -94,6 +94,66 @@ def test_map_to_reference_sequence_on_the_reference_test_inputs(msa, ref, bio):
     assert same == mapping
 
 
+def _golden_json(name):
+    import json
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, name)) as fh:
+        return json.load(fh)
+
+
+def test_backmapping_logic_equals_the_reference_on_its_own_outputs():
+    """Everything downstream of the pairwise alignment -- SequenceBackmapper.align_subsequences and
+    map_to_reference_sequence (sequence_backmapper.py:286-466) -- against 300 cases that the REFERENCE's code produced
+    (tests/golden/make_golden.py:backmap_golden; the alignment is injected on both sides, so Bio.pairwise2's choice
+    among co-optimal alignments is the only part of row f3 that stays unpinned), including the inputs on which the
+    reference raises IndexError."""
+    import types
+    from pydca_amd.sequence_backmapper.sequence_backmapper import SequenceBackmapper as SB
+    cases = _golden_json("backmap_cases.json")
+    assert len(cases) == 300 and sum(1 for c in cases if c["raises"]) >= 1
+    for k, c in enumerate(cases):
+        mid_ref = c["aligned_ref"][c["begin"]:c["end"]]
+        nmid = len(c["aligned_template"][c["begin"]:c["end"]].replace("-", ""))
+        if c["align_subsequences"].startswith("!"):
+            with pytest.raises(IndexError):
+                SB.align_subsequences(ref_middle_subseq=mid_ref, template_subseq_in_msa=c["row"], num_res_middle_template=nmid)
+        else:
+            assert SB.align_subsequences(ref_middle_subseq=mid_ref, template_subseq_in_msa=c["row"],
+                                         num_res_middle_template=nmid) == c["align_subsequences"], k
+        obj = object.__new__(SB)
+        obj._SequenceBackmapper__alignment = [c["row"]]
+        obj._SequenceBackmapper__ref_sequence = c["ref"]
+        obj._SequenceBackmapper__biomolecule = "RNA"
+        aln = [(c["aligned_ref"], c["aligned_template"], 0.0, c["begin"], c["end"])]
+        obj.align_pairs_local = types.MethodType(lambda self, a, b, score_only=False, _aln=aln: _aln, obj)
+        obj.find_matching_seqs_from_alignment = types.MethodType(lambda self, _row=c["row"]: [_row], obj)
+        if c["raises"]:
+            with pytest.raises(IndexError):
+                obj.map_to_reference_sequence()
+        else:
+            got = obj.map_to_reference_sequence()
+            assert sorted([int(a), int(b)] for a, b in got.items()) == c["mapping"], k
+
+
+def test_trimmer_selections_equal_the_reference(monkeypatch):
+    """MSATrimmer's column selections on MSA_RF00167.fa for five max_gap values, both refseq modes and the trimmed
+    records against what the reference's MSATrimmer returned (tests/golden/trimmer_cases.json); the matching row is
+    found here by the product's own Smith-Waterman search and must be the row the fixture was made with."""
+    from pydca_amd.msa_trimmer.msa_trimmer import MSATrimmer
+    from pydca_amd.sequence_backmapper.sequence_backmapper import SequenceBackmapper
+    G = _golden_json("trimmer_cases.json")
+    bm = SequenceBackmapper(msa_file=data_file("MSA_RF00167.fa"), refseq_file=data_file("ref_RF00167.fa"), biomolecule="rna")
+    assert bm.find_matching_seqs_from_alignment()[0].replace(".", "-") == G["matching_row"].replace(".", "-").upper()
+    for c in G["cases"]:
+        tr = MSATrimmer(data_file("MSA_RF00167.fa"), biomolecule="rna", max_gap=c["max_gap"], refseq_file=data_file("ref_RF00167.fa"))
+        assert list(tr.compute_msa_columns_gap_size()[:12]) == c["gap_size_first"]
+        assert list(tr.msa_columns_beyond_max_gap()) == c["beyond"] and list(tr.trim_by_gap_size()) == c["by_gap"]
+        assert list(tr.trim_by_refseq()) == c["by_refseq"]
+        assert list(tr.trim_by_refseq(remove_all_gaps=True)) == c["by_refseq_all"]
+        trimmed = tr.get_msa_trimmed_by_refseq()
+        assert [list(trimmed[0]), list(trimmed[-1])] == c["trimmed_first"] and len(trimmed[0][1]) == c["trimmed_len"]
+
+
 def test_backmapper_with_insertions_and_input_validation():
     from pydca_amd.sequence_backmapper.sequence_backmapper import SequenceBackmapper
     msa = [[1, 2, 3, 5, 4, 1, 2, 5, 3, 4, 1, 1], [2, 2, 3, 5, 4, 1, 3, 5, 3, 4, 2, 1]]      # RNA ints, 5 = gap
