@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdca_hip.so")
+# DCA_LIB_PATH: an alternative build of the SAME library (kernel experiments); never a different backend
+LIB_PATH = os.environ.get("DCA_LIB_PATH") or os.path.join(_HERE, "lib", "libdca_hip.so")
 
 DCA_OK = 0
 DCA_ERR_NOT_SPD = -7

@@ -54,6 +54,9 @@ def units(bank, sset):
         w = S[sset] + sq // 2
         r.append(("s_pack_ll_b32_b16 m0, s%d, 0" if sq % 2 == 0 else "s_lshr_b32 m0, s%d, 16") % w)
         a = ACC + 2 * sq
+        import os
+        if os.environ.get("LG_NOP"):
+            r.append("s_nop %s" % os.environ["LG_NOP"])
         r.append("v_pk_add_f32 v[%d:%d], v[%d:%d], v[%d:%d]" % (a, a + 1, a, a + 1, W[bank], W[bank] + 1))
     r.append("s_set_gpr_idx_off")
     return r

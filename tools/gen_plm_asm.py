@@ -37,6 +37,8 @@ import os
 
 ROWS, ROWBYTES, DEPTH, JW = 128, 512, 8, 2
 STAGE_AT = os.environ.get("DCA_GEN_STAGE_AT", "pre")
+SC_DMA_AUX = os.environ.get("DCA_GEN_SC_DMA_AUX", "")       # cache-policy bits of the scatter / logits LDS-DMA loads (experiments: " nt", " sc1" ...)
+LG_DMA_AUX = os.environ.get("DCA_GEN_LG_DMA_AUX", "")
 S0, T0 = 40, 72
 
 
@@ -103,7 +105,7 @@ def body_smem(q, f64):
                    "s_cbranch_scc0 .Ldca_sc_skip%d_%%=" % qk,
                    "s_add_u32 m0, %%[ldst], %d" % (qk * 1024),
                    "s_nop 0",
-                   "global_load_lds_dwordx4 %[vtmp], %[gbase]",
+                   "global_load_lds_dwordx4 %[vtmp], %[gbase]" + SC_DMA_AUX,
                    "v_add_u32 %[vtmp], %[ginc], %[vtmp]",
                    ".Ldca_sc_skip%d_%%=:" % qk]
             if STAGE_AT == "pre":
@@ -319,7 +321,7 @@ def logits_body(q, f64):
                       "s_cbranch_scc0 .Ldca_lg_skip%d_%%=" % i,
                       "s_mov_b32 m0, s%d" % ld,
                       "s_nop 0",
-                      "global_load_lds_dwordx4 %%[voff], s[%d:%d]" % (gb, gb + 1),
+                      "global_load_lds_dwordx4 %%[voff], s[%d:%d]" % (gb, gb + 1) + LG_DMA_AUX,
                       "s_add_u32 s%d, s%d, %%[ginc]" % (gb, gb),
                       "s_addc_u32 s%d, s%d, 0" % (gb + 1, gb + 1),
                       "s_add_u32 s%d, s%d, %d" % (ld, ld, waves * 1024),

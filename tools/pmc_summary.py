@@ -41,6 +41,8 @@ def main():
             t = {}
         d = {r[0]: r[6] for r in rows}
         t[wl] = {"plm_scatter": d.get("plm_scatter_kernel"), "plm_logits": d.get("plm_logits_kernel")}
+        import os
+        t["measured_at_commit"] = os.environ.get("DCA_COMMIT", "unknown")      # bench.py reports it next to roofline.traffic
         json.dump(t, open(path, "w"), indent=1)
     for r in rows[:8]:
         print("%-28s launches %4d  hbm bytes/launch %.4g" % (r[0], r[1], r[6]))

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Everything profiles/ holds for one round, in one gpurun call (run from the repository root on the GPU box):
-#   bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...
+#   DCA_COMMIT=<git rev-parse --short HEAD> bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...
+# (.git does not travel to the GPU box: the commit the traffic figures belong to comes in through DCA_COMMIT)
 # bench.py first (fresh process, cold box), then the rocprofv3 passes: kernel trace + stats, HBM traffic
 # (FETCH_SIZE / WRITE_SIZE in separate passes), SQ counters in their own passes (no tracing alongside --pmc).
 set -u
