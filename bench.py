@@ -191,12 +191,28 @@ def main():
     # exchange scheme of a multi-GPU run: the library's own RCCL communicator on its stream (default), or the
     # torch.distributed hooks (DCA_BENCH_TORCH_COMM=1; always in the gloo self-test, where RCCL cannot run)
     native = world > 1 and not selftest and os.environ.get("DCA_BENCH_TORCH_COMM") != "1"
-    uid = None
     if world == 1:
         full.compute_weights(0.8, _lib.DCA_F32)
+
+    def native_comm_up(context):
+        """Gives `context` the library's own communicator; every rank must agree that it came up, otherwise all of
+        them fall back to the torch.distributed hooks."""
+        ok = 1
+        try:
+            parallel.init_native_comm(context, _lib, rank, world, dist)
+        except Exception as exc:               # pragma: no cover (needs a multi-GPU node)
+            print("rank %d: native communicator unavailable (%r): torch.distributed hooks instead" % (rank, exc), file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    if native:
+        native = native_comm_up(full)
+    if world == 1:
+        pass
     elif native:
         # every rank counts 1/world of the identity comparisons, ONE all-reduce of the N integer counts (SURVEY 8 e2)
-        uid = parallel.init_native_comm(full, _lib, rank, world, dist)
         full.compute_weights_sharded(0.8, _lib.DCA_F32)
     else:
         part = torch.from_numpy(full.weights_partial_counts(0.8, _lib.DCA_F32, rank, world).astype(np.int64))
@@ -225,7 +241,8 @@ def main():
         small = ctx.num_params() * (4 if args.precision == 32 else 8) < (16 << 20)
         allreduce = os.environ.get("DCA_BENCH_ALLREDUCE") == "1" or (small and os.environ.get("DCA_BENCH_VECTORS") != "1")
         if native:
-            parallel.init_native_comm(ctx, _lib, rank, world, dist)
+            native = native_comm_up(ctx)
+        if native:
             ctx.plm_set_native_comm(1 if allreduce else 2)
         elif allreduce:
             hook = parallel.TorchAllReduceHook(local_rank)
