@@ -522,6 +522,34 @@ def test_sharded_optimiser_vectors_with_thread_comm(oracle_plm, world):
         assert np.array_equal(x_end, out[0][6]) and np.array_equal(scores, out[0][7])
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_exchange_path_with_several_ranks(world):
+    """The product's native exchange path -- RCCL entry points enqueued on the context's stream, in place: all-reduce of
+    g / fx, reduce-scatter + all-gather of the sharded optimiser vectors, the integer all-reduce of the sharded weights,
+    the mfDCA count reduction -- with 2 and 3 ranks (threads) on one GPU.  librccl.so is replaced by the thread-level
+    stand-in tests/fake_rccl (real RCCL refuses two ranks on one device); libdca_hip.so is the product build.  Every
+    rank must follow the unsharded float64 run."""
+    import json
+    import subprocess
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    assert os.path.exists(fake), "build it: python -c 'import __graft_entry__ as g; g.build()'"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "native_comm_threads.py"), str(world)], capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(res["ranks"]) == world
+    for r in res["ranks"]:
+        assert r is not None and "error" not in r, r
+        assert r["weights_equal"]
+        for mode in ("mode1", "mode2"):
+            m = r[mode]
+            assert m["fx_err"] <= 1e-11 and m["g_err"] < 1e-11, m
+            assert m["status"] == res["reference_status"], m
+            assert m["fx_end_err"] <= 1e-9 and m["x_err"] < 1e-7, m
+            assert m["x_sum"] == res["ranks"][0][mode]["x_sum"]           # every rank ends with the same x
+        assert r["mf_err"] < 1e-9
+
+
 @pytest.mark.parametrize("mode", ["vectors", "allreduce"])
 def test_bench_two_process_selftest(mode):
     """bench.py under torch.distributed.run with two ranks on ONE GPU (DCA_BENCH_SELFTEST=1: gloo
