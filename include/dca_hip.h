@@ -123,8 +123,9 @@ int dca_plm_get_g(dca_ctx* ctx, void* g_out, int dtype);
 /* ------------------------------------------------------------------ native collectives (RCCL over xGMI)
  * One process per GPU; every context owns one RCCL communicator whose collectives are enqueued on the context's own
  * stream, in place on the library's buffers: with it an objective evaluation has no host callback and no device
- * synchronisation around its exchange step.  librccl.so is opened with dlopen (rccl_path, else $DCA_RCCL_PATH, else the
- * default search path; pass the copy the process already uses, e.g. torch/lib/librccl.so under PyTorch).
+ * synchronisation around its exchange step.  librccl.so is opened with dlopen: rccl_path if given, else $DCA_RCCL_PATH,
+ * else the librccl that lies next to the libamdhip64 this library is bound to (RCCL must run on the same HIP runtime:
+ * it receives this library's stream and pointers; a process that also holds PyTorch can contain two HIP runtimes).
  *   rank 0:      dca_comm_unique_id(path, id)           128 bytes; hand them to every rank (store, MPI, file ...)
  *   every rank:  dca_comm_init(ctx, path, id, world, rank)   collective: returns when all ranks have called it
  * No reference counterpart (pydca is single-process); the partition is the one BASELINE.json's north_star names. */

@@ -36,10 +36,25 @@ template <typename F> bool bind(F& fn, const char* name)
     return fn != nullptr;
 }
 
+// RCCL must run on the SAME HIP runtime as this library: it receives this library's stream handles and device
+// pointers.  A process can hold two HIP runtimes (PyTorch wheels bundle their own libamdhip64.so next to the system's;
+// which one this library is bound to depends on what was loaded first), so the default is the librccl that lies next to
+// the libamdhip64 this library actually resolved its HIP calls to.
+std::string rccl_next_to_hip(const char* file)
+{
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void*>(&hipStreamSynchronize), &info) || !info.dli_fname) return std::string();
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash == std::string::npos) return std::string();
+    return dir.substr(0, slash + 1) + file;
+}
+
 int load_api(const char* path)
 {
     if (g_api.handle) return DCA_OK;
-    const char* candidates[] = {path, getenv("DCA_RCCL_PATH"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    const std::string near1 = rccl_next_to_hip("librccl.so.1"), near2 = rccl_next_to_hip("librccl.so");
+    const char* candidates[] = {path, getenv("DCA_RCCL_PATH"), near1.c_str(), near2.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
     for (const char* c : candidates) {
         if (!c || !*c) continue;
         g_api.handle = dlopen(c, RTLD_NOW | RTLD_GLOBAL);

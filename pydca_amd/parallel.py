@@ -43,24 +43,13 @@ def shard_with_halo(n_seqs, world, rank, warmup):
     return start - halo, stop, halo
 
 
-def torch_rccl_path():
-    """librccl.so of the running PyTorch (the copy torch.distributed's "nccl" backend has already loaded), so that the
-    library's native collectives and torch share one RCCL; None when torch is absent (the default search path is used)."""
-    try:
-        import os
-        import torch
-        p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        return p if os.path.exists(p) else None
-    except Exception:
-        return None
-
-
 def init_native_comm(ctx, lib_mod, rank, world, dist=None, group=None, rccl_path=None):
     """Give `ctx` its own RCCL communicator (csrc/comm_rccl.cpp): rank 0 makes the unique id, it travels through the
     process group `dist` already has (any backend: it is 128 bytes), every rank joins.  After this the context's
     exchange steps run as RCCL collectives on its own stream -- no Python callback, no device synchronisation:
         ctx.plm_set_native_comm(1 | 2),  ctx.mf_set_native_comm(),  ctx.compute_weights_sharded(seqid)."""
-    path = rccl_path or torch_rccl_path()
+    # rccl_path None: the library picks the librccl that belongs to the HIP runtime it is bound to (comm_rccl.cpp)
+    path = rccl_path
     if world == 1 or dist is None:
         uid = lib_mod.comm_unique_id(path)
     else:

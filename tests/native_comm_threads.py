@@ -86,7 +86,7 @@ def main():
         t.start()
     for t in threads:
         t.join(timeout=240)
-    print(json.dumps({"world": world, "reference_status": [st_ref.status, st_ref.iterations, st_ref.evaluations], "ranks": out}))
+    print(json.dumps({"world": world, "reference_status": [st_ref.status, st_ref.iterations, st_ref.evaluations], "ranks": out}), flush=True)
     os._exit(0)                       # a rank that failed leaves its peers inside a barrier
 
 
