@@ -39,6 +39,8 @@ ROWS, ROWBYTES, DEPTH, JW = 128, 512, 8, 2
 STAGE_AT = os.environ.get("DCA_GEN_STAGE_AT", "pre")
 SC_DMA_AUX = os.environ.get("DCA_GEN_SC_DMA_AUX", "")       # cache-policy bits of the scatter / logits LDS-DMA loads (experiments: " nt", " sc1" ...)
 LG_DMA_AUX = os.environ.get("DCA_GEN_LG_DMA_AUX", "")
+SC_DMA_PLAN = [int(c) for c in os.environ.get("DCA_GEN_SC_DMA_PLAN", "1111")]      # LDS-DMA pieces of the next tile issued per quarter
+assert len(SC_DMA_PLAN) == 4 and sum(SC_DMA_PLAN) == 4
 S0, T0 = 40, 72
 
 
@@ -101,13 +103,17 @@ def body_smem(q, f64):
                 o.append("s_set_gpr_idx_off")
             # this wave's LDS-DMA piece qk of the NEXT tile (4 pieces per wave and tile), issued here rather
             # than all 64 pieces of the workgroup at the tile start: no burst of LDS writes in front of everyone's reads
-            dma = ["s_cmp_lg_u32 %[npc], 0",
-                   "s_cbranch_scc0 .Ldca_sc_skip%d_%%=" % qk,
-                   "s_add_u32 m0, %%[ldst], %d" % (qk * 1024),
-                   "s_nop 0",
-                   "global_load_lds_dwordx4 %[vtmp], %[gbase]" + SC_DMA_AUX,
-                   "v_add_u32 %[vtmp], %[ginc], %[vtmp]",
-                   ".Ldca_sc_skip%d_%%=:" % qk]
+            # SC_DMA_PLAN[qk] pieces are issued at the start of quarter qk (default one per quarter)
+            first = sum(SC_DMA_PLAN[:qk])
+            dma = []
+            for piece in range(first, first + SC_DMA_PLAN[qk]):
+                dma += ["s_cmp_lg_u32 %[npc], 0",
+                        "s_cbranch_scc0 .Ldca_sc_skip%d_%%=" % piece,
+                        "s_add_u32 m0, %%[ldst], %d" % (piece * 1024),
+                        "s_nop 0",
+                        "global_load_lds_dwordx4 %[vtmp], %[gbase]" + SC_DMA_AUX,
+                        "v_add_u32 %[vtmp], %[ginc], %[vtmp]",
+                        ".Ldca_sc_skip%d_%%=:" % piece]
             if STAGE_AT == "pre":
                 o += dma
             o.append("s_waitcnt lgkmcnt(0)")
