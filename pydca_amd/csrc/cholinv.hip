@@ -220,20 +220,31 @@ __device__ __forceinline__ double rcp_refined(double a)
 }
 
 #ifdef DCA_LEAF_TRACE
-__device__ unsigned long long g_leaf_trace[16 * 8];
+__device__ unsigned long long g_leaf_trace[32 * 8];
 #endif
-__global__ __launch_bounds__(256)
+// NB = 64: 16 x 16 threads; NB = 128: 32 x 32 threads (one workgroup of 16 waves) -- the same steps on twice as many
+// block columns.  A 128-leaf replaces two 64-leaves AND the four one-tile products between them (2 x 29 + 4 x 7.5 us
+// of serial launches), which is where the recursion of the inverse spends a quarter of its time.
+template <int NB>
+__global__ __launch_bounds__((NB / 4) * (NB / 4))
 void cholinv_leaf_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info)
 {
-    constexpr int n = 64;
+    constexpr int n = NB;
+    constexpr int TB = NB / 4;           // threads per side = 4-wide block columns
     // all three [m][64]: a thread's four values per m are one 32-byte run and neighbouring threads' runs are 32 bytes
     // apart ([row][4] put the 16 column-side reads of a wave's lanes 128 bytes apart: two banks, 8-way conflicts)
     __shared__ __attribute__((aligned(16))) double panel[2][4][n];    // L(:,k) transposed, rows of block rows > k valid
     __shared__ __attribute__((aligned(16))) double panelx[2][4][n];   // L(:,k) D_k transposed
     __shared__ __attribute__((aligned(16))) double brow[2][4][n];     // block row k of B, columns of block columns <= k valid
-    __shared__ __attribute__((aligned(16))) double dinv[16][16];      // D_k, 4 x 4 row-major (upper part zero)
+    __shared__ __attribute__((aligned(16))) double dinv[TB][16];      // D_k, 4 x 4 row-major (upper part zero)
+    // block column major: the threads of one block column (the panel of a step) are neighbouring lanes of ONE wave,
+    // so the serial panel phase occupies one wave instead of a few lanes in every wave of the workgroup
     const int tid = threadIdx.x;
-    const int ty = tid >> 4, tx = tid & 15;
+#ifndef DCA_LEAF_ROW_MAJOR
+    const int tx = tid / TB, ty = tid % TB;
+#else
+    const int ty = tid / TB, tx = tid % TB;
+#endif
     const int r0 = 4 * ty, c0 = 4 * tx;
 
     double c[4][4];
@@ -251,7 +262,7 @@ void cholinv_leaf_kernel(double* __restrict__ M, int ld, int pivotBase, int* __r
 #else
 #define LEAF_T(slot) do { } while (0)
 #endif
-    for (int kb = 0; kb < 16; ++kb) {
+    for (int kb = 0; kb < TB; ++kb) {
         const int cur = kb & 1;
         LEAF_T(0);
 #ifndef DCA_LEAF_ABLATE
@@ -399,6 +410,164 @@ void cholinv_leaf_kernel(double* __restrict__ M, int ld, int pivotBase, int* __r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same leaf on the f64 matrix cores.  The register-block leaf above spends half of its time in the rank-4 updates
+// (64 FMAs per thread and step on the vector ALU); a rank-4 update of a 16 x 16 tile is exactly ONE
+// v_mfma_f64_16x16x4_f64.  Here the block lives in MFMA accumulator layout (tile (ti, tj), ti >= tj: lane holds column
+// lane & 15, rows (lane >> 4) + 4 r), the lower tiles dealt round-robin to the waves, and a step (4 columns, index kb)
+// is
+//   a. the owners publish the 4 columns of C below and on the diagonal (colbuf) and the 4 rows of B of block row kb
+//      (rowbuf) and restart B(i, kb) = 0 below the diagonal block;
+//   b. one lane factors the 4 x 4 diagonal block: D = inverse of its Cholesky triangle (the serial chain of the leaf);
+//   c. one lane per (m, index): below the block  L(i, kb) = C(i, kb) D^T  -> left[m][i] = right[m][i];  up to the block
+//      X(kb, j) = D B(kb, j) (D itself inside the block) -> right[m][j], left = 0, and X's rows -- final now -- go
+//      straight to memory (lower part + mirrored upper);
+//   d. every tile with rows below the block:  acc -= left^T right   (one MFMA per tile): for columns right of the
+//      block this is the Cholesky update C(i, j) -= L(i, kb) L(j, kb)^T, for the others the forward substitution
+//      B(i, j) -= L(i, kb) X(kb, j); rows up to the block have left = 0 and do not change.
+// Three barriers per step.  Same arithmetic as the register-block leaf up to the order of the FMAs.
+template <int NB>
+__global__ __launch_bounds__(NB == 128 ? 1024 : 256)
+void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info)
+{
+    constexpr int NT = NB / 16;                       // tiles per side
+    constexpr int NTILES = NT * (NT + 1) / 2;         // lower tiles
+    constexpr int WAVES = NB == 128 ? 16 : 4;
+    constexpr int SLOTS = (NTILES + WAVES - 1) / WAVES;
+    __shared__ __attribute__((aligned(16))) double colbuf[4][NB];
+    __shared__ __attribute__((aligned(16))) double rowbuf[4][NB];
+    __shared__ __attribute__((aligned(16))) double leftP[4][NB];
+    __shared__ __attribute__((aligned(16))) double rightP[4][NB];
+    __shared__ __attribute__((aligned(16))) double dinv[16];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, lr = lane >> 4;
+
+    // tile t of the row-major enumeration of the lower triangle -> (ti, tj); slot sl of this wave is tile wave + sl * WAVES
+    int tI[SLOTS], tJ[SLOTS];
+    double4_t acc[SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int t = wave + sl * WAVES;
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        const int tj = t - ti * (ti + 1) / 2;
+        tI[sl] = t < NTILES ? ti : -1;
+        tJ[sl] = tj;
+        acc[sl] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        if (tI[sl] >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + lr + 4 * r, j = 16 * tj + lc;
+                acc[sl][r] = M[(size_t)max(i, j) * ld + min(i, j)];          // diagonal tiles: the full symmetric tile
+            }
+        }
+    }
+
+    for (int kb = 0; kb < NB / 4; ++kb) {
+        const int T = kb >> 2, s = kb & 3, k0 = 4 * kb;
+        // ---- a. publish the step's columns of C and rows of B
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            if (tI[sl] < T) continue;                                           // wave-uniform (also skips empty slots: -1)
+            if (tJ[sl] == T && (lc >> 2) == s) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * tI[sl] + lr + 4 * r;
+                    colbuf[lc & 3][row] = acc[sl][r];
+                    if (row > k0 + 3) acc[sl][r] = 0.0;                         // B(i, kb) starts over as the zero block
+                }
+            }
+            if (tI[sl] == T) {
+                const double v = s == 0 ? acc[sl][0] : s == 1 ? acc[sl][1] : s == 2 ? acc[sl][2] : acc[sl][3];
+                rowbuf[lr][16 * tJ[sl] + lc] = v;                               // rows k0 + lr of B (columns left of the block)
+            }
+        }
+        __syncthreads();
+        // ---- b. the 4 x 4 diagonal block: Cholesky triangle l, D = l^-1
+        if (tid == 0) {
+            double c[4][4], l[4][4], xi[4][4], rs[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) { c[r][cc] = colbuf[min(r, cc)][k0 + max(r, cc)]; l[r][cc] = 0.0; xi[r][cc] = 0.0; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double dk = c[k][k];
+                if (!(dk > 0.0)) atomicCAS(info, 0, pivotBase + k0 + k + 1);
+                const double ik = k < 3 ? rcp_refined(dk) : 0.0;
+                rs[k] = rsqrt_refined(dk);
+                double t[4];
+#pragma unroll
+                for (int r = k + 1; r < 4; ++r) t[r] = c[r][k] * ik;
+#pragma unroll
+                for (int r = k + 1; r < 4; ++r)
+#pragma unroll
+                    for (int cc = k + 1; cc <= r; ++cc) c[r][cc] = __builtin_fma(-t[r], c[cc][k], c[r][cc]);
+                l[k][k] = dk * rs[k];
+#pragma unroll
+                for (int r = k + 1; r < 4; ++r) l[r][k] = c[r][k] * rs[k];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                xi[cc][cc] = rs[cc];
+#pragma unroll
+                for (int r = cc + 1; r < 4; ++r) {
+                    double a2 = 0.0;
+#pragma unroll
+                    for (int m = cc; m < r; ++m) a2 = __builtin_fma(l[r][m], xi[m][cc], a2);
+                    xi[r][cc] = -rs[r] * a2;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) dinv[r * 4 + cc] = xi[r][cc];
+        }
+        __syncthreads();
+        // ---- c. panel below the block, X rows up to it (one lane per (m, index))
+        if (tid < 4 * NB) {
+            const int m = tid / NB, idx = tid % NB;
+            double d[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) d[p] = dinv[m * 4 + p];                // row m of D (lower: d[p] = 0 for p > m)
+            if (idx > k0 + 3) {
+                double v = colbuf[0][idx] * d[0];
+#pragma unroll
+                for (int p = 1; p < 4; ++p) v = __builtin_fma(colbuf[p][idx], d[p], v);     // L(idx, kb)[m] = sum_p C[idx][p] D[m][p]
+                leftP[m][idx] = v;
+                rightP[m][idx] = v;
+            } else {
+                double x;
+                if (idx >= k0) x = d[idx - k0];                                 // X(kb, kb) = D
+                else {
+                    x = d[0] * rowbuf[0][idx];
+#pragma unroll
+                    for (int p = 1; p < 4; ++p) x = __builtin_fma(d[p], rowbuf[p][idx], x); // X(kb, j)[m] = sum_p D[m][p] B[p][j]
+                }
+                leftP[m][idx] = 0.0;
+                rightP[m][idx] = x;
+                const int row = k0 + m;
+                if (idx <= row) {
+                    M[(size_t)row * ld + idx] = x;
+                    if (idx < row) M[(size_t)idx * ld + row] = x;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- d. rank-4 update of every tile that has rows below the block
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            if (tI[sl] < 0 || 16 * tI[sl] + 15 <= k0 + 3) continue;             // wave-uniform
+            const double a = -leftP[lr][16 * tI[sl] + lc];
+            const double b = rightP[lr][16 * tJ[sl] + lc];
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[sl], 0, 0, 0);
+        }
+    }
+}
+
 constexpr size_t kLeafLds = 0;
 
 struct Arena {
@@ -427,11 +596,21 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
 
 int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws, int* dInfo)
 {
+    static const bool leaf128 = !(getenv("DCA_CHOLINV_LEAF128") && atoi(getenv("DCA_CHOLINV_LEAF128")) == 0);
+    static const bool leafMfma = !(getenv("DCA_CHOLINV_LEAF_MFMA") && atoi(getenv("DCA_CHOLINV_LEAF_MFMA")) == 0);
     if (n == 64) {
-        hipLaunchKernelGGL(cholinv_leaf_kernel, dim3(1), dim3(256), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
+        if (leafMfma) hipLaunchKernelGGL(cholinv_leaf_mfma_kernel<64>, dim3(1), dim3(256), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
+        else hipLaunchKernelGGL(cholinv_leaf_kernel<64>, dim3(1), dim3(256), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
         return DCA_OK;
     }
-    const int n1 = (n / 64 / 2) * 64, n2 = n - n1;
+    if (n == 128 && leaf128) {
+        if (leafMfma) hipLaunchKernelGGL(cholinv_leaf_mfma_kernel<128>, dim3(1), dim3(1024), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
+        else hipLaunchKernelGGL(cholinv_leaf_kernel<128>, dim3(1), dim3(1024), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
+        return DCA_OK;
+    }
+    // halves in multiples of 128 where possible, so that the recursion ends in 128-leaves (a 64-leaf only where n is an
+    // odd multiple of 64)
+    const int n1 = (leaf128 && n >= 256) ? (n / 128 / 2) * 128 : (n / 64 / 2) * 64, n2 = n - n1;
     double* M11 = M;
     double* M12 = M + n1;
     double* M21 = M + (size_t)n1 * ld;

@@ -320,7 +320,7 @@ def test_mf_singular_matrix_is_an_error(L_):
     ctx.close()
 
 
-@pytest.mark.parametrize("n", [1, 64, 100, 200, 500])
+@pytest.mark.parametrize("n", [1, 64, 100, 128, 129, 192, 200, 256, 320, 500, 1000])
 def test_spd_inverse_f64_mfma(L_, n):
     """Blocked Cholesky inverse on v_mfma_f64_16x16x4_f64 vs LAPACK; asymmetric-looking
     test matrices (random SPD, no special structure)."""

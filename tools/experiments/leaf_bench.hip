@@ -14,7 +14,10 @@ hipError_t dca_dev_free(void* p) { return hipFree(p); }
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 int main()
 {
-    const int n = 64, ld = 10048, reps = 200;
+#ifndef LEAF_NB
+#define LEAF_NB 64
+#endif
+    const int n = LEAF_NB, ld = 10048, reps = 200;
     std::vector<double> h((size_t)n * ld, 0.0);
     for (int i = 0; i < n; ++i)
         for (int j = 0; j <= i; ++j) h[(size_t)i * ld + j] = (i == j) ? 4.0 + 0.01 * i : 0.3 / (1.0 + i - j);
@@ -28,24 +31,24 @@ int main()
         CHECK(hipEventRecord(e0, st));
         // the inverse of the inverse factor is not SPD input, so alternate between two copies is pointless: re-run on
         // the same (overwritten) block -- timing only, values are whatever they become
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(cholinv_leaf_kernel, dim3(1), dim3(256), 0, st, dA, ld, 0, dInfo);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(cholinv_leaf_kernel<LEAF_NB>, dim3(1), dim3((LEAF_NB / 4) * (LEAF_NB / 4)), 0, st, dA, ld, 0, dInfo);
         CHECK(hipEventRecord(e1, st));
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
-    printf("ablate=%d  %.2f us per leaf (back to back, %d launches)\n", DCA_LEAF_ABLATE, best * 1e3 / reps, reps);
+    printf("NB=%d ablate=%d  %.2f us per leaf (back to back, %d launches)\n", LEAF_NB, DCA_LEAF_ABLATE, best * 1e3 / reps, reps);
 #ifdef DCA_LEAF_TRACE
     // phase stamps of thread DCA_LEAF_TRACE (100 MHz wall clock), last launch: 0 step start, 1 after its phase 1, 2 after
     // barrier A, 3 after its phase 2, 4 after barrier B, 5 after its phase 3
-    unsigned long long tr[16 * 8];
+    unsigned long long tr[32 * 8];
     CHECK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_leaf_trace), sizeof(tr)));
     printf("thread %d: step  phase1  waitA  phase2  waitB  phase3   (ns)\n", DCA_LEAF_TRACE);
-    for (int kb = 0; kb < 16; ++kb) {
+    for (int kb = 0; kb < LEAF_NB / 4; ++kb) {
         const unsigned long long* r = tr + kb * 8;
         printf("   %2d  %6llu %6llu %6llu %6llu %6llu\n", kb, (r[1] - r[0]) * 10, (r[2] - r[1]) * 10, (r[3] - r[2]) * 10, (r[4] - r[3]) * 10, (r[5] - r[4]) * 10);
     }
-    printf("total loop %llu ns\n", (tr[15 * 8 + 5] - tr[0]) * 10);
+    printf("total loop %llu ns\n", (tr[(LEAF_NB / 4 - 1) * 8 + 5] - tr[0]) * 10);
 #endif
     return 0;
 }
