@@ -415,46 +415,92 @@ void cholinv_leaf_kernel(double* __restrict__ M, int ld, int pivotBase, int* __r
 // The same leaf on the f64 matrix cores.  The register-block leaf above spends half of its time in the rank-4 updates
 // (64 FMAs per thread and step on the vector ALU); a rank-4 update of a 16 x 16 tile is exactly ONE
 // v_mfma_f64_16x16x4_f64.  Here the block lives in MFMA accumulator layout (tile (ti, tj), ti >= tj: lane holds column
-// lane & 15, rows (lane >> 4) + 4 r), the lower tiles dealt round-robin to the waves, and a step (4 columns, index kb)
-// is
-//   a. the owners publish the 4 columns of C below and on the diagonal (colbuf) and the 4 rows of B of block row kb
-//      (rowbuf) and restart B(i, kb) = 0 below the diagonal block;
-//   b. one lane factors the 4 x 4 diagonal block: D = inverse of its Cholesky triangle (the serial chain of the leaf);
-//   c. one lane per (m, index): below the block  L(i, kb) = C(i, kb) D^T  -> left[m][i] = right[m][i];  up to the block
-//      X(kb, j) = D B(kb, j) (D itself inside the block) -> right[m][j], left = 0, and X's rows -- final now -- go
-//      straight to memory (lower part + mirrored upper);
-//   d. every tile with rows below the block:  acc -= left^T right   (one MFMA per tile): for columns right of the
+// lane & 15, rows (lane >> 4) + 4 r), the lower tiles dealt round-robin to the WORKER waves 1 .. WAVES-1, and wave 0
+// does nothing but the serial part: the 4 x 4 diagonal blocks.  A step (4 columns, index kb):
+//   a. the owners publish the 4 columns of C on and below the diagonal (colbuf), the 4 rows of B of block row kb
+//      (rowbuf) and the NEXT diagonal block as it stands (nextdiag), and restart B(i, kb) = 0 below the block;
+//   c. [needs D_kb] one lane per (m, index): below the block  L(i, kb) = C(i, kb) D^T  -> left[m][i] = right[m][i];
+//      up to the block  X(kb, j) = D B(kb, j)  (D itself inside the block) -> right[m][j], left = 0, and X's rows --
+//      final now -- go straight to memory (lower part + mirrored upper);
+//   d. every tile with rows below the block:  acc -= left^T right  (one MFMA per tile): for columns right of the
 //      block this is the Cholesky update C(i, j) -= L(i, kb) L(j, kb)^T, for the others the forward substitution
-//      B(i, j) -= L(i, kb) X(kb, j); rows up to the block have left = 0 and do not change.
-// Three barriers per step.  Same arithmetic as the register-block leaf up to the order of the FMAs.
+//      B(i, j) -= L(i, kb) X(kb, j); rows up to the block have left = 0 and do not change;
+//   b. meanwhile wave 0 (look-ahead): the next diagonal block  C(kb+1, kb+1) - L(kb+1, kb) L(kb+1, kb)^T  from
+//      nextdiag and colbuf, its Cholesky triangle and D_{kb+1} = the triangle's inverse -- the dependent chain that
+//      bounds the leaf -- overlapped with d. and with a. of the next step.
+// Two barriers per step.  Same arithmetic as the register-block leaf up to the order of the FMAs.
+__device__ __forceinline__ void factor_diag_block(double (&c)[4][4], double* __restrict__ dinvOut, int* __restrict__ info, int pivot0)
+{
+    double l[4][4], xi[4][4], rs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) { l[r][cc] = 0.0; xi[r][cc] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double dk = c[k][k];
+        if (!(dk > 0.0)) atomicCAS(info, 0, pivot0 + k + 1);
+        const double ik = k < 3 ? rcp_refined(dk) : 0.0;       // on the chain to the next pivot (the last has none)
+        rs[k] = rsqrt_refined(dk);                             // beside it
+        double t[4];
+#pragma unroll
+        for (int r = k + 1; r < 4; ++r) t[r] = c[r][k] * ik;
+#pragma unroll
+        for (int r = k + 1; r < 4; ++r)
+#pragma unroll
+            for (int cc = k + 1; cc <= r; ++cc) c[r][cc] = __builtin_fma(-t[r], c[cc][k], c[r][cc]);
+        l[k][k] = dk * rs[k];
+#pragma unroll
+        for (int r = k + 1; r < 4; ++r) l[r][k] = c[r][k] * rs[k];
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        xi[cc][cc] = rs[cc];
+#pragma unroll
+        for (int r = cc + 1; r < 4; ++r) {
+            double a2 = 0.0;
+#pragma unroll
+            for (int m = cc; m < r; ++m) a2 = __builtin_fma(l[r][m], xi[m][cc], a2);
+            xi[r][cc] = -rs[r] * a2;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) dinvOut[r * 4 + cc] = xi[r][cc];
+}
+
 template <int NB>
-__global__ __launch_bounds__(NB == 128 ? 1024 : 256)
+__global__ __launch_bounds__(NB == 128 ? 512 : 320)
 void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info)
 {
     constexpr int NT = NB / 16;                       // tiles per side
     constexpr int NTILES = NT * (NT + 1) / 2;         // lower tiles
-    constexpr int WAVES = NB == 128 ? 16 : 4;
-    constexpr int SLOTS = (NTILES + WAVES - 1) / WAVES;
-    __shared__ __attribute__((aligned(16))) double colbuf[4][NB];
+    constexpr int WAVES = NB == 128 ? 8 : 5;           // 8 x 64 = 4 NB lanes for step c.; 256 VGPRs for the unrolled 4 x 4 chain
+    constexpr int WORKERS = WAVES - 1;
+    constexpr int SLOTS = (NTILES + WORKERS - 1) / WORKERS;
+    constexpr int STEPS = NB / 4;
+    __shared__ __attribute__((aligned(16))) double colbuf[2][4][NB];
     __shared__ __attribute__((aligned(16))) double rowbuf[4][NB];
     __shared__ __attribute__((aligned(16))) double leftP[4][NB];
     __shared__ __attribute__((aligned(16))) double rightP[4][NB];
-    __shared__ __attribute__((aligned(16))) double dinv[16];
+    __shared__ __attribute__((aligned(16))) double nextdiag[2][16];
+    __shared__ __attribute__((aligned(16))) double dinv[2][16];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 15, lr = lane >> 4;
 
-    // tile t of the row-major enumeration of the lower triangle -> (ti, tj); slot sl of this wave is tile wave + sl * WAVES
+    // tile t of the row-major enumeration of the lower triangle -> (ti, tj); slot sl of worker wave w is tile (w-1) + sl * WORKERS
     int tI[SLOTS], tJ[SLOTS];
     double4_t acc[SLOTS];
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
-        const int t = wave + sl * WAVES;
+        const int t = wave - 1 + sl * WORKERS;
         int ti = 0;
         while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
         const int tj = t - ti * (ti + 1) / 2;
-        tI[sl] = t < NTILES ? ti : -1;
+        tI[sl] = (wave > 0 && t < NTILES) ? ti : -1;
         tJ[sl] = tj;
         acc[sl] = (double4_t){0.0, 0.0, 0.0, 0.0};
         if (tI[sl] >= 0) {
@@ -463,12 +509,23 @@ void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int
                 const int i = 16 * ti + lr + 4 * r, j = 16 * tj + lc;
                 acc[sl][r] = M[(size_t)max(i, j) * ld + min(i, j)];          // diagonal tiles: the full symmetric tile
             }
+            if (ti == 0 && tj == 0 && (lc >> 2) == 0) nextdiag[0][lr * 4 + (lc & 3)] = acc[sl][0];   // block (0, 0)
         }
     }
+    __syncthreads();
+    if (tid == 0) {
+        double c[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) c[r][cc] = nextdiag[0][max(r, cc) * 4 + min(r, cc)];
+        factor_diag_block(c, dinv[0], info, pivotBase);
+    }
 
-    for (int kb = 0; kb < NB / 4; ++kb) {
-        const int T = kb >> 2, s = kb & 3, k0 = 4 * kb;
-        // ---- a. publish the step's columns of C and rows of B
+    for (int kb = 0; kb < STEPS; ++kb) {
+        const int T = kb >> 2, s = kb & 3, k0 = 4 * kb, cur = kb & 1;
+        LEAF_T(0);
+        // ---- a. publish the step's columns of C, the rows of B of block row kb and the next diagonal block
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
             if (tI[sl] < T) continue;                                           // wave-uniform (also skips empty slots: -1)
@@ -476,7 +533,7 @@ void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * tI[sl] + lr + 4 * r;
-                    colbuf[lc & 3][row] = acc[sl][r];
+                    colbuf[cur][lc & 3][row] = acc[sl][r];
                     if (row > k0 + 3) acc[sl][r] = 0.0;                         // B(i, kb) starts over as the zero block
                 }
             }
@@ -484,59 +541,25 @@ void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int
                 const double v = s == 0 ? acc[sl][0] : s == 1 ? acc[sl][1] : s == 2 ? acc[sl][2] : acc[sl][3];
                 rowbuf[lr][16 * tJ[sl] + lc] = v;                               // rows k0 + lr of B (columns left of the block)
             }
-        }
-        __syncthreads();
-        // ---- b. the 4 x 4 diagonal block: Cholesky triangle l, D = l^-1
-        if (tid == 0) {
-            double c[4][4], l[4][4], xi[4][4], rs[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { c[r][cc] = colbuf[min(r, cc)][k0 + max(r, cc)]; l[r][cc] = 0.0; xi[r][cc] = 0.0; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double dk = c[k][k];
-                if (!(dk > 0.0)) atomicCAS(info, 0, pivotBase + k0 + k + 1);
-                const double ik = k < 3 ? rcp_refined(dk) : 0.0;
-                rs[k] = rsqrt_refined(dk);
-                double t[4];
-#pragma unroll
-                for (int r = k + 1; r < 4; ++r) t[r] = c[r][k] * ik;
-#pragma unroll
-                for (int r = k + 1; r < 4; ++r)
-#pragma unroll
-                    for (int cc = k + 1; cc <= r; ++cc) c[r][cc] = __builtin_fma(-t[r], c[cc][k], c[r][cc]);
-                l[k][k] = dk * rs[k];
-#pragma unroll
-                for (int r = k + 1; r < 4; ++r) l[r][k] = c[r][k] * rs[k];
+            const int Tn = (kb + 1) >> 2, sn = (kb + 1) & 3;
+            if (kb + 1 < STEPS && tI[sl] == Tn && tJ[sl] == Tn && (lc >> 2) == sn) {
+                const double v = sn == 0 ? acc[sl][0] : sn == 1 ? acc[sl][1] : sn == 2 ? acc[sl][2] : acc[sl][3];
+                nextdiag[cur][lr * 4 + (lc & 3)] = v;                           // C(kb+1, kb+1) before this step's update
             }
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                xi[cc][cc] = rs[cc];
-#pragma unroll
-                for (int r = cc + 1; r < 4; ++r) {
-                    double a2 = 0.0;
-#pragma unroll
-                    for (int m = cc; m < r; ++m) a2 = __builtin_fma(l[r][m], xi[m][cc], a2);
-                    xi[r][cc] = -rs[r] * a2;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) dinv[r * 4 + cc] = xi[r][cc];
         }
+        LEAF_T(1);
         __syncthreads();
+        LEAF_T(2);
         // ---- c. panel below the block, X rows up to it (one lane per (m, index))
         if (tid < 4 * NB) {
             const int m = tid / NB, idx = tid % NB;
             double d[4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) d[p] = dinv[m * 4 + p];                // row m of D (lower: d[p] = 0 for p > m)
+            for (int p = 0; p < 4; ++p) d[p] = dinv[cur][m * 4 + p];           // row m of D (lower: d[p] = 0 for p > m)
             if (idx > k0 + 3) {
-                double v = colbuf[0][idx] * d[0];
+                double v = colbuf[cur][0][idx] * d[0];
 #pragma unroll
-                for (int p = 1; p < 4; ++p) v = __builtin_fma(colbuf[p][idx], d[p], v);     // L(idx, kb)[m] = sum_p C[idx][p] D[m][p]
+                for (int p = 1; p < 4; ++p) v = __builtin_fma(colbuf[cur][p][idx], d[p], v);   // L(idx, kb)[m] = sum_p C[idx][p] D[m][p]
                 leftP[m][idx] = v;
                 rightP[m][idx] = v;
             } else {
@@ -545,7 +568,7 @@ void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int
                 else {
                     x = d[0] * rowbuf[0][idx];
 #pragma unroll
-                    for (int p = 1; p < 4; ++p) x = __builtin_fma(d[p], rowbuf[p][idx], x); // X(kb, j)[m] = sum_p D[m][p] B[p][j]
+                    for (int p = 1; p < 4; ++p) x = __builtin_fma(d[p], rowbuf[p][idx], x);     // X(kb, j)[m] = sum_p D[m][p] B[p][j]
                 }
                 leftP[m][idx] = 0.0;
                 rightP[m][idx] = x;
@@ -556,8 +579,41 @@ void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int
                 }
             }
         }
+        LEAF_T(3);
         __syncthreads();
-        // ---- d. rank-4 update of every tile that has rows below the block
+        LEAF_T(4);
+        // ---- b. (wave 0, look-ahead) the next diagonal block and its D
+        if (tid == 0 && kb + 1 < STEPS) {
+            double d[4][4], l1[4][4], c[4][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) d[m][p] = dinv[cur][m * 4 + p];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {                                   // L(kb+1, kb)[r][m] = sum_{p <= m} C[r][p] D[m][p]
+                    double v = colbuf[cur][0][k0 + 4 + r] * d[m][0];
+#pragma unroll
+                    for (int p = 1; p < 4; ++p)
+                        if (p <= m) v = __builtin_fma(colbuf[cur][p][k0 + 4 + r], d[m][p], v);
+                    l1[r][m] = v;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc <= r; ++cc) {
+                    double v = nextdiag[cur][r * 4 + cc];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) v = __builtin_fma(-l1[r][m], l1[cc][m], v);
+                    c[r][cc] = v;
+                    c[cc][r] = v;
+                }
+            factor_diag_block(c, dinv[cur ^ 1], info, pivotBase + k0 + 4);
+        }
+        LEAF_T(5);
+        // ---- d. rank-4 update of every tile that has rows below the block.  (Issuing the next step's tiles first, or all
+        // operand fragments before the MFMAs, measured slower: 52 / 49 against 45 us per 128-leaf.)
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
             if (tI[sl] < 0 || 16 * tI[sl] + 15 <= k0 + 3) continue;             // wave-uniform
@@ -565,6 +621,7 @@ void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int
             const double b = rightP[lr][16 * tJ[sl] + lc];
             acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[sl], 0, 0, 0);
         }
+        LEAF_T(6);
     }
 }
 
@@ -599,12 +656,12 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     static const bool leaf128 = !(getenv("DCA_CHOLINV_LEAF128") && atoi(getenv("DCA_CHOLINV_LEAF128")) == 0);
     static const bool leafMfma = !(getenv("DCA_CHOLINV_LEAF_MFMA") && atoi(getenv("DCA_CHOLINV_LEAF_MFMA")) == 0);
     if (n == 64) {
-        if (leafMfma) hipLaunchKernelGGL(cholinv_leaf_mfma_kernel<64>, dim3(1), dim3(256), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
+        if (leafMfma) hipLaunchKernelGGL(cholinv_leaf_mfma_kernel<64>, dim3(1), dim3(320), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
         else hipLaunchKernelGGL(cholinv_leaf_kernel<64>, dim3(1), dim3(256), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
         return DCA_OK;
     }
     if (n == 128 && leaf128) {
-        if (leafMfma) hipLaunchKernelGGL(cholinv_leaf_mfma_kernel<128>, dim3(1), dim3(1024), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
+        if (leafMfma) hipLaunchKernelGGL(cholinv_leaf_mfma_kernel<128>, dim3(1), dim3(512), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
         else hipLaunchKernelGGL(cholinv_leaf_kernel<128>, dim3(1), dim3(1024), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
         return DCA_OK;
     }

@@ -31,7 +31,13 @@ int main()
         CHECK(hipEventRecord(e0, st));
         // the inverse of the inverse factor is not SPD input, so alternate between two copies is pointless: re-run on
         // the same (overwritten) block -- timing only, values are whatever they become
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(cholinv_leaf_kernel<LEAF_NB>, dim3(1), dim3((LEAF_NB / 4) * (LEAF_NB / 4)), 0, st, dA, ld, 0, dInfo);
+        for (int r = 0; r < reps; ++r) 
+#ifdef LEAF_MFMA
+            hipLaunchKernelGGL(cholinv_leaf_mfma_kernel<LEAF_NB>, dim3(1), dim3(LEAF_NB == 128 ? 512 : 320), 0, st, dA, ld, 0, dInfo);
+#else
+            hipLaunchKernelGGL(cholinv_leaf_kernel<LEAF_NB>, dim3(1), dim3((LEAF_NB / 4) * (LEAF_NB / 4)), 0, st, dA, ld, 0, dInfo);
+#endif
+
         CHECK(hipEventRecord(e1, st));
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -43,10 +49,10 @@ int main()
     // barrier A, 3 after its phase 2, 4 after barrier B, 5 after its phase 3
     unsigned long long tr[32 * 8];
     CHECK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_leaf_trace), sizeof(tr)));
-    printf("thread %d: step  phase1  waitA  phase2  waitB  phase3   (ns)\n", DCA_LEAF_TRACE);
+    printf("thread %d: step  phase1  waitA  phase2  waitB  phase3 [mfma leaf: a, B1, c, B2, chain, d]  (ns)\n", DCA_LEAF_TRACE);
     for (int kb = 0; kb < LEAF_NB / 4; ++kb) {
         const unsigned long long* r = tr + kb * 8;
-        printf("   %2d  %6llu %6llu %6llu %6llu %6llu\n", kb, (r[1] - r[0]) * 10, (r[2] - r[1]) * 10, (r[3] - r[2]) * 10, (r[4] - r[3]) * 10, (r[5] - r[4]) * 10);
+        printf("   %2d  %6llu %6llu %6llu %6llu %6llu %6llu\n", kb, (r[1] - r[0]) * 10, (r[2] - r[1]) * 10, (r[3] - r[2]) * 10, (r[4] - r[3]) * 10, (r[5] - r[4]) * 10, (r[6] - r[5]) * 10);
     }
     printf("total loop %llu ns\n", (tr[(LEAF_NB / 4 - 1) * 8 + 5] - tr[0]) * 10);
 #endif
