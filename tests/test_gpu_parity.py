@@ -232,6 +232,26 @@ def test_lbfgs_float32_default_path_scores_close(L_, oracle_plm, oracle_mf):
     ctx.close()
 
 
+@pytest.mark.parametrize("env", [{"DCA_CHOLINV_LEAF_MFMA": "0"}, {"DCA_CHOLINV_LEAF_MFMA": "0", "DCA_CHOLINV_LEAF128": "0"},
+                                 {"DCA_CHOLINV_LEAF128": "0"}])
+def test_spd_inverse_alternative_leaves(env):
+    """The recursion's other leaf kernels (register-block leaf, 64-only recursion; selected by environment variables
+    that the library reads once, hence a subprocess) give the same inverse to 1e-11."""
+    import subprocess
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from pydca_amd import _lib\n"
+        "worst = 0.0\n"
+        "for n in (64, 128, 192, 320, 500):\n"
+        "    rng = np.random.default_rng(n); B = rng.standard_normal((n, n + 8)); A = B @ B.T / n + 0.5 * np.diag(rng.random(n) + 0.5)\n"
+        "    ctx = _lib.Context(0, _lib.DCA_F64); inv = ctx.spd_inverse(A); ctx.close(); ref = np.linalg.inv(A)\n"
+        "    worst = max(worst, float(np.linalg.norm(inv - ref) / np.linalg.norm(ref))); assert np.array_equal(inv, inv.T)\n"
+        "print(worst)\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert float(p.stdout.strip().splitlines()[-1]) < 1e-11
+
+
 def test_scores_kernel(L_, oracle_mf):
     """FN / FN_APC kernel vs plmdca.py:437-524 restated in numpy (float64)."""
     rng = np.random.default_rng(3)
