@@ -7,6 +7,8 @@
 #include "../../pydca_amd/csrc/cholinv.hip"
 void dca_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); }
 void dca_flush_clocks(dca_ctx*) {}
+hipError_t dca_dev_malloc(void** p, size_t b, bool) { return hipMalloc(p, b); }
+hipError_t dca_dev_free(void* p) { return hipFree(p); }
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 __global__ void fill_kernel(double* p, size_t n, unsigned seed)
 {
