@@ -724,6 +724,59 @@ __global__ void vec_diff_kernel(T* __restrict__ s, T* __restrict__ y, const T* _
 struct VecPtrs5 { const void* s[5]; const void* y[5]; };
 struct DirCoefs { double g; double s[5]; double y[5]; };
 
+// Optimiser scalars that live on the device: dot products of the stored pairs and the coefficients of the current
+// search direction in {g, s_k, y_k}.  The two-loop recursion runs here (one thread), so an iteration needs ONE host
+// round trip -- the line search's decision after an evaluation -- instead of two.
+struct LbfgsDev { double SY[5][5]; double YY[5][5]; double ys[5]; DirCoefs cf; };
+constexpr int kSlotDginit = 30;      // dScal slot of g.d for the next line search
+
+// lbfgs.cpp:568-601 on the coefficients; scal[1..2] = y.s, y.y of the newest pair e, scal[3..27] the 25 Gram entries
+// [kind * 5 + k]: s_k.g, y_k.g, s_e.y_k, s_k.y_e, y_e.y_k; gg = g.g of the accepted point (the host has it).
+__global__ void lbfgs_two_loop_kernel(double* __restrict__ scal, LbfgsDev* __restrict__ st, int e, int endNext, int bound, double gg)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    constexpr int M = 5;
+    const double ys = scal[1], yy = scal[2];
+    const double* G5 = scal + 3;
+    double Sg[M], Yg[M], alpha[M];
+    st->ys[e] = ys;
+    for (int k2 = 0; k2 < M; ++k2) {
+        Sg[k2] = G5[k2]; Yg[k2] = G5[5 + k2];
+        st->SY[e][k2] = G5[10 + k2];            // s_e . y_k
+        st->SY[k2][e] = G5[15 + k2];            // s_k . y_e
+        st->YY[e][k2] = G5[20 + k2];
+        st->YY[k2][e] = G5[20 + k2];
+        alpha[k2] = 0.0;
+    }
+    st->SY[e][e] = ys; st->YY[e][e] = yy;
+    DirCoefs cf;
+    cf.g = -1.0;
+    for (int k2 = 0; k2 < M; ++k2) cf.s[k2] = cf.y[k2] = 0.0;
+    int j = endNext;
+    for (int i = 0; i < bound; ++i) {
+        j = (j + M - 1) % M;
+        double sd = cf.g * Sg[j];
+        for (int k2 = 0; k2 < M; ++k2) sd += cf.y[k2] * st->SY[j][k2];   // d has no s components yet
+        alpha[j] = sd / st->ys[j];
+        cf.y[j] -= alpha[j];
+    }
+    const double scale = ys / yy;
+    cf.g *= scale;
+    for (int k2 = 0; k2 < M; ++k2) cf.y[k2] *= scale;
+    for (int i = 0; i < bound; ++i) {
+        double yd = cf.g * Yg[j];
+        for (int k2 = 0; k2 < M; ++k2) yd += cf.s[k2] * st->SY[k2][j] + cf.y[k2] * st->YY[j][k2];
+        const double beta = yd / st->ys[j];
+        cf.s[j] += alpha[j] - beta;
+        j = (j + 1) % M;
+    }
+    st->cf = cf;
+    // g.d for the next line search, from the same coefficients
+    double gd = cf.g * gg;
+    for (int k2 = 0; k2 < M; ++k2) gd += cf.s[k2] * Sg[k2] + cf.y[k2] * Yg[k2];
+    scal[kSlotDginit] = gd;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kVecThreads)
 void vec_gram_kernel(VecPtrs5 P, const T* __restrict__ g, int e, size_t n, double* __restrict__ partials)
@@ -766,8 +819,9 @@ void vec_gram_kernel(VecPtrs5 P, const T* __restrict__ g, int e, size_t n, doubl
 
 // d = c.g * g + sum_k c.s[k] * s_k + c.y[k] * y_k
 template <typename T>
-__global__ void vec_compose_kernel(T* __restrict__ d, const T* __restrict__ g, VecPtrs5 P, DirCoefs c, size_t n)
+__global__ void vec_compose_kernel(T* __restrict__ d, const T* __restrict__ g, VecPtrs5 P, const DirCoefs* __restrict__ cp, size_t n)
 {
+    const DirCoefs c = *cp;
     DCA_VEC_LOOP(n,
         const Pack<T> pg = ldp(g, iv);
         double v[VEC];
@@ -941,6 +995,7 @@ struct PlmEngine : PlmEngineBase {
     T* dS[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     T* dY[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     T *dWt = nullptr, *dSR = nullptr, *dR = nullptr, *dG = nullptr, *dw = nullptr;
+    LbfgsDev* dLb = nullptr;       // optimiser scalars on the device (two-loop recursion)
     uint16_t* dXL = nullptr;
     uint16_t* dXT2 = nullptr;
     int NT = 0;
@@ -960,9 +1015,8 @@ struct PlmEngine : PlmEngineBase {
         bool begun = false, finished = false;
         int status = 0, k = 1, end = 0, iters = 0, evals = 0, max_iterations = 0, verbose = 0;
         double fx = 0, step = 0, xnorm = 0, gnorm = 0, seconds = 0;
-        double ys[5] = {0, 0, 0, 0, 0}, alpha[5] = {0, 0, 0, 0, 0};
-        double SY[5][5] = {}, YY[5][5] = {};   // s_j.y_k and y_j.y_k of the stored pairs
         double dginit = 0;                    // g.d of the current search direction
+        bool dginit_on_device = false;        // ... still in dScal[kSlotDginit]: read with the next evaluation's scalars
     } o;
 
     explicit PlmEngine(dca_ctx* c) : ctx(c), N(c->N), L(c->L), q(c->q), Ls(c->Ls) {}
@@ -976,7 +1030,7 @@ struct PlmEngine : PlmEngineBase {
     {
         dca_dev_free(dx); dca_dev_free(dg); dca_dev_free(dxp); dca_dev_free(dgp); dca_dev_free(dd);
         for (int i = 0; i < 5; ++i) { dca_dev_free(dS[i]); dca_dev_free(dY[i]); }
-        dca_dev_free(dWt); dca_dev_free(dSR); dca_dev_free(dR); dca_dev_free(dG); dca_dev_free(dw); dca_dev_free(dXL); dca_dev_free(dXT2);
+        dca_dev_free(dLb); dLb = nullptr; dca_dev_free(dWt); dca_dev_free(dSR); dca_dev_free(dR); dca_dev_free(dG); dca_dev_free(dw); dca_dev_free(dXL); dca_dev_free(dXT2);
         dca_dev_free(dPairs); dca_dev_free(dFxPart); dca_dev_free(dRegPart); dca_dev_free(dVecPart);
     }
     ~PlmEngine() override { freeall(); }
@@ -1352,8 +1406,9 @@ struct PlmEngine : PlmEngineBase {
         hipLaunchKernelGGL(vec_dot3_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dg + vlo, dd + vlo, dx + vlo, vn, dVecPart);
         hipLaunchKernelGGL(vec_final_kernel, dim3(3), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 3, ctx->dScal + 1);
         DCA_TRY(reduce_scalars(0, 4));     // fx (local data term) and the three partial dot products
-        DCA_TRY(read_scalars(4));
+        DCA_TRY(read_scalars(kSlotDginit + 1));
         *fx = ctx->hScal[0]; *gd = ctx->hScal[1]; *xx = ctx->hScal[2]; *gg = ctx->hScal[3];
+        if (o.dginit_on_device) { o.dginit = ctx->hScal[kSlotDginit]; o.dginit_on_device = false; }
         return DCA_OK;
     }
 
@@ -1372,6 +1427,8 @@ struct PlmEngine : PlmEngineBase {
             HIP_TRY(hipMemsetAsync(dS[i], 0, (P + kVecPad) * sizeof(T), ctx->stream));
             HIP_TRY(hipMemsetAsync(dY[i], 0, (P + kVecPad) * sizeof(T), ctx->stream));
         }
+        if (!dLb) HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dLb), sizeof(LbfgsDev)));
+        HIP_TRY(hipMemsetAsync(dLb, 0, sizeof(LbfgsDev), ctx->stream));
         o = decltype(o)();
         o.max_iterations = max_iterations;
         o.verbose = verbose;
@@ -1399,11 +1456,15 @@ struct PlmEngine : PlmEngineBase {
         const int max_ls = 5;
         int count = 0, uinfo = 0;
         bool brackt = false, stage1 = true;
-        const double dginit = o.dginit;   // g.d, known from the direction's coefficients
+        // g.d of the direction: known on the host, or still on its way from the device's two-loop recursion -- then it
+        // arrives with the scalars of the first evaluation (nothing before that evaluation depends on it)
+        double dginit = o.dginit;
+        bool have_dginit = !o.dginit_on_device;
         *rc_hip = 0;
         if (*stp <= 0.) return LB_INVALIDPARAMETERS;
-        if (0 < dginit) return LB_INCREASEGRADIENT;
-        const double finit = *f, dgtest = ftol * dginit;
+        if (have_dginit && 0 < dginit) return LB_INCREASEGRADIENT;
+        const double finit = *f;
+        double dgtest = ftol * dginit;
         double width = max_step - min_step, prev_width = 2.0 * width;
         LsPoint bx{0., finit, dginit}, by{0., finit, dginit};
         for (;;) {
@@ -1420,6 +1481,13 @@ struct PlmEngine : PlmEngineBase {
             if ((*rc_hip = evaluate_async())) return 0;
             double dg_;
             if ((*rc_hip = eval_scalars(f, &dg_, xx, gg))) return 0;
+            if (!have_dginit) {
+                have_dginit = true;
+                dginit = o.dginit;
+                if (0 < dginit) { o.evals -= 1; return LB_INCREASEGRADIENT; }    // the reference returns before evaluating (lbfgs.cpp:858-861); the caller restores x, g
+                dgtest = ftol * dginit;
+                bx.d = by.d = dginit;
+            }
             const double ftest1 = finit + *stp * dgtest;
             ++count;
             if (brackt && ((*stp <= stmin || stmax <= *stp) || uinfo != 0)) return LB_ROUNDING_ERROR;
@@ -1490,50 +1558,15 @@ struct PlmEngine : PlmEngineBase {
                 hipLaunchKernelGGL(vec_final_kernel, dim3(25), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 25, ctx->dScal + 3);
             }
             DCA_TRY(reduce_scalars(1, 27));
-            DCA_TRY(read_scalars(28));
-            const double ys = ctx->hScal[1], yy = ctx->hScal[2];
-            o.ys[e] = ys;
             const int bound = (M <= o.k) ? M : o.k;
             ++o.k;
             o.end = (o.end + 1) % M;
             {
+                // two-loop recursion on the device (no host round trip), then d = cf.g g + sum cf.s_k s_k + cf.y_k y_k
                 ScopedKernelClock kc(ctx, "lbfgs_vec");
-                const double* G5 = ctx->hScal + 3;       // [kind*5 + k]
-                double Sg[M], Yg[M];
-                for (int k2 = 0; k2 < M; ++k2) {
-                    Sg[k2] = G5[k2]; Yg[k2] = G5[5 + k2];
-                    o.SY[e][k2] = G5[10 + k2];            // s_e . y_k
-                    o.SY[k2][e] = G5[15 + k2];            // s_k . y_e
-                    o.YY[e][k2] = o.YY[k2][e] = G5[20 + k2];
-                }
-                o.SY[e][e] = ys; o.YY[e][e] = yy;
-                // two-loop recursion (lbfgs.cpp:568-601) on the coefficients of d in {g, s_k, y_k}
-                DirCoefs cf;
-                cf.g = -1.0;
-                for (int k2 = 0; k2 < M; ++k2) cf.s[k2] = cf.y[k2] = 0.0;
-                int j = o.end;
-                for (int i = 0; i < bound; ++i) {
-                    j = (j + M - 1) % M;
-                    double sd = cf.g * Sg[j];
-                    for (int k2 = 0; k2 < M; ++k2) sd += cf.y[k2] * o.SY[j][k2];   // d has no s components yet
-                    o.alpha[j] = sd / o.ys[j];
-                    cf.y[j] -= o.alpha[j];
-                }
-                const double scale = ys / yy;
-                cf.g *= scale;
-                for (int k2 = 0; k2 < M; ++k2) cf.y[k2] *= scale;
-                for (int i = 0; i < bound; ++i) {
-                    double yd = cf.g * Yg[j];
-                    for (int k2 = 0; k2 < M; ++k2) yd += cf.s[k2] * o.SY[k2][j] + cf.y[k2] * o.YY[j][k2];
-                    const double beta = yd / o.ys[j];
-                    cf.s[j] += o.alpha[j] - beta;
-                    j = (j + 1) % M;
-                }
-                hipLaunchKernelGGL(vec_compose_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dd + vlo, dg + vlo, ptrs, cf, vn);
-                // g.d for the next line search, from the same coefficients
-                double gd = cf.g * gg;
-                for (int k2 = 0; k2 < M; ++k2) gd += cf.s[k2] * Sg[k2] + cf.y[k2] * Yg[k2];
-                o.dginit = gd;
+                hipLaunchKernelGGL(lbfgs_two_loop_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->dScal, dLb, e, o.end, bound, gg);
+                hipLaunchKernelGGL(vec_compose_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dd + vlo, dg + vlo, ptrs, &dLb->cf, vn);
+                o.dginit_on_device = true;
             }
             o.step = 1.0;
         }
