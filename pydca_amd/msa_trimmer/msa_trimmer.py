@@ -48,7 +48,7 @@ class MSATrimmer:
         self.__refseq_file = refseq_file
         self.__max_gap = 0.5 if max_gap is None else max_gap
         if self.__max_gap > 1.0 or self.__max_gap < 0.0:
-            logger.error('\n\tThe value of max_gap should be between 0 and 1')
+            logger.error('max_gap is a fraction: 0 <= max_gap <= 1')
             raise MSATrimmerException
         self.__biomolecule = biomolecule.strip().upper() if biomolecule is not None else biomolecule
         self.__alignment_data = read_fasta_records(self.__msa_file)

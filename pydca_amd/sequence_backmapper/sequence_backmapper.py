@@ -37,14 +37,14 @@ class SequenceBackmapper:
                     unique_seqs.append(seq)
             self.__alignment = fasta_reader.sequences_to_char_form(unique_seqs, self.__biomolecule)
         else:
-            logger.error('\n\tPlease provide alignment file or a list of alignments')
+            logger.error('SequenceBackmapper needs msa_file or alignment_data')
             raise ValueError
         if refseq_file:
             self.__ref_sequence = self._reference_sequence(refseq_file=refseq_file)
         elif ref_seq:
             self.__ref_sequence = ref_seq.strip().upper()
         else:
-            logger.error('\n\tPlease provide a reference sequence or a FASTA file containing a reference sequence')
+            logger.error('SequenceBackmapper needs ref_seq or refseq_file')
             raise ValueError
         self._validate_refseq()
 
@@ -64,26 +64,27 @@ class SequenceBackmapper:
         standard = [s for s in fasta_reader.RES_TO_INT_ALL[self.__biomolecule].keys() if s not in ('-', '.', '~')]
         for res in self.__ref_sequence:
             if res not in standard:
-                logger.error('\n\tReference sequence should only contain standard residues')
+                logger.error('the reference sequence may hold standard residues only (no gaps, no ambiguity codes)')
                 raise ValueError
         return None
 
     def _reference_sequence(self, refseq_file):
         """sequence_backmapper.py:155-183: first record of the file."""
-        logger.info('\n\tObtaining reference sequence from file:\n\t\t{}'.format(refseq_file))
+        logger.info('
+	reference sequence from {}'.format(refseq_file))
         ref_seqs = fasta_reader.get_alignment_char_form(refseq_file, biomolecule=self.__biomolecule)
         ref_sequence = ref_seqs[0]
         if len(ref_seqs) > 1:
-            logger.warning('\n\tFound multiple reference sequences in file {}.\n\tFirst sequence taken as reference'.format(
-                os.path.basename(refseq_file)))
+            logger.warning('
+	{} holds several sequences; the first one is the reference'.format(os.path.basename(refseq_file)))
         if not ref_sequence:
-            logger.error('\n\tNo reference sequence found')
+            logger.error('the reference sequence file holds no sequence')
             raise ValueError
         return ref_sequence.strip().upper()
 
     def _scoring(self):
         if self.__biomolecule not in scoring_matrix.MATRICES:
-            logger.error('\n\tUnknown biomolecule type. Cannot figure out the scoring matrix.')
+            logger.error('no substitution matrix for biomolecule {}'.format(self.__biomolecule))
             raise ValueError
         return (scoring_matrix.MATRICES[self.__biomolecule],) + scoring_matrix.GAP_PENALTIES[self.__biomolecule]
 
@@ -109,19 +110,19 @@ class SequenceBackmapper:
 
     def find_matching_seqs_from_alignment(self):
         """sequence_backmapper.py:233-283: rows with the highest local score (all of them, MSA order)."""
-        logger.info('\n\tSearching for sequence(s) that match best with the reference sequence')
+        logger.info('\n\tlooking for the alignment row closest to the reference sequence')
         first = self.__alignment[0]
         if first.replace('-', '') == self.__ref_sequence:
-            logger.info('\n\tFirst sequence in alignment (gaps removed) matches reference,'
-                        '\n\tSkipping regorous search for matching sequence')
+            logger.info('
+	the first row, without its gaps, is the reference sequence: no search needed')
             return [first]
         sub, gap_open, gap_extend = self._scoring()
         scores = _lib.sw_scores(self.__ref_sequence, [s.replace('-', '') for s in self.__alignment], sub, gap_open, gap_extend)
         max_score = scores.max()
         best = [self.__alignment[k] for k in range(len(self.__alignment)) if scores[k] == max_score]
         if len(best) > 1:
-            logger.warning('\n\tFound {} sequences in MSA that match the reference'
-                           '\n\tThe first sequence is taken as matching'.format(len(best)))
+            logger.warning('
+	{} rows match the reference equally well; the first one is used'.format(len(best)))
         return best
 
     @staticmethod
