@@ -70,13 +70,11 @@ class SequenceBackmapper:
 
     def _reference_sequence(self, refseq_file):
         """sequence_backmapper.py:155-183: first record of the file."""
-        logger.info('
-	reference sequence from {}'.format(refseq_file))
+        logger.info('reference sequence from {}'.format(refseq_file))
         ref_seqs = fasta_reader.get_alignment_char_form(refseq_file, biomolecule=self.__biomolecule)
         ref_sequence = ref_seqs[0]
         if len(ref_seqs) > 1:
-            logger.warning('
-	{} holds several sequences; the first one is the reference'.format(os.path.basename(refseq_file)))
+            logger.warning('{} holds several sequences; the first one is the reference'.format(os.path.basename(refseq_file)))
         if not ref_sequence:
             logger.error('the reference sequence file holds no sequence')
             raise ValueError
@@ -110,19 +108,17 @@ class SequenceBackmapper:
 
     def find_matching_seqs_from_alignment(self):
         """sequence_backmapper.py:233-283: rows with the highest local score (all of them, MSA order)."""
-        logger.info('\n\tlooking for the alignment row closest to the reference sequence')
+        logger.info('looking for the alignment row closest to the reference sequence')
         first = self.__alignment[0]
         if first.replace('-', '') == self.__ref_sequence:
-            logger.info('
-	the first row, without its gaps, is the reference sequence: no search needed')
+            logger.info('the first row, without its gaps, is the reference sequence: no search needed')
             return [first]
         sub, gap_open, gap_extend = self._scoring()
         scores = _lib.sw_scores(self.__ref_sequence, [s.replace('-', '') for s in self.__alignment], sub, gap_open, gap_extend)
         max_score = scores.max()
         best = [self.__alignment[k] for k in range(len(self.__alignment)) if scores[k] == max_score]
         if len(best) > 1:
-            logger.warning('
-	{} rows match the reference equally well; the first one is used'.format(len(best)))
+            logger.warning('{} rows match the reference equally well; the first one is used'.format(len(best)))
         return best
 
     @staticmethod
