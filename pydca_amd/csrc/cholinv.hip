@@ -46,7 +46,7 @@ struct GemmArgs {
 template <int BK>
 constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BM + BN) * (BK + 1) * sizeof(double); }
 
-template <int BK>
+template <int BK, bool AHEAD2 = false>
 __global__ __launch_bounds__(256)
 void gemm_nt_f64_kernel(GemmArgs g)
 {
@@ -86,6 +86,17 @@ void gemm_nt_f64_kernel(GemmArgs g)
     const double* Bp = g.B + (size_t)(tj * BN + sr) * g.ldb + sp;
     const size_t aStep = (size_t)32 * g.lda, bStep = (size_t)32 * g.ldb;
     double2_t ra[2][PG], rb[2][PG];
+    double2_t ra2[2][PG], rb2[2][PG];      // second register set (AHEAD2: two k-tiles of global loads in flight)
+    auto load_tile_into = [&](double2_t (&xa)[2][PG], double2_t (&xb)[2][PG], int k0) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) {
+                const int kp = k0 + 16 * pg;
+                xa[ps][pg] = *reinterpret_cast<const double2_t*>(Ap + ps * aStep + kp);
+                xb[ps][pg] = *reinterpret_cast<const double2_t*>(Bp + ps * bStep + kp);
+            }
+    };
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps)
@@ -94,6 +105,35 @@ void gemm_nt_f64_kernel(GemmArgs g)
                 const int kp = k0 + 16 * pg;
                 ra[ps][pg] = *reinterpret_cast<const double2_t*>(Ap + ps * aStep + kp);
                 rb[ps][pg] = *reinterpret_cast<const double2_t*>(Bp + ps * bStep + kp);
+            }
+    };
+    auto store_tile_from = [&](double2_t (&ra)[2][PG], double2_t (&rb)[2][PG], int buf, int k0) {
+        const bool diagA = g.maskA != MASK_NONE && k0 + BK > ti * BM && k0 < (ti + 1) * BM;
+        const bool diagB = g.maskB != MASK_NONE && k0 + BK > tj * BN && k0 < (tj + 1) * BN;
+        if (diagA || diagB) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int aRow = ti * BM + sr + 32 * ps, bRow = tj * BN + sr + 32 * ps;
+                const int aLo = g.maskA == MASK_UPPER ? aRow : INT_MIN, aHi = g.maskA == MASK_LOWER ? aRow : INT_MAX;
+                const int bLo = g.maskB == MASK_UPPER ? bRow : INT_MIN, bHi = g.maskB == MASK_LOWER ? bRow : INT_MAX;
+#pragma unroll
+                for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int k = k0 + 16 * pg + sp + u;
+                        ra[ps][pg][u] = (k < aLo || k > aHi) ? 0.0 : ra[ps][pg][u];
+                        rb[ps][pg][u] = (k < bLo || k > bHi) ? 0.0 : rb[ps][pg][u];
+                    }
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) {
+                double* ad = As + buf * BM * LDS_STRIDE + (sr + 32 * ps) * LDS_STRIDE + 16 * pg + sp;
+                double* bd = Bs + buf * BN * LDS_STRIDE + (sr + 32 * ps) * LDS_STRIDE + 16 * pg + sp;
+                ad[0] = ra[ps][pg][0]; ad[1] = ra[ps][pg][1];
+                bd[0] = rb[ps][pg][0]; bd[1] = rb[ps][pg][1];
             }
     };
     auto store_tile = [&](int buf, int k0) {
@@ -129,14 +169,7 @@ void gemm_nt_f64_kernel(GemmArgs g)
     };
 
     const int nk = (kHi - kLo + BK - 1) / BK;
-    if (nk > 0) {
-        load_tile(kLo);
-        store_tile(0, kLo);
-    }
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nk) load_tile(kLo + (t + 1) * BK);
+    auto mma_tile = [&](int buf) {
         const double* as = As + buf * BM * LDS_STRIDE;
         const double* bs = Bs + buf * BN * LDS_STRIDE;
 #pragma unroll
@@ -151,8 +184,37 @@ void gemm_nt_f64_kernel(GemmArgs g)
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (t + 1 < nk) store_tile(buf ^ 1, kLo + (t + 1) * BK);
+    };
+    if constexpr (AHEAD2) {
+        // two k-tiles of global loads in flight (register sets ra/rb and ra2/rb2 alternate): a tile's data has two
+        // MFMA phases to arrive before it is written to LDS
+        if (nk > 0) { load_tile_into(ra, rb, kLo); store_tile_from(ra, rb, 0, kLo); }
+        if (nk > 1) load_tile_into(ra2, rb2, kLo + BK);
         __syncthreads();
+        for (int t = 0; t < nk; t += 2) {
+            if (t + 2 < nk) load_tile_into(ra, rb, kLo + (t + 2) * BK);
+            mma_tile(0);
+            if (t + 1 < nk) store_tile_from(ra2, rb2, 1, kLo + (t + 1) * BK);
+            __syncthreads();
+            if (t + 1 >= nk) break;
+            if (t + 3 < nk) load_tile_into(ra2, rb2, kLo + (t + 3) * BK);
+            mma_tile(1);
+            if (t + 2 < nk) store_tile_from(ra, rb, 0, kLo + (t + 2) * BK);
+            __syncthreads();
+        }
+    } else {
+        if (nk > 0) {
+            load_tile(kLo);
+            store_tile(0, kLo);
+        }
+        __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < nk) load_tile(kLo + (t + 1) * BK);
+            mma_tile(buf);
+            if (t + 1 < nk) store_tile(buf ^ 1, kLo + (t + 1) * BK);
+            __syncthreads();
+        }
     }
 
     // epilogue.  f64 16x16x4 accumulator layout: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -646,7 +708,9 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
         }
         hipLaunchKernelGGL(gemm_nt_f64_kernel<64>, grid, dim3(256), gemm_lds_bytes<64>(), ctx->stream, g);
     } else {
-        hipLaunchKernelGGL(gemm_nt_f64_kernel<16>, grid, dim3(256), gemm_lds_bytes<16>(), ctx->stream, g);
+        static const bool ahead2 = getenv("DCA_GEMM_AHEAD2") && atoi(getenv("DCA_GEMM_AHEAD2")) != 0;
+        if (ahead2) hipLaunchKernelGGL((gemm_nt_f64_kernel<16, true>), grid, dim3(256), gemm_lds_bytes<16>(), ctx->stream, g);
+        else hipLaunchKernelGGL(gemm_nt_f64_kernel<16>, grid, dim3(256), gemm_lds_bytes<16>(), ctx->stream, g);
     }
     return DCA_OK;
 }

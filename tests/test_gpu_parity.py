@@ -185,7 +185,7 @@ def _topL_same(a, b, L):
 
 
 @pytest.mark.parametrize("mode", ["serial", "chunked"])
-@pytest.mark.parametrize("tag,iters", [("toy_rna", 60), ("toy_protein", 30), ("rf71", 40)])
+@pytest.mark.parametrize("tag,iters", [("toy_rna", 60), ("toy_protein", 30), ("rf71", 40), ("rf00167", 25), ("pf02826", 8)])
 def test_lbfgs_float64_matches_oracle_at_equal_iteration_cap(L_, oracle_plm, oracle_mf, tag, iters, mode):
     """P3 of SURVEY 8c4 / north_star: same restated optimiser, same semantics, same cap =>
     FN and FN_APC within 1e-4 relative and identical top-L order (float64), with the strictly serial
