@@ -44,13 +44,14 @@ struct GemmArgs {
 // the recursion that are a handful of tiles on an otherwise empty GPU -- their time is a chain of global
 // round trips, one per k-tile, so a four times deeper tile means four times fewer of them (K = 64: one).
 template <int BK>
-constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BM + BN) * (BK + 1) * sizeof(double); }
+constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BM + BN) * (BK + 2) * sizeof(double); }
 
 template <int BK, bool AHEAD2 = false>
 __global__ __launch_bounds__(256)
 void gemm_nt_f64_kernel(GemmArgs g)
 {
-    constexpr int LDS_STRIDE = BK + 1;   // doubles; odd stride spreads the 16 fragment rows over banks
+    constexpr int LDS_STRIDE = BK + 2;   // doubles; even: rows stay 16-byte aligned, so a lane's two neighbouring k values are ONE
+                                         // ds_read_b128 / ds_write_b128 (operands of two MFMAs; the k order inside a tile is free as long as A and B agree)
     constexpr int PG = BK / 16;          // 16-byte pieces per thread and row: the row's BK/2 pieces over 8 threads
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];
     double* const As = reinterpret_cast<double*>(dca_gemm_smem);      // [2][BM * LDS_STRIDE]
@@ -132,8 +133,8 @@ void gemm_nt_f64_kernel(GemmArgs g)
             for (int pg = 0; pg < PG; ++pg) {
                 double* ad = As + buf * BM * LDS_STRIDE + (sr + 32 * ps) * LDS_STRIDE + 16 * pg + sp;
                 double* bd = Bs + buf * BN * LDS_STRIDE + (sr + 32 * ps) * LDS_STRIDE + 16 * pg + sp;
-                ad[0] = ra[ps][pg][0]; ad[1] = ra[ps][pg][1];
-                bd[0] = rb[ps][pg][0]; bd[1] = rb[ps][pg][1];
+                *reinterpret_cast<double2_t*>(ad) = ra[ps][pg];
+                *reinterpret_cast<double2_t*>(bd) = rb[ps][pg];
             }
     };
     auto store_tile = [&](int buf, int k0) {
@@ -163,8 +164,8 @@ void gemm_nt_f64_kernel(GemmArgs g)
             for (int pg = 0; pg < PG; ++pg) {
                 double* ad = As + buf * BM * LDS_STRIDE + (sr + 32 * ps) * LDS_STRIDE + 16 * pg + sp;
                 double* bd = Bs + buf * BN * LDS_STRIDE + (sr + 32 * ps) * LDS_STRIDE + 16 * pg + sp;
-                ad[0] = ra[ps][pg][0]; ad[1] = ra[ps][pg][1];
-                bd[0] = rb[ps][pg][0]; bd[1] = rb[ps][pg][1];
+                *reinterpret_cast<double2_t*>(ad) = ra[ps][pg];
+                *reinterpret_cast<double2_t*>(bd) = rb[ps][pg];
             }
     };
 
@@ -173,16 +174,20 @@ void gemm_nt_f64_kernel(GemmArgs g)
         const double* as = As + buf * BM * LDS_STRIDE;
         const double* bs = Bs + buf * BN * LDS_STRIDE;
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            const int kcol = kk * 4 + (lane >> 4);
-            const double a0 = as[(wm * 32 + (lane & 15)) * LDS_STRIDE + kcol];
-            const double a1 = as[(wm * 32 + 16 + (lane & 15)) * LDS_STRIDE + kcol];
-            const double b0 = bs[(wn * 32 + (lane & 15)) * LDS_STRIDE + kcol];
-            const double b1 = bs[(wn * 32 + 16 + (lane & 15)) * LDS_STRIDE + kcol];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            // lane group g = lane >> 4 holds k = 8 kk + 2 g, 8 kk + 2 g + 1: the first MFMA sums the even, the second the odd ones
+            const int kcol = kk * 8 + 2 * (lane >> 4);
+            const double2_t a0 = *reinterpret_cast<const double2_t*>(&as[(wm * 32 + (lane & 15)) * LDS_STRIDE + kcol]);
+            const double2_t a1 = *reinterpret_cast<const double2_t*>(&as[(wm * 32 + 16 + (lane & 15)) * LDS_STRIDE + kcol]);
+            const double2_t b0 = *reinterpret_cast<const double2_t*>(&bs[(wn * 32 + (lane & 15)) * LDS_STRIDE + kcol]);
+            const double2_t b1 = *reinterpret_cast<const double2_t*>(&bs[(wn * 32 + 16 + (lane & 15)) * LDS_STRIDE + kcol]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[h], b0[h], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[h], b1[h], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[h], b0[h], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[h], b1[h], acc[1][1], 0, 0, 0);
+            }
         }
     };
     if constexpr (AHEAD2) {
@@ -203,6 +208,9 @@ void gemm_nt_f64_kernel(GemmArgs g)
             __syncthreads();
         }
     } else {
+#ifndef DCA_GEMM_ABLATE
+#define DCA_GEMM_ABLATE 0          // tools/experiments/gemm_bench.hip, timing only: 1 no global loads in the loop, 2 no LDS stores, 4 no barrier
+#endif
         if (nk > 0) {
             load_tile(kLo);
             store_tile(0, kLo);
@@ -210,16 +218,139 @@ void gemm_nt_f64_kernel(GemmArgs g)
         __syncthreads();
         for (int t = 0; t < nk; ++t) {
             const int buf = t & 1;
-            if (t + 1 < nk) load_tile(kLo + (t + 1) * BK);
+            if (t + 1 < nk && !(DCA_GEMM_ABLATE & 1)) load_tile(kLo + (t + 1) * BK);
             mma_tile(buf);
-            if (t + 1 < nk) store_tile(buf ^ 1, kLo + (t + 1) * BK);
-            __syncthreads();
+            if (t + 1 < nk && !(DCA_GEMM_ABLATE & 2)) store_tile(buf ^ 1, kLo + (t + 1) * BK);
+            if (!(DCA_GEMM_ABLATE & 4)) __syncthreads();
         }
     }
 
     // epilogue.  f64 16x16x4 accumulator layout: col = lane & 15, row = (lane >> 4) + 4 * reg
     // (the mirror stores are 8 bytes at stride ldcm; transposing the block through LDS first made no
     // measurable difference to the inverse)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * BM + wm * 32 + m * 16 + (lane >> 4) + 4 * r;
+                const int j = tj * BN + wn * 32 + n * 16 + (lane & 15);
+                if (g.lowerOnly && j > i) continue;
+                double v = g.alpha * acc[m][n][r];
+                double* cp = g.C + (size_t)i * g.ldc + j;
+                if (g.beta != 0.0) v += g.beta * (*cp);
+                *cp = v;
+                if (g.Cm && !(g.lowerOnly && i == j)) g.Cm[(size_t)j * g.ldcm + i] = v;
+            }
+}
+
+// The same product with the operand tiles brought into LDS by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight
+// from global memory into LDS, no staging registers and no ds_write).  In the kernel above a quarter of the matrix-core
+// time is lost around the register -> LDS stores (tools/experiments/gemm_bench.hip -DDCA_GEMM_ABLATE=2: 59.6 -> 66.2 TF
+// without them, 67.7 with MFMAs and fragment reads alone, which is the f64 MFMA rate at the sustained clock).
+// A DMA instruction writes the 64 lanes' 16-byte pieces to CONTIGUOUS LDS (1 KiB), so a tile row is exactly its 16
+// doubles (128 bytes, no padding) and bank conflicts are avoided by a swizzle instead: the piece that lies in 16-byte
+// slot s of row R is k-piece s ^ ((R >> 1) & 7) -- chosen on the global side, where every lane may fetch what it likes.
+// A fragment read (16 rows x 4 lane groups, ds_read_b128) then touches 16 different slots of the 256-byte bank window in
+// each of its four lane groups.  Triangular operands: masked on the fragments of the k-tiles that cross the diagonal.
+__global__ __launch_bounds__(256)
+void gemm_nt_f64_dma_kernel(GemmArgs g)
+{
+    constexpr int BK = 16;
+    constexpr int OPB = BM * BK * (int)sizeof(double);       // bytes of one operand tile (8 KiB)
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];   // [2][A | B]
+    const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int tj = g.walk == WALK_COLUMNS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x;
+    if (g.lowerOnly && tj > ti) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int kLo = 0, kHi = g.K;
+    if (g.maskA == MASK_LOWER) kHi = min(kHi, (ti + 1) * BM);
+    if (g.maskA == MASK_UPPER) kLo = max(kLo, ti * BM);
+    if (g.maskB == MASK_LOWER) kHi = min(kHi, (tj + 1) * BN);
+    if (g.maskB == MASK_UPPER) kLo = max(kLo, tj * BN);
+    kLo = kLo / BK * BK;
+    const int nk = (kHi - kLo + BK - 1) / BK;
+
+    double4_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    // DMA role of the lane: pieces 2 wave and 2 wave + 1 of each operand (piece = 8 tile rows); row-in-piece lane >> 3, slot lane & 7
+    const double* srcA[2];
+    const double* srcB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int R = 8 * (2 * wave + i) + (lane >> 3);
+        const int piece = (lane & 7) ^ ((R >> 1) & 7);
+        srcA[i] = g.A + (size_t)(ti * BM + R) * g.lda + 2 * piece;
+        srcB[i] = g.B + (size_t)(tj * BN + R) * g.ldb + 2 * piece;
+    }
+    auto issue = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * 2 * OPB + (2 * wave + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * 2 * OPB + OPB + (2 * wave + i) * 1024), 16, 0, 0);
+        }
+    };
+    const int fr = lane & 15, fg = lane >> 4, swz = (fr >> 1) & 7;
+    auto mma_tile = [&](int buf, int k0) {
+        const unsigned char* as = dca_gemm_smem + buf * 2 * OPB;
+        const unsigned char* bs = as + OPB;
+        const bool diagA = g.maskA != MASK_NONE && k0 + BK > ti * BM && k0 < (ti + 1) * BM;    // wave-uniform
+        const bool diagB = g.maskB != MASK_NONE && k0 + BK > tj * BN && k0 < (tj + 1) * BN;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const int slot = (4 * kk + fg) ^ swz;             // lane group fg holds k = 8 kk + 2 fg, + 1
+            double2_t a[2], b[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                a[m] = *reinterpret_cast<const double2_t*>(as + (wm * 32 + 16 * m + fr) * 128 + slot * 16);
+                b[m] = *reinterpret_cast<const double2_t*>(bs + (wn * 32 + 16 * m + fr) * 128 + slot * 16);
+            }
+            if (diagA || diagB) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int aRow = ti * BM + wm * 32 + 16 * m + fr, bRow = tj * BN + wn * 32 + 16 * m + fr;
+                    const int aLo = g.maskA == MASK_UPPER ? aRow : INT_MIN, aHi = g.maskA == MASK_LOWER ? aRow : INT_MAX;
+                    const int bLo = g.maskB == MASK_UPPER ? bRow : INT_MIN, bHi = g.maskB == MASK_LOWER ? bRow : INT_MAX;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = k0 + 8 * kk + 2 * fg + h;
+                        a[m][h] = (k < aLo || k > aHi) ? 0.0 : a[m][h];
+                        b[m][h] = (k < bLo || k > bHi) ? 0.0 : b[m][h];
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][h], b[0][h], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][h], b[1][h], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][h], b[0][h], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][h], b[1][h], acc[1][1], 0, 0, 0);
+            }
+        }
+    };
+
+    if (nk > 0) issue(0, kLo);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) issue(buf ^ 1, kLo + (t + 1) * BK);
+        mma_tile(buf, kLo + t * BK);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next tile have landed
+        __syncthreads();                                       // ... everyone's; and the tile just used may be overwritten
+    }
+
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -709,7 +840,9 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
         hipLaunchKernelGGL(gemm_nt_f64_kernel<64>, grid, dim3(256), gemm_lds_bytes<64>(), ctx->stream, g);
     } else {
         static const bool ahead2 = getenv("DCA_GEMM_AHEAD2") && atoi(getenv("DCA_GEMM_AHEAD2")) != 0;
-        if (ahead2) hipLaunchKernelGGL((gemm_nt_f64_kernel<16, true>), grid, dim3(256), gemm_lds_bytes<16>(), ctx->stream, g);
+        static const bool dma = !(getenv("DCA_GEMM_DMA") && atoi(getenv("DCA_GEMM_DMA")) == 0);
+        if (dma) hipLaunchKernelGGL(gemm_nt_f64_dma_kernel, grid, dim3(256), (size_t)4 * BM * 16 * sizeof(double), ctx->stream, g);
+        else if (ahead2) hipLaunchKernelGGL((gemm_nt_f64_kernel<16, true>), grid, dim3(256), gemm_lds_bytes<16>(), ctx->stream, g);
         else hipLaunchKernelGGL(gemm_nt_f64_kernel<16>, grid, dim3(256), gemm_lds_bytes<16>(), ctx->stream, g);
     }
     return DCA_OK;
