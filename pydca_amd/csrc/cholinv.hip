@@ -254,11 +254,14 @@ void gemm_nt_f64_kernel(GemmArgs g)
 // slot s of row R is k-piece s ^ ((R >> 1) & 7) -- chosen on the global side, where every lane may fetch what it likes.
 // A fragment read (16 rows x 4 lane groups, ds_read_b128) then touches 16 different slots of the 256-byte bank window in
 // each of its four lane groups.  Triangular operands: masked on the fragments of the k-tiles that cross the diagonal.
-__global__ __launch_bounds__(256)
+template <int TW>      // MFMA tiles per wave and side: 2 -> 64 x 64 output tile per workgroup, 4 -> 128 x 128 (twice the flop per operand byte)
+__global__ __launch_bounds__(256, TW == 4 ? 2 : 4)
 void gemm_nt_f64_dma_kernel(GemmArgs g)
 {
     constexpr int BK = 16;
-    constexpr int OPB = BM * BK * (int)sizeof(double);       // bytes of one operand tile (8 KiB)
+    constexpr int BM = 32 * TW, BN = 32 * TW;                 // shadow the file-level 64 x 64
+    constexpr int PW = BM / 8 / 4;                            // 1 KiB DMA pieces (8 tile rows) per wave and operand
+    constexpr int OPB = BM * BK * (int)sizeof(double);       // bytes of one operand tile
     typedef double double2_t __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];   // [2][A | B]
     const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
@@ -276,29 +279,31 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
     kLo = kLo / BK * BK;
     const int nk = (kHi - kLo + BK - 1) / BK;
 
-    double4_t acc[2][2];
+    double4_t acc[TW][TW];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < TW; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int n = 0; n < TW; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    // DMA role of the lane: pieces 2 wave and 2 wave + 1 of each operand (piece = 8 tile rows); row-in-piece lane >> 3, slot lane & 7
-    const double* srcA[2];
-    const double* srcB[2];
+    // DMA role of the lane: pieces PW wave .. PW wave + PW - 1 of each operand (piece = 8 tile rows); row-in-piece lane >> 3,
+    // slot lane & 7.  Rows past the end of the operand (M, N multiples of 64, not of 128) are fetched from its last row:
+    // their results are not stored.
+    const double* srcA[PW];
+    const double* srcB[PW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int R = 8 * (2 * wave + i) + (lane >> 3);
+    for (int i = 0; i < PW; ++i) {
+        const int R = 8 * (PW * wave + i) + (lane >> 3);
         const int piece = (lane & 7) ^ ((R >> 1) & 7);
-        srcA[i] = g.A + (size_t)(ti * BM + R) * g.lda + 2 * piece;
-        srcB[i] = g.B + (size_t)(tj * BN + R) * g.ldb + 2 * piece;
+        srcA[i] = g.A + (size_t)min(ti * BM + R, g.M - 1) * g.lda + 2 * piece;
+        srcB[i] = g.B + (size_t)min(tj * BN + R, g.N - 1) * g.ldb + 2 * piece;
     }
     auto issue = [&](int buf, int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PW; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * 2 * OPB + (2 * wave + i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * 2 * OPB + (PW * wave + i) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * 2 * OPB + OPB + (2 * wave + i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * 2 * OPB + OPB + (PW * wave + i) * 1024), 16, 0, 0);
         }
     };
     const int fr = lane & 15, fg = lane >> 4, swz = (fr >> 1) & 7;
@@ -310,33 +315,47 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             const int slot = (4 * kk + fg) ^ swz;             // lane group fg holds k = 8 kk + 2 fg, + 1
-            double2_t a[2], b[2];
+            double2_t a[TW], b[TW];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                a[m] = *reinterpret_cast<const double2_t*>(as + (wm * 32 + 16 * m + fr) * 128 + slot * 16);
-                b[m] = *reinterpret_cast<const double2_t*>(bs + (wn * 32 + 16 * m + fr) * 128 + slot * 16);
+            for (int m = 0; m < TW; ++m) {
+                a[m] = *reinterpret_cast<const double2_t*>(as + (wm * 16 * TW + 16 * m + fr) * 128 + slot * 16);
+                b[m] = *reinterpret_cast<const double2_t*>(bs + (wn * 16 * TW + 16 * m + fr) * 128 + slot * 16);
             }
             if (diagA || diagB) {
+                // only the 16-row fragments whose rows the 8 k values of this slab actually cross need the per-element test
+                // (wave-uniform per fragment): the masking is vector-ALU work in front of the MFMAs
+                const int kmin = k0 + 8 * kk, kmax = kmin + 7;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int aRow = ti * BM + wm * 32 + 16 * m + fr, bRow = tj * BN + wn * 32 + 16 * m + fr;
-                    const int aLo = g.maskA == MASK_UPPER ? aRow : INT_MIN, aHi = g.maskA == MASK_LOWER ? aRow : INT_MAX;
-                    const int bLo = g.maskB == MASK_UPPER ? bRow : INT_MIN, bHi = g.maskB == MASK_LOWER ? bRow : INT_MAX;
+                for (int m = 0; m < TW; ++m) {
+                    const int aBase = ti * BM + wm * 16 * TW + 16 * m, bBase = tj * BN + wn * 16 * TW + 16 * m;
+                    const bool needA = diagA && ((g.maskA == MASK_UPPER && kmin < aBase + 15) || (g.maskA == MASK_LOWER && kmax > aBase));
+                    const bool needB = diagB && ((g.maskB == MASK_UPPER && kmin < bBase + 15) || (g.maskB == MASK_LOWER && kmax > bBase));
+                    if (needA) {
+                        const int aRow = aBase + fr;
+                        const int aLo = g.maskA == MASK_UPPER ? aRow : INT_MIN, aHi = g.maskA == MASK_LOWER ? aRow : INT_MAX;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int k = k0 + 8 * kk + 2 * fg + h;
-                        a[m][h] = (k < aLo || k > aHi) ? 0.0 : a[m][h];
-                        b[m][h] = (k < bLo || k > bHi) ? 0.0 : b[m][h];
+                        for (int h = 0; h < 2; ++h) {
+                            const int k = kmin + 2 * fg + h;
+                            a[m][h] = (k < aLo || k > aHi) ? 0.0 : a[m][h];
+                        }
+                    }
+                    if (needB) {
+                        const int bRow = bBase + fr;
+                        const int bLo = g.maskB == MASK_UPPER ? bRow : INT_MIN, bHi = g.maskB == MASK_LOWER ? bRow : INT_MAX;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int k = kmin + 2 * fg + h;
+                            b[m][h] = (k < bLo || k > bHi) ? 0.0 : b[m][h];
+                        }
                     }
                 }
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][h], b[0][h], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][h], b[1][h], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][h], b[0][h], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][h], b[1][h], acc[1][1], 0, 0, 0);
-            }
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int m = 0; m < TW; ++m)
+#pragma unroll
+                    for (int n = 0; n < TW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][h], b[n][h], acc[m][n], 0, 0, 0);
         }
     };
 
@@ -352,13 +371,14 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
     }
 
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < TW; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < TW; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = ti * BM + wm * 32 + m * 16 + (lane >> 4) + 4 * r;
-                const int j = tj * BN + wn * 32 + n * 16 + (lane & 15);
+                const int i = ti * BM + wm * 16 * TW + m * 16 + (lane >> 4) + 4 * r;
+                const int j = tj * BN + wn * 16 * TW + n * 16 + (lane & 15);
+                if (i >= g.M || j >= g.N) continue;
                 if (g.lowerOnly && j > i) continue;
                 double v = g.alpha * acc[m][n][r];
                 double* cp = g.C + (size_t)i * g.ldc + j;
@@ -841,7 +861,35 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
     } else {
         static const bool ahead2 = getenv("DCA_GEMM_AHEAD2") && atoi(getenv("DCA_GEMM_AHEAD2")) != 0;
         static const bool dma = !(getenv("DCA_GEMM_DMA") && atoi(getenv("DCA_GEMM_DMA")) == 0);
-        if (dma) hipLaunchKernelGGL(gemm_nt_f64_dma_kernel, grid, dim3(256), (size_t)4 * BM * 16 * sizeof(double), ctx->stream, g);
+        static const int dma128 = getenv("DCA_GEMM_DMA128") ? atoi(getenv("DCA_GEMM_DMA128")) : 1;     // 0 never, 1 by the rule below, 2 always
+        if (dma) {
+            // 128 x 128 tiles: 16 instead of 8 flop per operand byte (the 64 x 64 kernel sits at the L2 -> LDS fill limit), but a
+            // quarter of the tiles on half of the slots: taken when the rounds of equal tiles still fill up
+            const long long t64 = g.lowerOnly ? (long long)grid.x * (grid.x + 1) / 2 : (long long)grid.x * grid.y;
+            const int gx = (int)(grid.x + 1) / 2, gy = (int)(grid.y + 1) / 2;
+            const long long t128 = g.lowerOnly ? (long long)gx * (gx + 1) / 2 : (long long)gx * gy;
+            auto fill = [](long long t, long long slots) { return (double)t / (double)(((t + slots - 1) / slots) * slots); };
+            // measured inside the inverse at n = 10 048 (kernel trace, 64 vs 128): SYRK 2.84 -> 2.61 ms, L21 / T^T 2.26 -> 2.19,
+            // X21 2.40 -> 2.29, but X^T X (both operands triangular: the 128-tiles waste work along two diagonals) 6.10 -> 7.05
+            const int masks = (g.maskA != MASK_NONE) + (g.maskB != MASK_NONE);
+            bool use128 = false;
+            if (masks == 0) use128 = t128 >= 512 && fill(t128, 512) * 66.0 > fill(t64, 1024) * 59.0;
+            else if (masks == 1) use128 = t128 >= 1024;
+            if (dma128 == 0) use128 = false;
+            if (dma128 == 2) use128 = true;
+            if (use128) {
+                static bool attr128 = false;
+                if (!attr128) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 16 * 8));
+                    attr128 = true;
+                }
+                dim3 grid128(gx, gy);
+                if (g.walk == WALK_COLUMNS_REVERSED) grid128 = dim3((g.M + 127) / 128, (g.N + 127) / 128);
+                hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<4>, grid128, dim3(256), (size_t)4 * 128 * 16 * sizeof(double), ctx->stream, g);
+            } else {
+                hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<2>, grid, dim3(256), (size_t)4 * 64 * 16 * sizeof(double), ctx->stream, g);
+            }
+        }
         else if (ahead2) hipLaunchKernelGGL((gemm_nt_f64_kernel<16, true>), grid, dim3(256), gemm_lds_bytes<16>(), ctx->stream, g);
         else hipLaunchKernelGGL(gemm_nt_f64_kernel<16>, grid, dim3(256), gemm_lds_bytes<16>(), ctx->stream, g);
     }
