@@ -29,17 +29,19 @@ int main(int argc, char** argv)
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, ctx.stream, B, (size_t)n * n, 2u);
     CHECK(hipStreamSynchronize(ctx.stream));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    struct Case { const char* name; int maskA, maskB, lower; double flops; } cases[] = {
+    double* Cmirror = nullptr;
+    struct Case { const char* name; int maskA, maskB, lower; double flops; int mirror = 0; } cases[] = {
         {"plain NT", MASK_NONE, MASK_NONE, 0, 2.0 * n * (double)n * n},
         {"B lower-triangular (TRSM-like)", MASK_NONE, MASK_LOWER, 0, 1.0 * n * (double)n * n},
         {"SYRK lower tiles", MASK_NONE, MASK_NONE, 1, 1.0 * n * (double)n * n},
         {"X^T X (both upper, lower tiles)", MASK_UPPER, MASK_UPPER, 1, 2.0 / 6.0 * n * (double)n * n * 1.0},
+        {"X^T X + mirrored upper part", MASK_UPPER, MASK_UPPER, 1, 2.0 / 6.0 * n * (double)n * n * 1.0, 1},
     };
     for (auto& c : cases) {
         float best = 1e9;
         for (int rep = 0; rep < 3; ++rep) {
             CHECK(hipEventRecord(e0, ctx.stream));
-            launch_gemm(&ctx, GemmArgs{A, n, c.maskA, B, n, c.maskB, C, n, nullptr, 0, n, n, n, 1.0, 0.0, c.lower});
+            launch_gemm(&ctx, GemmArgs{A, n, c.maskA, B, n, c.maskB, C, n, c.mirror ? C : nullptr, c.mirror ? n : 0, n, n, n, c.mirror ? -1.0 : 1.0, 0.0, c.lower});
             CHECK(hipEventRecord(e1, ctx.stream));
             CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
