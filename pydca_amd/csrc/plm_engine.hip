@@ -122,10 +122,19 @@ __device__ __forceinline__ void logits_store(const LogitsAcc<NSEQ / 8>& acc, uns
     }
 }
 
+// timing experiments only (results are wrong when set): compile with -DDCA_LOGITS_ABLATE=<bits> /
+// -DDCA_SCATTER_ABLATE=<bits> -- 1 no per-tile barrier, 2 / 8 no staging of the next tile, 4 no wait for the landed pieces
+#ifndef DCA_LOGITS_ABLATE
+#define DCA_LOGITS_ABLATE 0
+#endif
+#ifndef DCA_SCATTER_ABLATE
+#define DCA_SCATTER_ABLATE 0
+#endif
+
 template <typename T, int Q>
 __global__ __launch_bounds__(logits_waves(Q) * 64)
 void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL, T* __restrict__ S,
-                       int N, int Npad, int L, int Cs, int numColTiles, int numNBlocks, int ablate)
+                       int N, int Npad, int L, int Cs, int numColTiles, int numNBlocks)
 {
     constexpr int WAVES = logits_waves(Q);
     constexpr int NSEQ = logits_nseq(Q);
@@ -193,14 +202,14 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
     stage(0, 0);
     for (int jt = 0; jt < numJT; ++jt) {
         const int buf = jt & 1;
-        if (!(ablate & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile jt have landed
-        if (!(ablate & 1)) __syncthreads();                 // ... everyone's; and tile jt-1 is no longer read  (ablate: timing experiment only)
-        if (jt + 1 < numJT && !(ablate & 8)) prefetch_states(jt + 1);
+        if (!(DCA_LOGITS_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile jt have landed
+        if (!(DCA_LOGITS_ABLATE & 1)) __syncthreads();                 // ... everyone's; and tile jt-1 is no longer read
+        if (jt + 1 < numJT && !(DCA_LOGITS_ABLATE & 8)) prefetch_states(jt + 1);
         const uint16_t* sp = XL + (size_t)jt * JT * Npad + n0;     // wave-uniform
         const uint32_t vbase = ldsBase + buf * TILE;
         const uint32_t strideBytes = (uint32_t)Npad * 2u;
         // the block also issues this wave's LDS-DMA pieces of tile jt+1 (piece i = wave + i*WAVES), spread over its sites
-        const uint32_t npc = __builtin_amdgcn_readfirstlane((jt + 1 < numJT && !(ablate & 2)) ? (uint32_t)((PIECES - wave + WAVES - 1) / WAVES) : 0u);
+        const uint32_t npc = __builtin_amdgcn_readfirstlane((jt + 1 < numJT && !(DCA_LOGITS_ABLATE & 2)) ? (uint32_t)((PIECES - wave + WAVES - 1) / WAVES) : 0u);
         const unsigned char* gbase = Wbytes + (size_t)((jt + 1) * (JT * Q) + wave * 2) * rowStrideBytes;     // wave-uniform
         const uint32_t ldst = (uint32_t)(uintptr_t)dca_smem + (buf ^ 1) * TILE + wave * 1024;
         if constexpr (Q == 21 && sizeof(T) == 4) DCA_LOGITS_Q21_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
@@ -403,7 +412,7 @@ template <typename T, int Q, int JW>
 __global__ __launch_bounds__(kScatWavesC * 64)
 void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT2,
                         T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int NT, int numColTiles,
-                        int numJG, int chunksPerSplit, size_t slabElems, int ablate)
+                        int numJG, int chunksPerSplit, size_t slabElems)
 {
     constexpr int WAVES = kScatWavesC;
     constexpr int JG = WAVES * JW;                     // sites per workgroup
@@ -449,7 +458,7 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
     auto tile_src = [&](int c) { return Rbytes + (size_t)(halo + c * kNC + wave * DMA_PER_WAVE * 2) * rowStrideBytes; };
     auto stage = [&](int c, int buf) {        // all four pieces at once: only for the first tile
 #pragma unroll
-        for (int i = 0; i < DMA_PER_WAVE && !(ablate & 8); ++i)
+        for (int i = 0; i < DMA_PER_WAVE && !(DCA_SCATTER_ABLATE & 8); ++i)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(tile_src(c) + (size_t)i * ginc + voff),
                 (__attribute__((address_space(3))) void*)(dca_smem + buf * TILE + (wave * DMA_PER_WAVE + i) * 1024), 16, 0, 0);
@@ -460,13 +469,13 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
     for (int c = cBegin; c < cEnd; ++c) {
         const int buf = (c - cBegin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile c have landed
-        if (!(ablate & 1)) __syncthreads();                 // ... everyone's; and tile c-1 is no longer read
+        if (!(DCA_SCATTER_ABLATE & 1)) __syncthreads();                 // ... everyone's; and tile c-1 is no longer read
         const uint32_t vbase = ldsBase + buf * TILE;
         // two sites per wave: the state words come through scalar loads inside the block, which also
         // issues the wave's four LDS-DMA pieces of tile c+1, one per quarter tile
         const uint32_t* sp0 = xs[0] + c * (kNC / 2);
         const uint32_t* sp1 = xs[1] + c * (kNC / 2);
-        const uint32_t npc = __builtin_amdgcn_readfirstlane((c + 1 < cEnd && !(ablate & 8)) ? 1u : 0u);
+        const uint32_t npc = __builtin_amdgcn_readfirstlane((c + 1 < cEnd && !(DCA_SCATTER_ABLATE & 8)) ? 1u : 0u);
         const unsigned char* gbase = tile_src(c + 1);
         const uint32_t ldst = (uint32_t)(uintptr_t)dca_smem + (buf ^ 1) * TILE + wave * DMA_PER_WAVE * 1024;
         uint32_t vtmp;
@@ -1241,8 +1250,7 @@ struct PlmEngine : PlmEngineBase {
             auto kern = plm_logits_kernel<T, Q>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ScopedKernelClock kc(ctx, "plm_logits");
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(logits_waves(Q) * 64), lds, st, dWt, dXL, dSR, N, Npad, L, Cs, numCT, numNB,
-                               getenv("DCA_LOGITS_ABLATE") ? atoi(getenv("DCA_LOGITS_ABLATE")) : 0);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(logits_waves(Q) * 64), lds, st, dWt, dXL, dSR, N, Npad, L, Cs, numCT, numNB);
         }
         {
             dim3 grid(ceil_div(L, 64), ceil_div(numScanChunks, 4));
@@ -1259,12 +1267,11 @@ struct PlmEngine : PlmEngineBase {
             const int numJG = ceil_div(L, kScatWavesC * scatJW);
             const int blocks = kNumXcd * ceil_div(numCT, kNumXcd) * numJG;
             const size_t lds = (size_t)2 * kNC * kRowBytes;
-            const int ablate = getenv("DCA_SCATTER_ABLATE") ? atoi(getenv("DCA_SCATTER_ABLATE")) : 0;
             auto launch = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ScopedKernelClock kc(ctx, "plm_scatter");
                 hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG, N, L, Cs, halo,
-                                   numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs, ablate);
+                                   numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
                 return DCA_OK;
             };
             DCA_TRY(launch(plm_scatter_kernel<T, Q, 2>));
