@@ -24,13 +24,30 @@ void bench_kernel(const float* __restrict__ tile, const uint16_t* __restrict__ s
     __syncthreads();
     const uint32_t vbase = (uint32_t)(uintptr_t)smem + lane * 8;
     const uint16_t* sp = states + ((size_t)blockIdx.x * WAVES + wave) * NBSEQ;
+#ifdef PREFETCH
+    // as in the product kernel: one vector load per wave touches every 64-byte line of the NEXT tile's state words
+    constexpr int LPS = (2 * NBSEQ + 63) / 64 + 1;
+    const int pfSite = min(lane / LPS, JT - 1);
+    const size_t pfOff = (size_t)pfSite * strideBytes + min((lane % LPS) * 64, NBSEQ * 2 - 4);
+    uint32_t sink = 0;
+#endif
     for (int it = 0; it < iters; ++it) {
+#ifdef PREFETCH
+        if (it + 1 < iters)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(sp) + (size_t)JT * strideBytes + pfOff),
+                (__attribute__((address_space(3))) void*)(smem + ROWS * ROWB + wave * 256), 4, 0, 0);
+#endif
         LOGITS_BLOCK(vbase, sp, strideBytes);
 #ifndef STATES_CACHED
         sp += (size_t)JT * strideBytes / 2;
 #endif
     }
+#ifdef PREFETCH
+    out[(size_t)blockIdx.x * WAVES * 64 + tid] = (float)(iters + (sink == 0x12345u));
+#else
     out[(size_t)blockIdx.x * WAVES * 64 + tid] = (float)iters;
+#endif
 }
 int main(int argc, char** argv)
 {
@@ -45,12 +62,12 @@ int main(int argc, char** argv)
     CHECK(hipMalloc(&dT, tile.size() * 4)); CHECK(hipMalloc(&dS, st.size() * 2)); CHECK(hipMalloc(&dO, (size_t)blocks * WAVES * 64 * 4));
     CHECK(hipMemcpy(dT, tile.data(), tile.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dS, st.data(), st.size() * 2, hipMemcpyHostToDevice));
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bench_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS * ROWB));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bench_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS * ROWB + WAVES * 256));
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     float best = 1e9;
     for (int rep = 0; rep < 4; ++rep) {
         CHECK(hipEventRecord(a));
-        hipLaunchKernelGGL(bench_kernel, dim3(blocks), dim3(WAVES * 64), ROWS * ROWB, 0, dT, dS, dO, iters, strideBytes);
+        hipLaunchKernelGGL(bench_kernel, dim3(blocks), dim3(WAVES * 64), ROWS * ROWB + WAVES * 256, 0, dT, dS, dO, iters, strideBytes);
         CHECK(hipEventRecord(b));
         CHECK(hipEventSynchronize(b));
         float ms; CHECK(hipEventElapsedTime(&ms, a, b));

@@ -256,24 +256,40 @@ def logits_jt(q):
     return {21: 6, 5: 25}[q]
 
 
-# (waves per workgroup, sequences per wave) of plm_logits_kernel.  q=21: 12 waves x 56 sequences on
-# 168 VGPRs (3 waves per SIMD) -- per site a wave spends a fixed ~490 clk fetching the q rows and
-# ~15.5 clk per sequence (the M0 write -> indexed add chain), so more sequences per wave amortise
-# the fetch, and 672 instead of 512 sequences per workgroup share one staged tile of W
-# (tools/experiments/gen_logits_variants.py wide: 2.25 -> 2.04 clk per (sequence, site) per CU).
-LOGITS_CFG = {21: (12, 56), 5: (16, 48)}
+# (waves per workgroup, sequences per wave) of plm_logits_kernel.  Per site a wave spends a fixed ~490 clk fetching
+# the q rows and ~15.5 clk per sequence (the M0 write -> indexed add chain), so more sequences per wave amortise the
+# fetch, and more sequences per workgroup share one staged tile of W.  q=21: 8 waves x 96 sequences on 256 VGPRs
+# (2 waves per SIMD).  The 48 state dwords of a site then fit the SGPR budget (s36..s95) only ONCE, so the single set
+# is refilled in place, in thirds, each request >= a third of a site ahead of its use (logits_body); measured in
+# isolation with L2-hot state words (tools/experiments/gen_logits8b.py): 1.66 clk per (sequence, site) per CU against
+# 1.88 for 12 waves x 56 sequences with two ping-pong sets (round 1's shape; 16 x 32: 2.25).
+# q=5: 16 waves x 48 sequences, two sets.
+LOGITS_CFG = {21: (8, 96), 5: (16, 48)}
 LS0 = 36                       # first state-word SGPR
+LOGITS_CHUNK = 16              # dwords per scalar load of the single-set schedule (32 sequences)
+
+
+def logits_single_set(q):
+    return LOGITS_CFG[q][0] == 8
 
 
 def logits_plan(q):
     """-> (waves, nseq, first row register, first accumulator register, words per SGPR set, first temp SGPR)"""
     waves, nseq = LOGITS_CFG[q]
-    vg = 128 if waves == 16 else 168
+    vg = {16: 128, 12: 168, 8: 256}[waves]
     acc0 = vg - 2 * nseq
     nw = (nseq // 2 + 3) // 4 * 4
-    tb = LS0 + 2 * nw
-    assert tb + 7 <= 100 and nseq % 8 == 0
+    tb = LS0 + (1 if logits_single_set(q) else 2) * nw
+    assert tb + 7 <= 96 and nseq % 8 == 0
+    assert not logits_single_set(q) or (nw % LOGITS_CHUNK == 0 and nw // LOGITS_CHUNK >= 2)
     return waves, nseq, acc0 - 2 * q, acc0, nw, tb
+
+
+def logits_chunk_load(q, c):
+    """single-set schedule: scalar load of chunk c (LOGITS_CHUNK dwords) of the site the state pointer is at"""
+    waves, nseq, w0, acc0, nw, tb = logits_plan(q)
+    base = LS0 + c * LOGITS_CHUNK
+    return "s_load_dwordx%d s[%d:%d], s[%d:%d], 0x%x" % (LOGITS_CHUNK, base, base + LOGITS_CHUNK - 1, tb + 2, tb + 3, c * LOGITS_CHUNK * 4)
 
 
 def logits_state_loads(q, sset):
@@ -304,23 +320,33 @@ def logits_stage_sites(q):
 def logits_body(q, f64):
     """One tile.  Besides the adds, the wave issues its share of the LDS-DMA pieces of the next tile, one
     piece at the start of a site (logits_stage_sites) instead of all of them at the start of the tile:
-    a burst of 64 KiB of LDS writes right after the barrier holds up every wave's row reads at once."""
+    a burst of 64 KiB of LDS writes right after the barrier holds up every wave's row reads at once.
+
+    State words.  Two-set plan: the next site's words are requested into the other set right after this site's
+    `s_waitcnt`, a whole site ahead.  Single-set plan (the words are consumed in order, chunk by chunk): after the
+    wait at the start of a site -- chunks 0 .. m-2 of this site have landed -- the LAST chunk of this site is requested
+    (its registers were in use until the end of the previous site); a second wait in front of the last chunk's first use
+    finds nothing else outstanding, and behind it chunks 0 .. m-2 of the NEXT site are requested into their by then
+    free registers.  Every request is at least a chunk's worth of adds (plus the row fetch) ahead of the wait that
+    covers it."""
     waves, nseq, w0, acc0, nw, tb = logits_plan(q)
     jt = logits_jt(q)
+    single = logits_single_set(q)
+    nchunks = nw // LOGITS_CHUNK
     add = "v_add_f64" if f64 else "v_pk_add_f32"
     gb, ld = tb + 4, tb + 6
     stage_at = logits_stage_sites(q)
+    advance = ["s_add_u32 s%d, s%d, %%[stride]" % (tb + 2, tb + 2), "s_addc_u32 s%d, s%d, 0" % (tb + 3, tb + 3)]
     o = ["s_mov_b32 s%d, m0" % (tb + 1),
          "s_mov_b64 s[%d:%d], %%[sptr]" % (tb + 2, tb + 3),
          "s_mov_b64 s[%d:%d], %%[gbase]" % (gb, gb + 1),
          "s_mov_b32 s%d, %%[ldst]" % ld,
          "s_mov_b32 s%d, 0" % tb]
-    o += logits_state_loads(q, 0)
+    o += [logits_chunk_load(q, c) for c in range(nchunks - 1)] if single else logits_state_loads(q, 0)
     for jj in range(jt):
-        cur = LS0 + (jj % 2) * nw
-        if jj + 1 < jt:
-            o.append("s_add_u32 s%d, s%d, %%[stride]" % (tb + 2, tb + 2))
-            o.append("s_addc_u32 s%d, s%d, 0" % (tb + 3, tb + 3))
+        cur = LS0 if single else LS0 + (jj % 2) * nw
+        if jj + 1 < jt and not single:
+            o += advance
         for i, at in enumerate(stage_at):
             if at == jj:
                 o += ["s_cmp_gt_u32 %%[npc], %d" % i,
@@ -335,10 +361,16 @@ def logits_body(q, f64):
         for b in range(q):
             o.append("ds_read_b64 v[%d:%d], %%[vbase] offset:%d" % (w0 + 2 * b, w0 + 2 * b + 1, (jj * q + b) * ROWBYTES))
         o.append("s_waitcnt lgkmcnt(0)")
-        if jj + 1 < jt:
+        if single:
+            o.append(logits_chunk_load(q, nchunks - 1))
+        elif jj + 1 < jt:
             o += logits_state_loads(q, (jj + 1) % 2)
         o.append("s_set_gpr_idx_on s%d, 0x2" % tb)
         for sq in range(nseq):
+            if single and sq == (nchunks - 1) * LOGITS_CHUNK * 2:
+                o.append("s_waitcnt lgkmcnt(0)")
+                if jj + 1 < jt:
+                    o += advance + [logits_chunk_load(q, c) for c in range(nchunks - 1)]
             w = cur + sq // 2
             if sq % 2 == 0:
                 o.append("s_pack_ll_b32_b16 m0, s%d, 0" % w)
