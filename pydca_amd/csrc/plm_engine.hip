@@ -145,13 +145,22 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
     constexpr int DMA_PER_WAVE = (PIECES + WAVES - 1) / WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
 
-    // XCD-aware decode: all sequence blocks of one column strip run on one XCD so that
-    // its slice of W is served by that XCD's L2.
+    // XCD-aware decode: all sequence blocks of one column strip run on one XCD (workgroup id % 8) so that its slice
+    // of W is served by that XCD's L2 -- for the strips that come in full sets of eight.  The sequence blocks of the
+    // numColTiles % 8 strips left over go round ALL XCDs (one strip at a time): handing those strips to XCDs 0 .. r-1
+    // whole left the other XCDs idle for a round (D: 83 strips, 23 rounds on three XCDs against 21 on five).
     const int id = blockIdx.x;
-    const int xcd = id % kNumXcd, k = id / kNumXcd;
-    const int ct = (k / numNBlocks) * kNumXcd + xcd;
-    const int nb = k % numNBlocks;
-    if (ct >= numColTiles) return;
+    const int fullCT = (numColTiles / kNumXcd) * kNumXcd;
+    int ct, nb;
+    if (id < fullCT * numNBlocks) {
+        const int xcd = id % kNumXcd, k = id / kNumXcd;
+        ct = (k / numNBlocks) * kNumXcd + xcd;
+        nb = k % numNBlocks;
+    } else {
+        const int r = id - fullCT * numNBlocks;
+        ct = fullCT + r / numNBlocks;
+        nb = r % numNBlocks;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -411,7 +420,7 @@ __device__ __forceinline__ void scatter_store_site(const SiteAcc<Q>& acc, unsign
 template <typename T, int Q, int JW>
 __global__ __launch_bounds__(kScatWavesC * 64)
 void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT2,
-                        T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int NT, int numColTiles,
+                        T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int NT, int ctBase, int numPairs, int splitX,
                         int numJG, int chunksPerSplit, size_t slabElems)
 {
     constexpr int WAVES = kScatWavesC;
@@ -423,13 +432,17 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
     static_assert(JW == 2 && (Q == 21 || Q == 5), "no generated gather block for this shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
 
-    // workgroup id -> (XCD, column strip, site group): the numJG site groups of a strip run on the
-    // same XCD (id % 8) so that their reads of the strip can meet in that XCD's L2
+    // workgroup id -> (XCD, (column strip, tile-range split) pair, site group): the numJG site groups of a pair run on
+    // the same XCD (id % 8) so that their reads of the strip can meet in that XCD's L2.  The main launch has one pair
+    // per strip and the splits in blockIdx.y; the launch for the strips left over after the full sets of eight
+    // (launch_eval) carries a finer split in the pair index (splitX) so that it fills all XCDs for a fraction of a round.
     const int id = blockIdx.x;
     const int xcd = id % kNumXcd, k = id / kNumXcd;
-    const int ct = (k / numJG) * kNumXcd + xcd;
+    const int pr = (k / numJG) * kNumXcd + xcd;
     const int jg = k % numJG;
-    if (ct >= numColTiles) return;
+    if (pr >= numPairs) return;
+    const int ct = ctBase + pr / splitX;
+    const int split = blockIdx.y + pr % splitX;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -438,7 +451,7 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
 
     // blockIdx.y splits the tile range; every split writes its own slab of G (summed by
     // the fold kernels in a fixed order), so small L*q shapes still fill the chip.
-    const int cBegin = blockIdx.y * chunksPerSplit;
+    const int cBegin = split * chunksPerSplit;
     const int cEnd = min(numChunks, cBegin + chunksPerSplit);
 
     SiteAcc<Q> acc[JW];
@@ -489,7 +502,7 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
             DCA_GATHER_Q5_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
     }
 
-    T* const Gslab = G + (size_t)blockIdx.y * slabElems;
+    T* const Gslab = G + (size_t)split * slabElems;
 #pragma unroll
     for (int jj = 0; jj < JW; ++jj)
         if (j0 + jj < L)
@@ -507,6 +520,20 @@ __global__ void plm_sum_slabs_kernel(T* __restrict__ G, size_t slabElems, int ns
         for (int sidx = 1; sidx < nsplit; ++sidx) a += G[(size_t)sidx * slabElems + i];
         G[i] = a;
     }
+}
+
+// The same for a column range whose slab count differs from the rest (the left-over strips of the scatter kernel):
+// slab 0 receives the sum of slabs 0 .. nsplit-1, slabs 1 .. nzero-1 are cleared so that later sums over them add nothing.
+template <typename T>
+__global__ void plm_sum_slabs_cols_kernel(T* __restrict__ G, size_t slabElems, int Cs, int col0, int ncols, int rows, int nsplit, int nzero)
+{
+    const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * ncols) return;
+    const size_t off = (idx / ncols) * (size_t)Cs + col0 + idx % ncols;
+    T a = G[off];
+    for (int sidx = 1; sidx < nsplit; ++sidx) a += G[(size_t)sidx * slabElems + off];
+    G[off] = a;
+    for (int sidx = 1; sidx < nzero; ++sidx) G[(size_t)sidx * slabElems + off] = (T)0;
 }
 
 // ------------------------------------------------------------------ fold
@@ -999,6 +1026,7 @@ struct PlmEngine : PlmEngineBase {
     int numScanChunks = 0, numScatChunks = 0;
     static constexpr int kScatWaves = 16;
     int scatSplit = 1, scatChunksPerSplit = 0, scatJW = 2;
+    int scatRemCT = 0, scatRemSplit = 0, scatRemChunksPerSplit = 0;     // left-over strips (numCT % 8) in their own, finer split launch
 
     T *dx = nullptr, *dg = nullptr, *dxp = nullptr, *dgp = nullptr, *dd = nullptr;
     T* dS[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1108,8 +1136,28 @@ struct PlmEngine : PlmEngineBase {
             if (const char* e = getenv("DCA_SCATTER_SPLIT")) scatSplit = std::max(1, std::min(numScatChunks, atoi(e)));   // tuning knob
             scatChunksPerSplit = ceil_div(numScatChunks, scatSplit);
             scatSplit = ceil_div(numScatChunks, scatChunksPerSplit);
+            // Strips are dealt to the XCDs in sets of eight (plm_scatter_kernel), so numCT % 8 left-over strips keep
+            // that many XCDs busy for a whole extra round while the others idle (D: 83 strips = 11 rounds on three XCDs,
+            // 10 on five).  They get their own launch with a finer split that spreads them over all XCDs for a fraction of
+            // a round; taken when the round model says it saves >= 2 %.
+            scatRemCT = scatRemSplit = scatRemChunksPerSplit = 0;
+            const int numCT = ceil_div(Cs, cw), numJGs = ceil_div(L, JG);
+            const int fullCT = numCT / kNumXcd * kNumXcd, rem = numCT - fullCT;
+            const char* remEnv = getenv("DCA_SCATTER_REM");        // tuning / test knob: 0 never, 1 whenever there are left-over strips
+            if (fullCT > 0 && rem > 0 && !(remEnv && atoi(remEnv) == 0)) {
+                const int cuPerXcd = 256 / kNumXcd;
+                auto rounds = [&](long long wgsPerXcd) { return (double)((wgsPerXcd + cuPerXcd - 1) / cuPerXcd); };
+                const double now = rounds((long long)ceil_div(numCT, kNumXcd) * numJGs * scatSplit) * (scatChunksPerSplit + 2.0);
+                int sB = std::max(scatSplit, 256 / (rem * numJGs));
+                sB = std::max(1, std::min(sB, std::max(1, numScatChunks / 12)));
+                const int cpsB = ceil_div(numScatChunks, sB);
+                sB = ceil_div(numScatChunks, cpsB);
+                const double with = rounds((long long)(fullCT / kNumXcd) * numJGs * scatSplit) * (scatChunksPerSplit + 2.0) +
+                                    rounds((long long)ceil_div(rem * sB, kNumXcd) * numJGs) * (cpsB + 2.0);
+                if (with < 0.98 * now || (remEnv && atoi(remEnv) == 1)) { scatRemCT = rem; scatRemSplit = sB; scatRemChunksPerSplit = cpsB; }
+            }
         }
-        DCA_TRY(dalloc(&dG, (size_t)scatSplit * Grows * Cs));
+        DCA_TRY(dalloc(&dG, (size_t)std::max(scatSplit, scatRemSplit) * Grows * Cs));
         DCA_TRY(dalloc(&dw, N));
         DCA_TRY(dalloc(&dXL, (size_t)ceil_div(L, JT) * JT * Npad));
         NT = numScatChunks * kNC;
@@ -1126,7 +1174,7 @@ struct PlmEngine : PlmEngineBase {
         HIP_TRY(hipMemsetAsync(dg, 0, (P + kVecPad) * sizeof(T), ctx->stream));
         vlo = 0; vn = P; Ppad = P; comm = nullptr; comm_user = nullptr;
         HIP_TRY(hipMemsetAsync(dWt, 0, (size_t)Wrows * Cs * sizeof(T), ctx->stream));
-        HIP_TRY(hipMemsetAsync(dG, 0, (size_t)scatSplit * Grows * Cs * sizeof(T), ctx->stream));
+        HIP_TRY(hipMemsetAsync(dG, 0, (size_t)std::max(scatSplit, scatRemSplit) * Grows * Cs * sizeof(T), ctx->stream));
 
         std::vector<PairIJ> hp(npairs);
         {
@@ -1245,7 +1293,7 @@ struct PlmEngine : PlmEngineBase {
             constexpr int CW = 512 / (int)sizeof(T);
             const int numCT = ceil_div(Cs, CW);
             const int numNB = Npad / logits_seq_per_wg(q);
-            const int blocks = kNumXcd * ceil_div(numCT, kNumXcd) * numNB;
+            const int blocks = numCT * numNB;
             const size_t lds = (size_t)2 * 128 * 512 + (size_t)logits_waves(Q) * 256;   // two tiles + prefetch scratch
             auto kern = plm_logits_kernel<T, Q>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1265,13 +1313,21 @@ struct PlmEngine : PlmEngineBase {
             constexpr int CW = kRowBytes / (int)sizeof(T);
             const int numCT = ceil_div(Cs, CW);
             const int numJG = ceil_div(L, kScatWavesC * scatJW);
-            const int blocks = kNumXcd * ceil_div(numCT, kNumXcd) * numJG;
+            const int mainCT = numCT - scatRemCT;            // strips of the main launch (all of them without a left-over launch)
             const size_t lds = (size_t)2 * kNC * kRowBytes;
             auto launch = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ScopedKernelClock kc(ctx, "plm_scatter");
-                hipLaunchKernelGGL(kern, dim3(blocks, scatSplit), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG, N, L, Cs, halo,
-                                   numScatChunks, NT, numCT, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
+                hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(mainCT, kNumXcd) * numJG, scatSplit), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG,
+                                   N, L, Cs, halo, numScatChunks, NT, 0, mainCT, 1, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
+                if (scatRemCT) {
+                    const int pairs = scatRemCT * scatRemSplit;
+                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(pairs, kNumXcd) * numJG, 1), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG,
+                                       N, L, Cs, halo, numScatChunks, NT, mainCT, pairs, scatRemSplit, numJG, scatRemChunksPerSplit, (size_t)Grows * Cs);
+                    const int col0 = mainCT * CW, ncols = Cs - col0;
+                    hipLaunchKernelGGL(plm_sum_slabs_cols_kernel<T>, dim3((unsigned)(((size_t)Lq * ncols + 255) / 256)), dim3(256), 0, st, dG,
+                                       (size_t)Grows * Cs, Cs, col0, ncols, Lq, scatRemSplit, scatSplit);
+                }
                 return DCA_OK;
             };
             DCA_TRY(launch(plm_scatter_kernel<T, Q, 2>));

@@ -72,6 +72,30 @@ def test_config_C_weights_and_fixed_x_vs_oracle(L_, oracle_plm, msa_C):
         ctx.close()
 
 
+def test_config_C_left_over_strips_launch(L_, oracle_plm, msa_C, monkeypatch):
+    """The scatter kernel's separate, finer-split launch for the numCT % 8 column strips left over after the full sets
+    of eight (config C: 33 strips in float32, 66 in float64): forced on (DCA_SCATTER_REM=1) it must give the gradient
+    of the single-launch path (=0) up to the summation order of the slabs, and both must match the oracle."""
+    X, q = msa_C, Q_C
+    for prec, wtype, tol_g, tol_modes in ((L_.DCA_F32, np.float32, 1e-5, 2e-6), (L_.DCA_F64, np.float64, 1e-10, 1e-13)):
+        w = oracle_plm.weights(X, 0.8, wtype)
+        x = perturbed(oracle_plm.init_x(X, w, q), L_C, q)
+        fx_o, g_o = oracle_plm.gradient(X, w.astype(np.float64), q, LAMBDA_H, LAMBDA_J, x.astype(np.float64), carry=True)
+        got = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("DCA_SCATTER_REM", mode)
+            ctx = _ctx(L_, X, q, prec, prec)
+            ctx.plm_configure(LAMBDA_H, LAMBDA_J)
+            ctx.plm_set_x(x)
+            fx = ctx.plm_gradient()
+            got[mode] = (fx, ctx.plm_get_g(np.float64))
+            ctx.close()
+            assert rel_err(got[mode][1], g_o) < tol_g, (prec, mode, rel_err(got[mode][1], g_o))
+        assert got["0"][0] == got["1"][0]
+        assert rel_err(got["1"][1], got["0"][1]) < tol_modes, (prec, rel_err(got["1"][1], got["0"][1]))
+        assert not np.array_equal(got["1"][1], got["0"][1]) or prec == L_.DCA_F64      # the forced path really ran (float32: other slab order)
+
+
 def test_config_C_lbfgs_P3_chunked_float64(L_, oracle_plm, oracle_mf, msa_C):
     """P3 at config C (BASELINE.json: "DI/FN score tolerance 1e-4"): 10 L-BFGS iterations, float64, the chunked
     scan the product ships, against oracle.plm.lbfgs with the same cap => same status / iterations / evaluations,
