@@ -74,9 +74,10 @@ __global__ void plm_expand_kernel(const T* __restrict__ x, T* __restrict__ W, co
 // (sequence, site) pair costs one SALU write of M0 and one packed add; the NS running sums are
 // fixed registers.  No per-lane LDS addresses, hence no bank conflicts and no row permutation.
 // Inner block: generated assembly (tools/gen_plm_asm.py -> logits_gather_asm.inc), accumulator and
-// row registers pinned.  Workgroup shape per q (generator LOGITS_CFG): q=21 runs 12 waves x 56
-// sequences on 168 VGPRs (672 sequences share one staged tile; the fixed per-site cost of fetching
-// the q rows is spread over 56 instead of 32 adds), q=5 runs 16 waves x 32 sequences on 128.
+// row registers pinned.  Workgroup shape per q (generator LOGITS_CFG): q=21 runs 8 waves x 96
+// sequences on 256 VGPRs (768 sequences share one staged tile; the fixed per-site cost of fetching
+// the q rows is spread over 96 adds; the site's 48 state dwords live in ONE SGPR set refilled in
+// place, in thirds, see the generator), q=5 runs 16 waves x 48 sequences on 128.
 typedef float dca_v32f __attribute__((ext_vector_type(32)));
 typedef float dca_v16f __attribute__((ext_vector_type(16)));
 typedef float dca_v8f __attribute__((ext_vector_type(8)));

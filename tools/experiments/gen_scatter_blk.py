@@ -7,6 +7,9 @@ usage: gen_scatter_blk.py JW BLK > scatter_variant.inc      (scatter_bench.hip -
 import sys
 Q, ROWS, ROWBYTES = 21, 128, 512
 JW, BLK = int(sys.argv[1]), int(sys.argv[2])
+DMA = len(sys.argv) > 3 and sys.argv[3] == "dma"
+WAVES = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+PPW = 64 // WAVES                     # 1 KiB LDS-DMA pieces per wave and tile
 VG = {2: 128, 3: 168}.get(JW, 256)
 acc = [VG - 2 * Q * (JW - jj) for jj in range(JW)]
 d0 = acc[0] - 4 * BLK                 # two ring halves of BLK register pairs
@@ -45,6 +48,8 @@ o += sloads(sets[0], 0) + dsreads(0)
 o.append(".Ltile_%=:")
 assert NB % 2 == 0
 for b in range(NB):
+    if DMA and b % (NB // PPW) == 0:
+        o += ["s_mov_b32 m0, %d" % (65536 + (b // (NB // PPW)) * 1024), "s_nop 0", "global_load_lds_dwordx4 %[voff], %[gsrc]"]
     o.append("s_waitcnt lgkmcnt(0)")
     if b + 1 < NB:
         o += sloads(sets[(b + 1) % 2], b + 1)
@@ -66,11 +71,11 @@ o.append("s_mov_b32 m0, vcc_lo")
 o.append("v_mov_b32 %%[res], v%d" % acc[0])
 print("#define SC_JW %d" % JW)
 print("#define SC_VGPRS %d" % VG)
-print("#define SCATTER_BLOCK(VBASE, SP, ITERS, RES) asm volatile( \\")
+print("#define SCATTER_BLOCK(VBASE, SP, ITERS, RES%s) asm volatile( \\" % (", VOFF, GSRC" if DMA else ""))
 for ln in o:
     print('    "%s\\n" \\' % ln)
 print('    : [res] "=v"(RES), [iters] "+s"(ITERS) \\')
-print('    : [vbase] "v"(VBASE), [sp] "s"(SP) \\')
+print('    : [vbase] "v"(VBASE), [sp] "s"(SP)%s \\' % (', [voff] "v"(VOFF), [gsrc] "s"(GSRC)' if DMA else ""))
 clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(d0, VG)] + ['"s%d"' % i for i in range(SA, SB + SETW)] + ['"s100"', '"s101"']
 print("    : %s)" % ", ".join(clob))
 print("#define SC_STREAM_WORDS_PER_TILE %d" % (NB * JW * GW))

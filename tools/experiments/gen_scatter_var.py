@@ -6,6 +6,7 @@ import sys
 Q, ROWS, ROWBYTES = 21, 128, 512
 JW, GROUP, DEPTH = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 SKIPLAST = len(sys.argv) > 4 and sys.argv[4] == "skiplast"
+DMA = sys.argv[-1] == "dma"          # one 1 KiB LDS-DMA piece per group start (product: 16 waves x 4 quarters = 64 KiB per tile)
 VG = {2: 128, 3: 168}.get(JW, 256)
 acc = [VG - 2 * Q * (JW - jj) for jj in range(JW)]
 d0 = acc[0] - 2 * DEPTH
@@ -48,6 +49,8 @@ for r in range(ROWS):
         g = r // GROUP
         if r:
             o.append("s_set_gpr_idx_off")
+        if DMA:
+            o += ["s_mov_b32 m0, %d" % (65536 + g * 1024), "s_nop 0", "global_load_lds_dwordx4 %[voff], %[gsrc]"]
         o.append("s_waitcnt lgkmcnt(0)")
         if g + 1 < NG:
             o += sloads(sets[(g + 1) % 2], g + 1)
@@ -78,11 +81,11 @@ o.append("s_mov_b32 m0, vcc_lo")
 o.append("v_mov_b32 %%[res], v%d" % acc[0])
 print("#define SC_JW %d" % JW)
 print("#define SC_VGPRS %d" % VG)
-print("#define SCATTER_BLOCK(VBASE, SP, ITERS, RES) asm volatile( \\")
+print("#define SCATTER_BLOCK(VBASE, SP, ITERS, RES%s) asm volatile( \\" % (", VOFF, GSRC" if DMA else ""))
 for ln in o:
     print('    "%s\\n" \\' % ln)
 print('    : [res] "=v"(RES), [iters] "+s"(ITERS) \\')
-print('    : [vbase] "v"(VBASE), [sp] "s"(SP) \\')
+print('    : [vbase] "v"(VBASE), [sp] "s"(SP)%s \\' % (', [voff] "v"(VOFF), [gsrc] "s"(GSRC)' if DMA else ""))
 clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(d0, VG)] + ['"s%d"' % i for i in range(SA, SB + SETW)] + ['"s100"', '"s101"']
 print("    : %s)" % ", ".join(clob))
 print("#define SC_STREAM_WORDS_PER_TILE %d" % (NG * JW * GW))

@@ -26,7 +26,12 @@ void bench_kernel(const float* __restrict__ tile, const uint32_t* __restrict__ s
 #endif
     float res;
     int it = iters;
+#ifdef WITH_DMA      // the product's staging traffic: every wave copies its share of 64 KiB per tile into a second LDS buffer
+    const uint32_t voff = lane * 16;
+    SCATTER_BLOCK(vbase, sp, it, res, voff, tile);
+#else
     SCATTER_BLOCK(vbase, sp, it, res);
+#endif
     out[(size_t)blockIdx.x * WAVES * 64 + tid] = res;
 }
 int main(int argc, char** argv)
@@ -40,12 +45,12 @@ int main(int argc, char** argv)
     CHECK(hipMalloc(&dT, tile.size() * 4)); CHECK(hipMalloc(&dS, st.size() * 4)); CHECK(hipMalloc(&dO, (size_t)blocks * WAVES * 64 * 4));
     CHECK(hipMemcpy(dT, tile.data(), tile.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dS, st.data(), st.size() * 4, hipMemcpyHostToDevice));
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bench_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bench_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     float best = 1e9;
     for (int rep = 0; rep < 4; ++rep) {
         CHECK(hipEventRecord(a));
-        hipLaunchKernelGGL(bench_kernel, dim3(blocks), dim3(WAVES * 64), 100 * 1024, 0, dT, dS, dO, iters);
+        hipLaunchKernelGGL(bench_kernel, dim3(blocks), dim3(WAVES * 64), 132 * 1024, 0, dT, dS, dO, iters);
         CHECK(hipEventRecord(b));
         CHECK(hipEventSynchronize(b));
         float ms; CHECK(hipEventElapsedTime(&ms, a, b));
