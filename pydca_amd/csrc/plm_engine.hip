@@ -1120,42 +1120,46 @@ struct PlmEngine : PlmEngineBase {
         DCA_TRY(dalloc(&dR, (size_t)(N + kNC) * Cs));           // R = w (p - delta); + kNC zero rows: the scatter kernel's last tile reads past row N-1
         HIP_TRY(hipMemsetAsync(dR, 0, (size_t)(N + kNC) * Cs * sizeof(T), ctx->stream));    // pad columns and halo rows stay zero
         {
-            // Split of the tile range over blockIdx.y.  Aim at ~2048 workgroups (8 rounds of one workgroup
-            // per CU) but keep >= 12 tiles per workgroup (prologue + epilogue cost about two tiles), then
-            // take the split within 25 % below that which wastes least in the last, partly filled round:
-            // rounds x (tiles per workgroup + 2).  Measured optima (tools/time_eval.py, DCA_SCATTER_SPLIT):
-            // D 2, D/8 2, C 5-6, E 64-68.
+            // Split of the tile range (every split writes its own slab of G) and the left-over launch.  Strips are dealt to
+            // the XCDs in sets of eight (plm_scatter_kernel), the numJG site groups of a strip and split run side by side on
+            // one XCD's 32 CUs, and a workgroup costs its tiles + about two for prologue and epilogue.  numCT % 8 left-over
+            // strips keep that many XCDs busy for whole extra rounds while the others idle (D: 83 strips = 11 rounds on
+            // three XCDs, 10 on five), so they may get their own launch with a finer split that spreads them over all XCDs
+            // for a fraction of a round.  Every extra slab costs the fold one more pass over G (about `slabUnits` tile
+            // times).  Model: cost = rounds x (tiles per workgroup + 2) [+ the same for the left-over launch] + slabs;
+            // candidates up to ~2048 workgroups with >= 12 tiles each.  Measured (tools/time_eval.py, DCA_SCATTER_SPLIT /
+            // DCA_SCATTER_REM; scatter + fold, ms): D 1 + left-over 7.28 (split 2 without: 7.74), D/8 1.19 (1.34),
+            // C 0.376 (0.458 for the best split without a left-over launch), E split 19-32: 0.90 (51: 0.93).
             const int cw = kRowBytes / (int)sizeof(T);
-            const int wgs = ceil_div(Cs, cw) * ceil_div(L, JG);
-            const int s0 = std::max(1, std::min({numScatChunks, ceil_div(2048, wgs), std::max(1, numScatChunks / 12)}));
-            double bestCost = 1e300;
-            scatSplit = s0;
-            for (int sp = std::max(1, s0 * 3 / 4); sp <= s0; ++sp) {
-                const double cost = std::ceil((double)wgs * sp / 256.0) * (ceil_div(numScatChunks, sp) + 2.0);
-                if (cost <= bestCost) { bestCost = cost; scatSplit = sp; }
-            }
-            if (const char* e = getenv("DCA_SCATTER_SPLIT")) scatSplit = std::max(1, std::min(numScatChunks, atoi(e)));   // tuning knob
-            scatChunksPerSplit = ceil_div(numScatChunks, scatSplit);
-            scatSplit = ceil_div(numScatChunks, scatChunksPerSplit);
-            // Strips are dealt to the XCDs in sets of eight (plm_scatter_kernel), so numCT % 8 left-over strips keep
-            // that many XCDs busy for a whole extra round while the others idle (D: 83 strips = 11 rounds on three XCDs,
-            // 10 on five).  They get their own launch with a finer split that spreads them over all XCDs for a fraction of
-            // a round; taken when the round model says it saves >= 2 %.
-            scatRemCT = scatRemSplit = scatRemChunksPerSplit = 0;
             const int numCT = ceil_div(Cs, cw), numJGs = ceil_div(L, JG);
             const int fullCT = numCT / kNumXcd * kNumXcd, rem = numCT - fullCT;
+            const int s0 = std::max(1, std::min({numScatChunks, ceil_div(2048, numCT * numJGs), std::max(1, numScatChunks / 12)}));
+            const int cuPerXcd = 256 / kNumXcd;
+            auto rounds = [&](long long wgsPerXcd) { return (double)((wgsPerXcd + cuPerXcd - 1) / cuPerXcd); };
+            const double slabUnits = (double)Grows * Cs * sizeof(T) / 4e12 / 4e-6;      // one pass over a slab at ~4 TB/s, in 4 us tile times
             const char* remEnv = getenv("DCA_SCATTER_REM");        // tuning / test knob: 0 never, 1 whenever there are left-over strips
-            if (fullCT > 0 && rem > 0 && !(remEnv && atoi(remEnv) == 0)) {
-                const int cuPerXcd = 256 / kNumXcd;
-                auto rounds = [&](long long wgsPerXcd) { return (double)((wgsPerXcd + cuPerXcd - 1) / cuPerXcd); };
-                const double now = rounds((long long)ceil_div(numCT, kNumXcd) * numJGs * scatSplit) * (scatChunksPerSplit + 2.0);
-                int sB = std::max(scatSplit, 256 / (rem * numJGs));
-                sB = std::max(1, std::min(sB, std::max(1, numScatChunks / 12)));
-                const int cpsB = ceil_div(numScatChunks, sB);
-                sB = ceil_div(numScatChunks, cpsB);
-                const double with = rounds((long long)(fullCT / kNumXcd) * numJGs * scatSplit) * (scatChunksPerSplit + 2.0) +
-                                    rounds((long long)ceil_div(rem * sB, kNumXcd) * numJGs) * (cpsB + 2.0);
-                if (with < 0.98 * now || (remEnv && atoi(remEnv) == 1)) { scatRemCT = rem; scatRemSplit = sB; scatRemChunksPerSplit = cpsB; }
+            const char* splitEnv = getenv("DCA_SCATTER_SPLIT");    // tuning knob: the split of the main launch
+            double bestCost = 1e300;
+            scatSplit = 1; scatChunksPerSplit = numScatChunks; scatRemCT = scatRemSplit = scatRemChunksPerSplit = 0;
+            for (int sp = 1; sp <= (splitEnv ? numScatChunks : s0); ++sp) {
+                if (splitEnv && sp != std::max(1, std::min(numScatChunks, atoi(splitEnv)))) continue;
+                const int cps = ceil_div(numScatChunks, sp);
+                if (ceil_div(numScatChunks, cps) != sp && !splitEnv) continue;               // same as a smaller split
+                const int spEff = ceil_div(numScatChunks, cps);
+                const double slabs = (spEff - 1) * slabUnits;
+                if (!(remEnv && atoi(remEnv) == 1 && fullCT > 0 && rem > 0)) {
+                    const double cost = rounds((long long)ceil_div(numCT, kNumXcd) * numJGs * spEff) * (cps + 2.0) + slabs;
+                    if (cost < bestCost) { bestCost = cost; scatSplit = spEff; scatChunksPerSplit = cps; scatRemCT = scatRemSplit = scatRemChunksPerSplit = 0; }
+                }
+                if (fullCT > 0 && rem > 0 && !(remEnv && atoi(remEnv) == 0)) {
+                    int sB = std::max(spEff, 256 / (rem * numJGs));
+                    sB = std::max(1, std::min(sB, std::max(1, numScatChunks / 12)));
+                    const int cpsB = ceil_div(numScatChunks, sB);
+                    sB = ceil_div(numScatChunks, cpsB);
+                    const double cost = rounds((long long)(fullCT / kNumXcd) * numJGs * spEff) * (cps + 2.0) +
+                                        rounds((long long)ceil_div(rem * sB, kNumXcd) * numJGs) * (cpsB + 2.0) + slabs + 3.0;   // + two more launches
+                    if (cost < bestCost) { bestCost = cost; scatSplit = spEff; scatChunksPerSplit = cps; scatRemCT = rem; scatRemSplit = sB; scatRemChunksPerSplit = cpsB; }
+                }
             }
         }
         DCA_TRY(dalloc(&dG, (size_t)std::max(scatSplit, scatRemSplit) * Grows * Cs));

@@ -454,6 +454,44 @@ def _reader_child(path, bio, L, q):
     return rows
 
 
+def config_c_golden():
+    """config_C_reference.npz: the compiled reference itself at BASELINE.json's config C (tools/gen_msa.py seed 12345,
+    L=200 N=10k q=21, lambda_h=1 lambda_J=50) at the initial point and at the perturbed point of the goldens' recipe:
+    fx, every 997th gradient element, ||g||, and the reference's OWN float32 error against the float64 oracle (1 and 8
+    threads) -- the yardstick for the float32 device path, whose accumulation chains are as long as the reference's."""
+    from tools.gen_msa import SEEDS, dedup, generate
+    L, N, q, lh, lJ = 200, 10000, 21, 1.0, 50.0
+    X = dedup(generate(L, N, q, SEEDS["C"]))
+    letters = "ACDEFGHIKLMNPQRSTVWY-"
+    tmp = tempfile.mkdtemp(prefix="pydca_c_")
+    try:
+        path = os.path.join(tmp, "c.fa")
+        with open(path, "w") as fh:
+            for i, row in enumerate(X):
+                fh.write(">s%d\n%s\n" % (i, "".join(letters[v] for v in row)))
+        w = oplm.weights(X, 0.8, np.float32)
+        x0 = oplm.init_x(X, w, q)
+        out = {"stride": 997, "n_unique": X.shape[0]}
+        for name, x in (("x0", x0), ("x1", perturbed(x0, L, q))):
+            fx_o, g_o = oplm.gradient(X, w.astype(np.float64), q, lh, lJ, x.astype(np.float64), carry=True)
+            errs = []
+            for thr in (1, 8):
+                ref = oplm.Reference(path, 1, L, q, 0.8, lh, lJ, threads=thr)
+                assert np.array_equal(ref.seqs(), X) and np.array_equal(ref.weights(), w)
+                if name == "x0":
+                    np.testing.assert_allclose(ref.init_x(), x0, rtol=2e-6, atol=2e-6)
+                fx_r, g_r = ref.gradient(x.astype(np.float32))
+                ref.close()
+                errs.append(float(np.linalg.norm(g_r.astype(np.float64) - g_o) / np.linalg.norm(g_o)))
+                if thr == 1:
+                    out.update({name + "_fx": np.float32(fx_r), name + "_g_sub": g_r[::997].copy(), name + "_gnorm": np.float64(np.linalg.norm(g_r.astype(np.float64)))})
+            out[name + "_ref_err_vs_f64"] = np.array(errs)
+            print("config C %s: reference float32 vs float64 oracle rel. error %.3e (1 thread) %.3e (8 threads), fx %.9g" % (name, errs[0], errs[1], out[name + "_fx"]))
+        np.savez_compressed(os.path.join(HERE, "config_C_reference.npz"), **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-slow", action="store_true")
@@ -462,7 +500,12 @@ def main():
     ap.add_argument("--only-backmap", action="store_true", help="regenerate only backmap_cases.json / trimmer_cases.json")
     ap.add_argument("--only-params", action="store_true", help="regenerate only params_*.npz")
     ap.add_argument("--only-di", action="store_true", help="regenerate only di_*.npz (needs plm_*.npz present)")
+    ap.add_argument("--only-config-c", action="store_true", help="regenerate only config_C_reference.npz")
     args = ap.parse_args()
+    if args.only_config_c:
+        oplm.build(ref=True)
+        config_c_golden()
+        return
     if args.only_reader:
         oplm.build(ref=True)
         reader_golden()
@@ -536,6 +579,8 @@ def main():
     if not args.skip_slow:
         plm_golden("pf02826", pf, 1, 195, 21, 0.8, 1.0, 50.0, subsample=9973)
     runs_golden()
+    if not args.skip_slow:
+        config_c_golden()
 
     # ---- mfDCA via the stubbed import of the reference ---------------------------
     tmp = tempfile.mkdtemp(prefix="pydca_stubs_")

@@ -48,9 +48,15 @@ def _top(a, L):
 
 
 def test_config_C_weights_and_fixed_x_vs_oracle(L_, oracle_plm, msa_C):
-    """Config C, fixed x (initial point and the perturbed point of the goldens' recipe): float32 kernels <= 1e-5,
-    float64 kernels <= 1e-10 against oracle.plm.gradient (reference semantics, carry-over on); weights bit-exact."""
+    """Config C, fixed x (initial point and the perturbed point of the goldens' recipe): float64 kernels <= 1e-10 against
+    oracle.plm.gradient (reference semantics, carry-over on); weights bit-exact.  float32 kernels: <= 1e-5, or where the
+    compiled reference's OWN float32 gradient is further than that from the float64 oracle (tests/golden/
+    config_C_reference.npz: 1.8e-5 at the initial point, where the gradient is the small residual of long float32 sums --
+    the device accumulates chains as long as the reference's) no worse than 1.25 x the reference; and the device's
+    gradient agrees with the reference's own sampled elements to the sum of the two."""
     X, q = msa_C, Q_C
+    gold = golden("config_C_reference")
+    assert int(gold["n_unique"]) == X.shape[0]
     for prec, wtype, tol_fx, tol_g in ((L_.DCA_F32, np.float32, 2e-6, 1e-5), (L_.DCA_F64, np.float64, 1e-10, 1e-10)):
         # float32 context: float compare and float32 1/count as plmdca_numerics.cpp:642,669; float64 context: the
         # double compare and double 1/count of the float64 oracle
@@ -62,13 +68,20 @@ def test_config_C_weights_and_fixed_x_vs_oracle(L_, oracle_plm, msa_C):
         ctx.plm_configure(LAMBDA_H, LAMBDA_J)                       # default = chunked scan, the shipped mode
         ctx.plm_init_x()
         np.testing.assert_allclose(ctx.plm_get_x(wtype), x0, rtol=2e-6, atol=2e-6)
-        for x in xs:
+        for name, x in zip(("x0", "x1"), xs):
             fx_o, g_o = oracle_plm.gradient(X, w.astype(np.float64), q, LAMBDA_H, LAMBDA_J, x.astype(np.float64), carry=True)
             ctx.plm_set_x(x)
             fx = ctx.plm_gradient()
             g = ctx.plm_get_g(np.float64)
+            ref_err = float(gold[name + "_ref_err_vs_f64"].min())
+            bound = tol_g if prec == L_.DCA_F64 else max(tol_g, 1.25 * ref_err)
             assert abs(fx - fx_o) <= tol_fx * abs(fx_o), (prec, fx, fx_o)
-            assert rel_err(g, g_o) < tol_g, (prec, rel_err(g, g_o))
+            assert rel_err(g, g_o) < bound, (prec, name, rel_err(g, g_o), ref_err)
+            # the reference itself at this point: fx and every 997th gradient element
+            assert abs(fx - float(gold[name + "_fx"])) <= 1e-5 * abs(fx_o), (prec, fx, float(gold[name + "_fx"]))
+            sub = g[::int(gold["stride"])]
+            dev = np.linalg.norm(sub - gold[name + "_g_sub"]) / np.linalg.norm(gold[name + "_g_sub"])
+            assert dev < bound + 1.5 * ref_err, (prec, name, dev)
         ctx.close()
 
 
