@@ -1148,7 +1148,10 @@ struct PlmEngine : PlmEngineBase {
                 const int spEff = ceil_div(numScatChunks, cps);
                 const double slabs = (spEff - 1) * slabUnits;
                 if (!(remEnv && atoi(remEnv) == 1 && fullCT > 0 && rem > 0)) {
-                    const double cost = rounds((long long)ceil_div(numCT, kNumXcd) * numJGs * spEff) * (cps + 2.0) + slabs;
+                    // fewer than eight strips: the (strip, split) pairs, not the strips, are dealt to the XCDs (launch_eval)
+                    const long long perXcd = fullCT > 0 ? (long long)ceil_div(numCT, kNumXcd) * numJGs * spEff
+                                                        : (long long)ceil_div(numCT * spEff, kNumXcd) * numJGs;
+                    const double cost = rounds(perXcd) * (cps + 2.0) + slabs;
                     if (cost < bestCost) { bestCost = cost; scatSplit = spEff; scatChunksPerSplit = cps; scatRemCT = scatRemSplit = scatRemChunksPerSplit = 0; }
                 }
                 if (fullCT > 0 && rem > 0 && !(remEnv && atoi(remEnv) == 0)) {
@@ -1323,8 +1326,12 @@ struct PlmEngine : PlmEngineBase {
             auto launch = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ScopedKernelClock kc(ctx, "plm_scatter");
-                hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(mainCT, kNumXcd) * numJG, scatSplit), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG,
-                                   N, L, Cs, halo, numScatChunks, NT, 0, mainCT, 1, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
+                if (numCT < kNumXcd)        // E: 6 strips would leave two XCDs idle: deal the (strip, split) pairs to the XCDs instead
+                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(numCT * scatSplit, kNumXcd) * numJG, 1), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG,
+                                       N, L, Cs, halo, numScatChunks, NT, 0, numCT * scatSplit, scatSplit, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
+                else
+                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(mainCT, kNumXcd) * numJG, scatSplit), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG,
+                                       N, L, Cs, halo, numScatChunks, NT, 0, mainCT, 1, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
                 if (scatRemCT) {
                     const int pairs = scatRemCT * scatRemSplit;
                     hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(pairs, kNumXcd) * numJG, 1), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG,
