@@ -40,7 +40,12 @@ def main():
         except Exception:
             t = {}
         d = {r[0]: r[6] for r in rows}
-        t[wl] = {"plm_scatter": d.get("plm_scatter_kernel"), "plm_logits": d.get("plm_logits_kernel")}
+        n = {r[0]: r[1] for r in rows}
+        # per EVALUATION (= per launch of the logits kernel): the scatter stage is two launches of plm_scatter_kernel (main +
+        # left-over strips) and the column-range slab sum when the alignment has left-over strips
+        evals = max(n.get("plm_logits_kernel", 1), 1)
+        scatter = sum(d[k] * n[k] for k in ("plm_scatter_kernel", "plm_sum_slabs_cols_kernel") if k in d) / evals
+        t[wl] = {"plm_scatter": scatter or None, "plm_logits": d.get("plm_logits_kernel")}
         import os
         t["measured_at_commit"] = os.environ.get("DCA_COMMIT", "unknown")      # bench.py reports it next to roofline.traffic
         json.dump(t, open(path, "w"), indent=1)
