@@ -928,8 +928,10 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     DCA_TRY(launch_gemm(ctx, GemmArgs{L21, n1, MASK_NONE, L21, n1, MASK_NONE, M22, ld, nullptr, 0, n2, n2, n1, -1.0, 1.0, 1}));
     DCA_TRY(cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo));
     // T^T[j][i] = sum_k X11^T[j][k] * L21[i][k];  X11^T rows are the mirrored upper part of M11 (k >= j)
-    // (running this product on a side stream next to the A22 subtree was tried and gained nothing:
-    // profiles/experiments/cholinv_gemm128_v2_and_overlap.hip.txt)
+    // (running this product on a side stream next to the A22 subtree was tried twice and gained nothing: plain streams in
+    // round 1, profiles/experiments/cholinv_gemm128_v2_and_overlap.hip.txt; in round 2 a CU-masked stream
+    // (hipExtStreamCreateWithCUMask, 2 / 4 / 8 / 16 CUs of every XCD kept free for the chain of small kernels) at the two
+    // top levels: 28.1 / 27.5 / 27.1 / 25.8 ms against 26.6 without)
     DCA_TRY(launch_gemm(ctx, GemmArgs{M11, ld, MASK_UPPER, L21, n1, MASK_NONE, Tt, n2, nullptr, 0, n1, n2, n1, 1.0, 0.0, 0}));
     // X21[i][j] = -sum_k X22[i][k] * T^T[j][k];  X22 lower (k <= i); mirrored into the (1,2) block
     DCA_TRY(launch_gemm(ctx, GemmArgs{M22, ld, MASK_LOWER, Tt, n2, MASK_NONE, M21, ld, M12, ld, n2, n1, n2, -1.0, 0.0, 0, WALK_ROWS_REVERSED}));

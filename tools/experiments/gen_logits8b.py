@@ -10,13 +10,14 @@ usage: gen_logits8b.py U CH > logits_variant.inc     (gpridx_logits.hip -DNWAVES
 import sys
 Q, JT, ROWBYTES = 21, 6, 512
 U, CH = int(sys.argv[1]), int(sys.argv[2])
+OPTS = sys.argv[3:]                  # nop: s_nop 0 between the M0 write and the add; read2: rows fetched in pairs (ds_read2_b64)
 assert U % CH == 0 and CH in (8, 16, 32)
 M = U // CH                       # chunks per site
 CW = CH // 2                      # dwords per chunk
 W0, ACC = 4, 4 + 2 * Q
 S0 = 36
 TB = S0 + U // 2                  # temporaries: sptr pair (this site), saved m0, zero, next-site pointer pair
-assert TB + 6 <= 96 and ACC + 2 * U <= 256, (TB, ACC + 2 * U)
+assert TB + 6 <= 96 and ACC + 2 * U + 2 <= 256, (TB, ACC + 2 * U)
 o = ["s_mov_b32 s%d, m0" % (TB + 2), "s_mov_b64 s[%d:%d], %%[sptr]" % (TB, TB + 1), "s_mov_b32 s%d, 0" % (TB + 3)]
 
 
@@ -28,8 +29,15 @@ def sload(c, ptr):
 for c in range(M - 1):
     o.append(sload(c, TB))
 for jj in range(JT):
-    for b in range(Q):
-        o.append("ds_read_b64 v[%d:%d], %%[vbase] offset:%d" % (W0 + 2 * b, W0 + 2 * b + 1, (jj * Q + b) * ROWBYTES))
+    if "read2" in OPTS:
+        for b in range(0, Q - 1, 2):              # offsets are 8 bits x 8 bytes: a pair per address register
+            t = ACC + 2 * U + (b // 2) % 2
+            o.append("v_add_u32 v%d, %d, %%[vbase]" % (t, (jj * Q + b) * ROWBYTES))
+            o.append("ds_read2_b64 v[%d:%d], v%d offset0:0 offset1:64" % (W0 + 2 * b, W0 + 2 * b + 3, t))
+        o.append("ds_read_b64 v[%d:%d], %%[vbase] offset:%d" % (W0 + 2 * (Q - 1), W0 + 2 * (Q - 1) + 1, (jj * Q + Q - 1) * ROWBYTES))
+    else:
+        for b in range(Q):
+            o.append("ds_read_b64 v[%d:%d], %%[vbase] offset:%d" % (W0 + 2 * b, W0 + 2 * b + 1, (jj * Q + b) * ROWBYTES))
     o.append("s_waitcnt lgkmcnt(0)")
     o.append(sload(M - 1, TB))
     o.append("s_set_gpr_idx_on s%d, 0x2" % (TB + 3))
@@ -42,11 +50,13 @@ for jj in range(JT):
                     o.append(sload(c, TB))
         w = S0 + sq // 2
         o.append(("s_pack_ll_b32_b16 m0, s%d, 0" if sq % 2 == 0 else "s_lshr_b32 m0, s%d, 16") % w)
+        if "nop" in OPTS:
+            o.append("s_nop 0")
         a = ACC + 2 * sq
         o.append("v_pk_add_f32 v[%d:%d], v[%d:%d], v[%d:%d]" % (a, a + 1, a, a + 1, W0, W0 + 1))
     o.append("s_set_gpr_idx_off")
 o.append("s_mov_b32 m0, s%d" % (TB + 2))
-clob = ['"memory"', '"scc"'] + ['"v%d"' % i for i in range(W0, ACC + 2 * U)] + ['"s%d"' % i for i in range(36, TB + 4)]
+clob = ['"memory"', '"scc"'] + ['"v%d"' % i for i in range(W0, ACC + 2 * U + 2)] + ['"s%d"' % i for i in range(36, TB + 4)]
 print("#define LOGITS_BLOCK(VBASE, SPTR, STRIDE) asm volatile( \\")
 for ln in o:
     print('    "%s\\n" \\' % ln)
