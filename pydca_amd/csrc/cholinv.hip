@@ -949,10 +949,15 @@ int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* 
     HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dInfo), sizeof(int)));
     HIP_TRY(hipMemsetAsync(dInfo, 0, sizeof(int), ctx->stream));
     Arena ws{dWork, (size_t)n * n};
-    int rc = cholinv_rec(ctx, dA, n, n, 0, ws, dInfo);
+    int rc;
+    {
+        ScopedKernelClock kr(ctx, "mf_inverse_recursion");
+        rc = cholinv_rec(ctx, dA, n, n, 0, ws, dInfo);
+    }
     if (rc == DCA_OK) {
         double* out = dWork + (size_t)n * n;
         // scale * inv(A)[i][j] = scale * sum_{k >= max(i,j)} X[k][i] X[k][j] = scale * sum_k Xt[i][k] Xt[j][k]
+        ScopedKernelClock kx(ctx, "mf_inverse_xtx");
         rc = launch_gemm(ctx, GemmArgs{dA, n, MASK_UPPER, dA, n, MASK_UPPER, out, n, out, n, n, n, n, scale, 0.0, 1});
         *result = out;
     }

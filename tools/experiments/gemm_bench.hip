@@ -1,6 +1,7 @@
 // Stand-alone timing of the f64 NT GEMM of csrc/cholinv.hip (the file is included, so the kernel
 // under test is the product kernel): plain and triangular-operand products at the sizes of the inverse.
 // hipcc --offload-arch=gfx950 -O3 -I../../include -I../../pydca_amd/csrc -o gemm_bench gemm_bench.hip
+#include <unistd.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,13 @@ __global__ void fill_kernel(double* p, size_t n, unsigned seed)
         p[i] = (double)(h & 0xffffff) / 16777216.0 - 0.5;
     }
 }
+__global__ void tiny_kernel(double* p, int spin)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < spin / 10) { }
+    if (p == nullptr) p[0] = 0;
+}
+
 int main(int argc, char** argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 5056;
@@ -49,6 +57,27 @@ int main(int argc, char** argv)
         }
         printf("n=%d %-34s %.3f ms  %.1f TFLOP/s (useful flops)\n", n, c.name, best, c.flops / (best * 1e-3) / 1e12);
     }
+    // the final product of the inverse in its own situation: both operands the SAME matrix, one launch, after a stretch of
+    // tiny single-workgroup kernels (the tail of the recursion) or after idling
+    auto once = [&](const char* what, double* Bop, int tiny, int sleep_us) {
+        if (sleep_us) usleep(sleep_us);
+        for (int i = 0; i < tiny; ++i) hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, ctx.stream, C, 4000);
+        CHECK(hipEventRecord(e0, ctx.stream));
+        launch_gemm(&ctx, GemmArgs{A, n, MASK_UPPER, Bop, n, MASK_UPPER, C, n, C, n, n, n, n, -1.0, 0.0, 1});
+        CHECK(hipEventRecord(e1, ctx.stream));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("n=%d X^T X once, %-44s %.3f ms\n", n, what, ms);
+    };
+    once("B != A, back to back", B, 0, 0);
+    once("B != A, back to back", B, 0, 0);
+    once("B == A, back to back", A, 0, 0);
+    once("B == A, back to back", A, 0, 0);
+    once("B == A, after 5 ms host sleep", A, 0, 5000);
+    once("B == A, after 100 ms host sleep", A, 0, 100000);
+    once("B == A, after 200 tiny kernels (~1 ms)", A, 200, 0);
+    once("B == A, after 1000 tiny kernels (~5 ms)", A, 1000, 0);
+    once("B == A, back to back", A, 0, 0);
     fflush(stdout);
     return 0;
 }

@@ -31,7 +31,7 @@ for rep in range(a.reps):
     t3 = time.perf_counter()
     order = ctx.scores_order()
     dt = time.perf_counter() - t0
-    print("rep", rep, "total %.1f ms" % (dt * 1e3), {k: round(ctx.kernel_time(k)[0], 2) for k in ("weights", "mf_counts", "mf_inverse", "scores")},
+    print("rep", rep, "total %.1f ms" % (dt * 1e3), {k: round(ctx.kernel_time(k)[0], 2) for k in ("weights", "mf_counts", "mf_inverse", "mf_inverse_recursion", "mf_inverse_xtx", "scores")},
           "pairs/s %.0f" % (a.L * (a.L - 1) / 2 / dt),
           "host ms: set_msa %.1f weights %.1f mf_run %.1f order %.1f" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t0 + dt - t3) * 1e3))
     ctx.close()
