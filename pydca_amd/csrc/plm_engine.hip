@@ -731,33 +731,11 @@ __global__ void vec_dot_kernel(const T* __restrict__ a, const T* __restrict__ b,
         s0 += (double)a[i] * (double)b[i];)
     block_reduce_store(s0, red, partials + blockIdx.x);
 }
-// s = x - xp, y = g - gp, partials: y.s, y.y   (lbfgs.cpp:546-558)
-template <typename T>
-__global__ void vec_diff_kernel(T* __restrict__ s, T* __restrict__ y, const T* __restrict__ x, const T* __restrict__ xp,
-                                const T* __restrict__ g, const T* __restrict__ gp, size_t n, double* __restrict__ partials)
-{
-    __shared__ double red[kVecThreads];
-    double s0 = 0, s1 = 0;
-    DCA_VEC_LOOP(n,
-        const Pack<T> px = ldp(x, iv); const Pack<T> pxp = ldp(xp, iv); const Pack<T> pg = ldp(g, iv); const Pack<T> pgp = ldp(gp, iv);
-        Pack<T> ps; Pack<T> py;
-        _Pragma("unroll") for (int k = 0; k < VEC; ++k) {
-            const T sv = px.v[k] - pxp.v[k]; const T yv = pg.v[k] - pgp.v[k];
-            ps.v[k] = sv; py.v[k] = yv;
-            s0 += (double)yv * (double)sv; s1 += (double)yv * (double)yv;
-        }
-        stp(s, iv, ps); stp(y, iv, py);,
-        { const T sv = x[i] - xp[i]; const T yv = g[i] - gp[i]; s[i] = sv; y[i] = yv;
-          s0 += (double)yv * (double)sv; s1 += (double)yv * (double)yv; })
-    block_reduce_store(s0, red, partials + blockIdx.x);
-    block_reduce_store(s1, red, partials + gridDim.x + blockIdx.x);
-}
 // L-BFGS direction in one pass instead of 2m dependent dot/axpy rounds: every vector of the
 // two-loop recursion (lbfgs.cpp:568-601) lies in span{g, s_k, y_k}, so the recursion can be run
-// on 2m+1 coefficients on the host once the Gram entries it needs are known.  This kernel
-// produces, for the newest pair e and every slot k: s_k.g, y_k.g, s_e.y_k, y_e.s_k, y_e.y_k
-// (25 dot products, 12 vector reads); the entries between older pairs are kept from earlier
-// iterations.  partials[v * gridDim.x + block], v = kind * 5 + k.
+// on 2m+1 coefficients once the Gram entries it needs are known: for the newest pair e and every
+// slot k: s_k.g, y_k.g, s_e.y_k, y_e.s_k, y_e.y_k (25 dot products; the entries between older pairs are
+// kept from earlier iterations).  vec_diff_gram_kernel below produces them in the pass that forms the pair.
 struct VecPtrs5 { const void* s[5]; const void* y[5]; };
 struct DirCoefs { double g; double s[5]; double y[5]; };
 
@@ -814,40 +792,51 @@ __global__ void lbfgs_two_loop_kernel(double* __restrict__ scal, LbfgsDev* __res
     scal[kSlotDginit] = gd;
 }
 
+// s_e = x - xp, y_e = g - gp (lbfgs.cpp:546-558) are formed, stored and used in one pass, so the newest pair is not
+// read back and g is read once (14 vector passes; 19 as two kernels, 0.75 -> 0.6 ms at D).  partials[v * gridDim.x +
+// block]: v = 0, 1 are y_e.s_e and y_e.y_e, v = 2 + kind * 5 + k the Gram entries (kinds in the order above).
 template <typename T>
 __global__ __launch_bounds__(kVecThreads)
-void vec_gram_kernel(VecPtrs5 P, const T* __restrict__ g, int e, size_t n, double* __restrict__ partials)
+void vec_diff_gram_kernel(VecPtrs5 P, T* __restrict__ se, T* __restrict__ ye, const T* __restrict__ x, const T* __restrict__ xp,
+                          const T* __restrict__ g, const T* __restrict__ gp, int e, size_t n, double* __restrict__ partials)
 {
-    __shared__ double red[kVecThreads / 64][25];
-    double acc[25];
+    __shared__ double red[kVecThreads / 64][27];
+    double acc[27];
 #pragma unroll
-    for (int v = 0; v < 25; ++v) acc[v] = 0.0;
-    const T* se = static_cast<const T*>(P.s[e]);
-    const T* ye = static_cast<const T*>(P.y[e]);
+    for (int v = 0; v < 27; ++v) acc[v] = 0.0;
     DCA_VEC_LOOP(n,
-        const Pack<T> pg = ldp(g, iv); const Pack<T> pse = ldp(se, iv); const Pack<T> pye = ldp(ye, iv);
+        const Pack<T> px = ldp(x, iv); const Pack<T> pxp = ldp(xp, iv); const Pack<T> pg = ldp(g, iv); const Pack<T> pgp = ldp(gp, iv);
+        Pack<T> pse; Pack<T> pye;
+        _Pragma("unroll") for (int u = 0; u < VEC; ++u) {
+            pse.v[u] = px.v[u] - pxp.v[u]; pye.v[u] = pg.v[u] - pgp.v[u];
+            acc[0] += (double)pye.v[u] * (double)pse.v[u]; acc[1] += (double)pye.v[u] * (double)pye.v[u];
+        }
+        stp(se, iv, pse); stp(ye, iv, pye);
         _Pragma("unroll") for (int k = 0; k < 5; ++k) {
-            const Pack<T> psk = ldp(static_cast<const T*>(P.s[k]), iv); const Pack<T> pyk = ldp(static_cast<const T*>(P.y[k]), iv);
+            Pack<T> psk = pse; Pack<T> pyk = pye;
+            if (k != e) { psk = ldp(static_cast<const T*>(P.s[k]), iv); pyk = ldp(static_cast<const T*>(P.y[k]), iv); }
             _Pragma("unroll") for (int u = 0; u < VEC; ++u) {
                 const double gv = pg.v[u]; const double sev = pse.v[u]; const double yev = pye.v[u];
                 const double sk = psk.v[u]; const double yk = pyk.v[u];
-                acc[k] += sk * gv; acc[5 + k] += yk * gv; acc[10 + k] += sev * yk; acc[15 + k] += yev * sk; acc[20 + k] += yev * yk;
+                acc[2 + k] += sk * gv; acc[7 + k] += yk * gv; acc[12 + k] += sev * yk; acc[17 + k] += yev * sk; acc[22 + k] += yev * yk;
             }
         },
-        { const double gv = g[i]; const double sev = se[i]; const double yev = ye[i];
+        { const T sev_ = x[i] - xp[i]; const T yev_ = g[i] - gp[i]; se[i] = sev_; ye[i] = yev_;
+          const double gv = g[i]; const double sev = sev_; const double yev = yev_;
+          acc[0] += yev * sev; acc[1] += yev * yev;
           _Pragma("unroll") for (int k = 0; k < 5; ++k) {
-              const double sk = static_cast<const T*>(P.s[k])[i]; const double yk = static_cast<const T*>(P.y[k])[i];
-              acc[k] += sk * gv; acc[5 + k] += yk * gv; acc[10 + k] += sev * yk; acc[15 + k] += yev * sk; acc[20 + k] += yev * yk;
+              const double sk = k == e ? sev : (double)static_cast<const T*>(P.s[k])[i]; const double yk = k == e ? yev : (double)static_cast<const T*>(P.y[k])[i];
+              acc[2 + k] += sk * gv; acc[7 + k] += yk * gv; acc[12 + k] += sev * yk; acc[17 + k] += yev * sk; acc[22 + k] += yev * yk;
           } })
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int v = 0; v < 25; ++v) {
+    for (int v = 0; v < 27; ++v) {
         double a = acc[v];
         for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
         if (lane == 0) red[wv][v] = a;
     }
     __syncthreads();
-    if (threadIdx.x < 25) {
+    if (threadIdx.x < 27) {
         double a = 0.0;
         for (int w = 0; w < kVecThreads / 64; ++w) a += red[w][threadIdx.x];
         partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = a;
@@ -1176,7 +1165,7 @@ struct PlmEngine : PlmEngineBase {
         nRegPart = (int)npairs + ceil_div(Lq, 256);
         DCA_TRY(dalloc(&dFxPart, nFxPart));
         DCA_TRY(dalloc(&dRegPart, nRegPart + kSumStageBlocks));      // + the first-stage sums of the regulariser partials
-        DCA_TRY(dalloc(&dVecPart, 25 * kVecBlocks));
+        DCA_TRY(dalloc(&dVecPart, 27 * kVecBlocks));
 
         HIP_TRY(hipMemsetAsync(dx, 0, (P + kVecPad) * sizeof(T), ctx->stream));
         HIP_TRY(hipMemsetAsync(dg, 0, (P + kVecPad) * sizeof(T), ctx->stream));
@@ -1619,18 +1608,16 @@ struct PlmEngine : PlmEngineBase {
             if (o.gnorm / xn <= 1e-3) { o.status = 0; o.finished = true; break; }
             if (o.max_iterations != 0 && o.max_iterations < o.k + 1) { o.status = LB_MAXIMUMITERATION; o.finished = true; break; }
 
-            // s, y of the accepted step and every dot product the direction needs, in two kernels and ONE
+            // s, y of the accepted step and every dot product the direction needs, in one kernel and ONE
             // round trip for the scalars: dScal[1..2] = y.s, y.y;  dScal[3..27] = the 25 Gram entries
             const int e = o.end;              // slot of the newest pair
             VecPtrs5 ptrs;
             for (int i = 0; i < M; ++i) { ptrs.s[i] = dS[i] + vlo; ptrs.y[i] = dY[i] + vlo; }
             {
                 ScopedKernelClock kc(ctx, "lbfgs_vec");
-                hipLaunchKernelGGL(vec_diff_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream,
-                                   dS[e] + vlo, dY[e] + vlo, dx + vlo, dxp + vlo, dg + vlo, dgp + vlo, vn, dVecPart);
-                hipLaunchKernelGGL(vec_final_kernel, dim3(2), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 2, ctx->dScal + 1);
-                hipLaunchKernelGGL(vec_gram_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, ptrs, dg + vlo, e, vn, dVecPart);
-                hipLaunchKernelGGL(vec_final_kernel, dim3(25), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 25, ctx->dScal + 3);
+                hipLaunchKernelGGL(vec_diff_gram_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, ptrs, dS[e] + vlo, dY[e] + vlo,
+                                   dx + vlo, dxp + vlo, dg + vlo, dgp + vlo, e, vn, dVecPart);
+                hipLaunchKernelGGL(vec_final_kernel, dim3(27), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 27, ctx->dScal + 1);
             }
             DCA_TRY(reduce_scalars(1, 27));
             const int bound = (M <= o.k) ? M : o.k;
