@@ -5,12 +5,13 @@ the only wait is ONE `s_waitcnt lgkmcnt(0)` per block, a whole block of adds aft
 waits, which over-count while scalar loads are in flight).  Self-contained for timing as gen_scatter_var.py.
 usage: gen_scatter_blk.py JW BLK > scatter_variant.inc      (scatter_bench.hip -DNWAVES=...)"""
 import sys
-Q, ROWS, ROWBYTES = 21, 128, 512
+import os
+Q, ROWS, ROWBYTES = int(os.environ.get('SC_Q', '21')), 128, 512
 JW, BLK = int(sys.argv[1]), int(sys.argv[2])
 DMA = len(sys.argv) > 3 and sys.argv[3] == "dma"
 WAVES = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 PPW = 64 // WAVES                     # 1 KiB LDS-DMA pieces per wave and tile
-VG = {2: 128, 3: 168}.get(JW, 256)
+VG = int(os.environ['SC_VG']) if 'SC_VG' in os.environ else {2: 128, 3: 168}.get(JW, 256)
 acc = [VG - 2 * Q * (JW - jj) for jj in range(JW)]
 d0 = acc[0] - 4 * BLK                 # two ring halves of BLK register pairs
 assert d0 >= 8, d0

@@ -3,11 +3,12 @@
 self-contained for timing: accumulators and the tile loop live inside the asm.
 usage: gen_scatter_var.py JW GROUP DEPTH [skiplast] > scatter_variant.inc      (scatter_bench.hip)"""
 import sys
-Q, ROWS, ROWBYTES = 21, 128, 512
+import os
+Q, ROWS, ROWBYTES = int(os.environ.get('SC_Q', '21')), 128, 512
 JW, GROUP, DEPTH = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 SKIPLAST = len(sys.argv) > 4 and sys.argv[4] == "skiplast"
 DMA = sys.argv[-1] == "dma"          # one 1 KiB LDS-DMA piece per group start (product: 16 waves x 4 quarters = 64 KiB per tile)
-VG = {2: 128, 3: 168}.get(JW, 256)
+VG = int(os.environ['SC_VG']) if 'SC_VG' in os.environ else {2: 128, 3: 168}.get(JW, 256)
 acc = [VG - 2 * Q * (JW - jj) for jj in range(JW)]
 d0 = acc[0] - 2 * DEPTH
 assert d0 >= 8

@@ -6,6 +6,9 @@
 #include <vector>
 #include <cstdint>
 #include "scatter_variant.inc"
+#ifndef SC_QSTATES
+#define SC_QSTATES 21
+#endif
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 #ifndef NWAVES
 #define NWAVES 8
@@ -40,7 +43,7 @@ int main(int argc, char** argv)
     std::vector<float> tile(ROWS * 128, 0.25f);
     std::vector<uint32_t> st((size_t)blocks * WAVES * (iters + 1) * SC_STREAM_WORDS_PER_TILE + 64);
     srand(1);
-    for (auto& s : st) s = (0x9000u | (2u * (rand() % 21))) | ((0x9000u | (2u * (rand() % 21))) << 16);
+    for (auto& s : st) s = (0x9000u | (2u * (rand() % SC_QSTATES))) | ((0x9000u | (2u * (rand() % SC_QSTATES))) << 16);
     float *dT, *dO; uint32_t* dS;
     CHECK(hipMalloc(&dT, tile.size() * 4)); CHECK(hipMalloc(&dS, st.size() * 4)); CHECK(hipMalloc(&dO, (size_t)blocks * WAVES * 64 * 4));
     CHECK(hipMemcpy(dT, tile.data(), tile.size() * 4, hipMemcpyHostToDevice));
