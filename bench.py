@@ -315,6 +315,12 @@ def main():
                 "unit": "GB/s", "frac": alg_bytes[dom] / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_measured_at_commit": traffic_commit,
                 "avg_kernel_ms": ms / max(launches, 1), "launches": launches,
+                # one "launch" here = the stage of one evaluation, bracketed by HIP events on the library's stream; the scatter
+                # stage is plm_scatter_kernel (main) + plm_scatter_kernel (left-over column strips, when the strip count is
+                # not a multiple of 8) + plm_sum_slabs_cols_kernel: a rocprofv3 kernel trace lists those separately
+                "stage_kernels": {"plm_logits": ["plm_logits_kernel"],
+                                  "plm_scatter": ["plm_scatter_kernel (main)", "plm_scatter_kernel (left-over strips)",
+                                                  "plm_sum_slabs_cols_kernel"]}[dom],
                 "note": "gather kernels: bound on chip (VALU/SALU issue of the indexed adds, LDS reads), not by HBM (DESIGN.md section 4); see valu / onchip",
                 "onchip": {"bound": "lds", "achieved": lds_bytes[dom] / avg_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                            "frac": lds_bytes[dom] / avg_s / 1e9 / LDS_PEAK_GBS},
