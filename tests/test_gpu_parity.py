@@ -472,11 +472,13 @@ def test_scores_order_matches_stable_argsort(L_, oracle_mf):
 
 
 @pytest.mark.parametrize("N,L,q", [(1, 2, 5), (3, 2, 21), (7, 5, 21), (33, 7, 5), (129, 13, 21), (130, 33, 5),
-                                    (513, 6, 21), (640, 25, 5), (257, 31, 21)])
+                                    (513, 6, 21), (640, 25, 5), (257, 31, 21),
+                                    (96, 6, 21), (97, 7, 21), (768, 5, 21), (769, 8, 21), (49, 26, 5), (769, 27, 5)])
 def test_gradient_edge_shapes(L_, oracle_plm, N, L, q):
-    """Shapes at and across the tile boundaries of the two gather kernels: fewer sequences than one
-    32-sequence wave block / 128-row tile / 512-sequence workgroup (+1), fewer sites than one LDS tile
-    of W (6 resp. 24 sites) or one 32-site scatter group (+1), a single sequence, the minimum L = 2."""
+    """Shapes at and across the tile boundaries of the two gather kernels: fewer sequences than one wave's block of
+    the logits kernel (96 for q = 21, 48 for q = 5; 32 earlier) / one 128-row tile / one workgroup's 768 sequences
+    (512 earlier), each + 1; fewer sites than one LDS tile of W (6 resp. 25 sites) or one 32-site scatter group (+1), a
+    single sequence, the minimum L = 2."""
     rng = np.random.default_rng(1000 * N + 10 * L + q)
     X = rng.integers(0, q, size=(N, L), dtype=np.uint8)
     X = np.unique(X, axis=0)                      # the library expects de-duplicated rows like the reader yields
