@@ -95,8 +95,15 @@ def test_config_C_left_over_strips_launch(L_, oracle_plm, msa_C, monkeypatch):
         x = perturbed(oracle_plm.init_x(X, w, q), L_C, q)
         fx_o, g_o = oracle_plm.gradient(X, w.astype(np.float64), q, LAMBDA_H, LAMBDA_J, x.astype(np.float64), carry=True)
         got = {}
-        for mode in ("0", "1"):
+        for mode, split in (("0", None), ("1", None), ("1", "2"), ("1", "3")):
+            # split 2: the fold adds two slabs, the left-over columns' second slab must have been cleared; split 3: the
+            # all-column slab sum runs after the column-range one
             monkeypatch.setenv("DCA_SCATTER_REM", mode)
+            if split:
+                monkeypatch.setenv("DCA_SCATTER_SPLIT", split)
+            else:
+                monkeypatch.delenv("DCA_SCATTER_SPLIT", raising=False)
+            mode = mode + (":" + split if split else "")
             ctx = _ctx(L_, X, q, prec, prec)
             ctx.plm_configure(LAMBDA_H, LAMBDA_J)
             ctx.plm_set_x(x)
@@ -104,8 +111,9 @@ def test_config_C_left_over_strips_launch(L_, oracle_plm, msa_C, monkeypatch):
             got[mode] = (fx, ctx.plm_get_g(np.float64))
             ctx.close()
             assert rel_err(got[mode][1], g_o) < tol_g, (prec, mode, rel_err(got[mode][1], g_o))
-        assert got["0"][0] == got["1"][0]
-        assert rel_err(got["1"][1], got["0"][1]) < tol_modes, (prec, rel_err(got["1"][1], got["0"][1]))
+        for mode in ("1", "1:2", "1:3"):
+            assert got["0"][0] == got[mode][0]
+            assert rel_err(got[mode][1], got["0"][1]) < tol_modes, (prec, mode, rel_err(got[mode][1], got["0"][1]))
         assert not np.array_equal(got["1"][1], got["0"][1]) or prec == L_.DCA_F64      # the forced path really ran (float32: other slab order)
 
 
