@@ -25,7 +25,7 @@ constexpr int kKG = 4;         // 32-site groups per LDS stage
 // compared, but the early exit of weights_count_kernel does: a wave stops when ALL its 1024 pairs have passed L - T
 // mismatches, so the variable columns should come first and the conserved ones last.  Columns are ranked by their
 // collision probability sum_a count(a)^2 (unweighted; ascending, ties by index): D 3.97 -> 3.01 ms, E 19.5 -> 17.5 ms
-// including the two small kernels below; the counts are the same integers whatever the order (DCA_WEIGHTS_FILE_ORDER=1: file order).
+// including the two small kernels below; the counts are the same integers whatever the order (DCA_WEIGHTS_ORDER=file: file order).
 __global__ __launch_bounds__(256)
 void weights_column_hist_kernel(const uint8_t* __restrict__ X, uint32_t* __restrict__ hist, int N, int L, int Ls, int seqPerBlock)
 {
@@ -252,9 +252,14 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int p
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dPerm), (size_t)ctx->Ls * sizeof(int)));
         HIP_TRY(hipMemsetAsync(dHist, 0, (size_t)L * 32 * sizeof(uint32_t), ctx->stream));
         constexpr int kSeqPerBlock = 256;
-        hipLaunchKernelGGL(weights_column_hist_kernel, dim3(ceil_div(L, 256), ceil_div(N, kSeqPerBlock)), dim3(256), 0, ctx->stream,
-                           ctx->dX, dHist, N, L, ctx->Ls, kSeqPerBlock);
-        const bool ranked = (size_t)L * sizeof(unsigned long long) <= 60000 && !getenv("DCA_WEIGHTS_FILE_ORDER");
+        // worth its two small kernels and the gathered plane build only for large problems (C, N = 10k: 0.15 -> 0.22 ms with it)
+        // (DCA_WEIGHTS_ORDER=file / variable forces one or the other)
+        const char* orderEnv = getenv("DCA_WEIGHTS_ORDER");
+        const bool wantRanked = orderEnv ? (orderEnv[0] == 'v') : (double)N * N * L >= 2e11;
+        const bool ranked = wantRanked && (size_t)L * sizeof(unsigned long long) <= 60000;
+        if (ranked)
+            hipLaunchKernelGGL(weights_column_hist_kernel, dim3(ceil_div(L, 256), ceil_div(N, kSeqPerBlock)), dim3(256), 0, ctx->stream,
+                               ctx->dX, dHist, N, L, ctx->Ls, kSeqPerBlock);
         hipLaunchKernelGGL(weights_column_rank_kernel, dim3(1), dim3(1024), ranked ? (size_t)L * sizeof(unsigned long long) : 0, ctx->stream,
                            ranked ? dHist : nullptr, dPerm, L, ctx->Ls);
         const unsigned tb = (unsigned)(((size_t)N * G + 255) / 256);

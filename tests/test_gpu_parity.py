@@ -33,9 +33,12 @@ def make_ctx(L_, X, q, precision, seqid=0.8, cmp=None):
 PLM_TAGS = ["toy_rna", "toy_protein", "rf71", "rf00167", "pf02826"]
 
 
+@pytest.mark.parametrize("order", ["file", "variable"])
 @pytest.mark.parametrize("tag", PLM_TAGS)
-def test_weights_bit_exact(L_, oracle_plm, tag):
-    """plmdca_numerics.cpp:611-671 -- integer counts and float32 1/count, bit for bit."""
+def test_weights_bit_exact(L_, oracle_plm, tag, order, monkeypatch):
+    """plmdca_numerics.cpp:611-671 -- integer counts and float32 1/count, bit for bit; with the sites compared in file
+    order and most variable first (what large alignments get by default): the counts do not depend on it."""
+    monkeypatch.setenv("DCA_WEIGHTS_ORDER", order)
     G = golden("plm_" + tag)
     ctx = make_ctx(L_, G["X"], int(G["q"]), L_.DCA_F32, float(G["seqid"]))
     counts = ctx.weight_counts()
@@ -58,11 +61,16 @@ def test_weights_thresholds_and_ragged_sizes(L_, oracle_plm):
         flip = rng.random((N, L)) < 0.2
         X[flip] = rng.integers(0, q, size=int(flip.sum()), dtype=np.uint8)
         for seqid in (0.5, 0.8, 0.9, 0.999):
-            ctx = L_.Context(0, L_.DCA_F32)
-            ctx.set_msa(X, q)
-            w = ctx.compute_weights(seqid, L_.DCA_F32)
-            assert np.array_equal(w.astype(np.float32), oracle_plm.weights(X, seqid, np.float32)), (N, L, q, seqid)
-            ctx.close()
+            for order in ("file", "variable"):
+                os.environ["DCA_WEIGHTS_ORDER"] = order
+                try:
+                    ctx = L_.Context(0, L_.DCA_F32)
+                    ctx.set_msa(X, q)
+                    w = ctx.compute_weights(seqid, L_.DCA_F32)
+                finally:
+                    del os.environ["DCA_WEIGHTS_ORDER"]
+                assert np.array_equal(w.astype(np.float32), oracle_plm.weights(X, seqid, np.float32)), (N, L, q, seqid, order)
+                ctx.close()
 
 
 @pytest.mark.parametrize("tag", PLM_TAGS)
