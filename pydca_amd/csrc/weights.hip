@@ -25,6 +25,7 @@ constexpr int kKG = 4;         // 32-site groups per LDS stage
 // compared, but the early exit of weights_count_kernel does: a wave stops when ALL its 1024 pairs have passed L - T
 // mismatches, so the variable columns should come first and the conserved ones last.  Columns are ranked by their
 // collision probability sum_a count(a)^2 (unweighted; ascending, ties by index): D 3.97 -> 3.01 ms, E 19.5 -> 17.5 ms
+// (then 2.59 / 13.0 ms with the cheaper exit test, the skipped epilogue of finished waves and 16-byte staging loads)
 // including the two small kernels below; the counts are the same integers whatever the order (DCA_WEIGHTS_ORDER=file: file order).
 __global__ __launch_bounds__(256)
 void weights_column_hist_kernel(const uint8_t* __restrict__ X, uint32_t* __restrict__ hist, int N, int L, int Ls, int seqPerBlock)
@@ -134,26 +135,29 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
     // and short alignments (config E: 150 sites, passed after ~64) are over before the first stage of 128 sites ends.
     const unsigned maxMism = (unsigned)(L - thresh);
     bool waveDone = false;       // wave-uniform
-    auto all_passed = [&]() {
-        bool d = true;
+    auto all_passed = [&]() {          // smallest of the 16 counts against the bound: 8 x v_min3 instead of 16 compares and ands
+        unsigned mn = mism[0][0];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) d = d && mism[r][c] > maxMism;
-        return d;
+            for (int c = 0; c < 4; ++c) mn = min(mn, mism[r][c]);
+        return mn > maxMism;
     };
 
     for (int g0 = 0; g0 < G; g0 += kKG) {
         if (__syncthreads_and(waveDone)) break;      // also the barrier that protects sA / sB
-        for (int t = threadIdx.x; t < kTile * ROWDW; t += 256) {
-            const int r = t / ROWDW, k = t % ROWDW;
-            uint32_t a = 0, b = 0;
-            if (g0 * PLP + k < rowDwords) {
-                if (rowBase + r < N) a = P[(size_t)(rowBase + r) * rowDwords + g0 * PLP + k];
-                if (colBase + r < N) b = P[(size_t)(colBase + r) * rowDwords + g0 * PLP + k];
-            }
-            sA[r * STRIDE + k] = a;
-            sB[r * STRIDE + k] = b;
+        // a stage is ROWDW dwords (64 or 96 bytes, 16-byte aligned: G is a multiple of kKG) of every row: 16-byte loads,
+        // 8-byte LDS stores (the LDS row stride is only 8-byte aligned)
+        constexpr int Q4 = ROWDW / 4;
+        for (int t = threadIdx.x; t < kTile * Q4; t += 256) {
+            const int r = t / Q4, k4 = t % Q4;
+            uint4 a = make_uint4(0, 0, 0, 0), b = a;
+            if (rowBase + r < N) a = *reinterpret_cast<const uint4*>(P + (size_t)(rowBase + r) * rowDwords + g0 * PLP + 4 * k4);
+            if (colBase + r < N) b = *reinterpret_cast<const uint4*>(P + (size_t)(colBase + r) * rowDwords + g0 * PLP + 4 * k4);
+            uint2* da = reinterpret_cast<uint2*>(&sA[r * STRIDE + 4 * k4]);
+            uint2* db = reinterpret_cast<uint2*>(&sB[r * STRIDE + 4 * k4]);
+            da[0] = make_uint2(a.x, a.y); da[1] = make_uint2(a.z, a.w);
+            db[0] = make_uint2(b.x, b.y); db[1] = make_uint2(b.z, b.w);
         }
         __syncthreads();
 #pragma unroll
@@ -187,7 +191,9 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
         }
         if (!waveDone) waveDone = __all(all_passed());
     }
-    // ident = L - mismatches (padding sites are state 0 in every row and never mismatch)
+    // ident = L - mismatches (padding sites are state 0 in every row and never mismatch).  A wave whose pairs have all
+    // passed the bound has nothing to count (ident >= thresh <=> mismatches <= L - thresh): most waves skip the epilogue.
+    if (!waveDone) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         unsigned cnt = 0;
@@ -201,7 +207,9 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
         const int n = rowBase + ty + 16 * r;
         if (tx == 0 && n < N && cnt) atomicAdd(&counts[n], cnt);
     }
+    }
     if (offDiag) {
+        if (!waveDone) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             unsigned cnt = 0;
@@ -211,6 +219,7 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
                 if (n < N && (int)(L - mism[r][c]) >= thresh) cnt++;
             }
             if (cnt) atomicAdd(&sCol[tx + 16 * c], cnt);     // integer LDS atomics: order-independent
+        }
         }
         __syncthreads();
         const int m = colBase + threadIdx.x;
