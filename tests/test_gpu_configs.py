@@ -85,6 +85,34 @@ def test_config_C_weights_and_fixed_x_vs_oracle(L_, oracle_plm, msa_C):
         ctx.close()
 
 
+def test_config_D_fixed_x_vs_oracle(L_, oracle_plm):
+    """BASELINE.json's headline configuration itself (D: L=500 N=50k q=21, lambda_h=1, lambda_J=50), the shipped float32 /
+    chunked-scan path at the perturbed point against ONE evaluation of the float64 oracle on the box's host cores (about a
+    minute on 256 cores; skipped on small hosts, where it would take half an hour).  The weights come from the device (their
+    counts are checked against the oracle elsewhere); fx <= 2e-6, gradient <= 1e-5 relative -- this is where the logits
+    kernel's 8 x 96 blocks, the scatter's left-over launch and the 1-slab split all run at full size."""
+    if (os.cpu_count() or 1) < 64:
+        pytest.skip("needs the GPU box's host cores for the oracle evaluation at D")
+    L, N, q = 500, 50000, 21
+    X = dedup(generate(L, N, q, SEEDS["D"]))
+    ctx = _ctx(L_, X, q, L_.DCA_F32, L_.DCA_F32)
+    w = ctx.weights().astype(np.float32)
+    x = perturbed(oracle_plm.init_x(X, w, q), L, q)
+    ctx.plm_configure(LAMBDA_H, LAMBDA_J)
+    ctx.plm_set_x(x)
+    fx = ctx.plm_gradient()
+    g = ctx.plm_get_g(np.float64)
+    ctx.close()
+    fx_o, g_o = oracle_plm.gradient(X, w.astype(np.float64), q, LAMBDA_H, LAMBDA_J, x.astype(np.float64), carry=True)
+    err = rel_err(g, g_o)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "config_D_vs_oracle.json"), "w") as fh:
+        json.dump({"fx_gpu": fx, "fx_oracle": fx_o, "rel_err_fx": abs(fx - fx_o) / abs(fx_o), "rel_err_g": err,
+                   "max_abs_err_g": float(np.abs(g - g_o).max()), "n_unique": int(X.shape[0])}, fh, indent=1)
+    assert abs(fx - fx_o) <= 2e-6 * abs(fx_o), (fx, fx_o)
+    assert err < 1e-5, err
+
+
 def test_config_C_left_over_strips_launch(L_, oracle_plm, msa_C, monkeypatch):
     """The scatter kernel's separate, finer-split launch for the numCT % 8 column strips left over after the full sets
     of eight (config C: 33 strips in float32, 66 in float64): forced on (DCA_SCATTER_REM=1) it must give the gradient
