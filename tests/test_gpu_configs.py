@@ -216,6 +216,25 @@ def test_config_B_mfdca_vs_oracle(L_, oracle_plm, oracle_mf, msa_C):
     ctx.close()
 
 
+def test_config_D_mfdca_vs_oracle(L_, oracle_mf):
+    """The mfDCA half of the headline at its full size (L=500 N=50k q=21, theta 0.5, seqid 0.8, n = 10 000): FN_APC of all
+    124 750 pairs against the numpy float64 restatement (numpy pair counts, LAPACK inverse: about 40 s on the box's host
+    cores; skipped on small hosts) -- <= 1e-9 relative, identical full ranking.  The weights come from the device (their
+    counts are checked elsewhere)."""
+    if (os.cpu_count() or 1) < 64:
+        pytest.skip("needs the GPU box's host cores for the numpy / LAPACK restatement at D")
+    L, N, q = 500, 50000, 21
+    X = dedup(generate(L, N, q, SEEDS["D"]))
+    ctx = _ctx(L_, X, q, L_.DCA_F64, L_.DCA_F64)
+    w64 = ctx.weights().astype(np.float64)
+    s_gpu = ctx.mf_run(0.5, True)
+    order_gpu = ctx.scores_order()
+    ctx.close()
+    s_ref, _ = oracle_mf.mfdca_fn(X.astype(np.int32) + 1, q, 0.5, 0.8, weights=w64, apc_correct=True)
+    np.testing.assert_allclose(s_gpu, s_ref, rtol=1e-9, atol=1e-12)
+    assert np.array_equal(order_gpu, np.argsort(-s_ref, kind="stable"))
+
+
 # ------------------------------------------------------------------------------------------------ P4 report
 def _rankdata(a):
     order = np.argsort(a, kind="stable")
