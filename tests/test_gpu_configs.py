@@ -85,28 +85,33 @@ def test_config_C_weights_and_fixed_x_vs_oracle(L_, oracle_plm, msa_C):
         ctx.close()
 
 
-def test_config_D_fixed_x_vs_oracle(L_, oracle_plm):
-    """BASELINE.json's headline configuration itself (D: L=500 N=50k q=21, lambda_h=1, lambda_J=50), the shipped float32 /
+FULL_SIZE = {"D": (500, 50000, 21, 1.0, 50.0), "E": (150, 200000, 5, 29.8, 29.8)}       # bench.py WORKLOADS
+
+
+@pytest.mark.parametrize("cfg", ["D", "E"])
+def test_config_D_fixed_x_vs_oracle(L_, oracle_plm, cfg):
+    """BASELINE.json's headline configuration itself (D: L=500 N=50k q=21, lambda_h=1, lambda_J=50) and the RNA one (E: L=150
+    N=200k q=5, default lambda = 0.2 (L-1)), the shipped float32 /
     chunked-scan path at the perturbed point against ONE evaluation of the float64 oracle on the box's host cores (about a
     minute on 256 cores; skipped on small hosts, where it would take half an hour).  The weights come from the device (their
     counts are checked against the oracle elsewhere); fx <= 2e-6, gradient <= 1e-5 relative -- this is where the logits
     kernel's 8 x 96 blocks, the scatter's left-over launch and the 1-slab split all run at full size."""
     if (os.cpu_count() or 1) < 64:
         pytest.skip("needs the GPU box's host cores for the oracle evaluation at D")
-    L, N, q = 500, 50000, 21
-    X = dedup(generate(L, N, q, SEEDS["D"]))
+    L, N, q, lh, lJ = FULL_SIZE[cfg]
+    X = dedup(generate(L, N, q, SEEDS[cfg]))
     ctx = _ctx(L_, X, q, L_.DCA_F32, L_.DCA_F32)
     w = ctx.weights().astype(np.float32)
     x = perturbed(oracle_plm.init_x(X, w, q), L, q)
-    ctx.plm_configure(LAMBDA_H, LAMBDA_J)
+    ctx.plm_configure(lh, lJ)
     ctx.plm_set_x(x)
     fx = ctx.plm_gradient()
     g = ctx.plm_get_g(np.float64)
     ctx.close()
-    fx_o, g_o = oracle_plm.gradient(X, w.astype(np.float64), q, LAMBDA_H, LAMBDA_J, x.astype(np.float64), carry=True)
+    fx_o, g_o = oracle_plm.gradient(X, w.astype(np.float64), q, lh, lJ, x.astype(np.float64), carry=True)
     err = rel_err(g, g_o)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "config_D_vs_oracle.json"), "w") as fh:
+    with open(os.path.join(ROOT, "gpurun_out", "config_%s_vs_oracle.json" % cfg), "w") as fh:
         json.dump({"fx_gpu": fx, "fx_oracle": fx_o, "rel_err_fx": abs(fx - fx_o) / abs(fx_o), "rel_err_g": err,
                    "max_abs_err_g": float(np.abs(g - g_o).max()), "n_unique": int(X.shape[0])}, fh, indent=1)
     assert abs(fx - fx_o) <= 2e-6 * abs(fx_o), (fx, fx_o)
@@ -216,15 +221,16 @@ def test_config_B_mfdca_vs_oracle(L_, oracle_plm, oracle_mf, msa_C):
     ctx.close()
 
 
-def test_config_D_mfdca_vs_oracle(L_, oracle_mf):
-    """The mfDCA half of the headline at its full size (L=500 N=50k q=21, theta 0.5, seqid 0.8, n = 10 000): FN_APC of all
-    124 750 pairs against the numpy float64 restatement (numpy pair counts, LAPACK inverse: about 40 s on the box's host
+@pytest.mark.parametrize("cfg", ["D", "E"])
+def test_config_D_mfdca_vs_oracle(L_, oracle_mf, cfg):
+    """The mfDCA half of the headline at its full size (D: L=500 N=50k q=21, theta 0.5, seqid 0.8, n = 10 000; and E: RNA
+    L=150 N=200k q=5): FN_APC of all 124 750 (11 175) pairs against the numpy float64 restatement (numpy pair counts, LAPACK inverse: about 40 s on the box's host
     cores; skipped on small hosts) -- <= 1e-9 relative, identical full ranking.  The weights come from the device (their
     counts are checked elsewhere)."""
     if (os.cpu_count() or 1) < 64:
         pytest.skip("needs the GPU box's host cores for the numpy / LAPACK restatement at D")
-    L, N, q = 500, 50000, 21
-    X = dedup(generate(L, N, q, SEEDS["D"]))
+    L, N, q = FULL_SIZE[cfg][:3]
+    X = dedup(generate(L, N, q, SEEDS[cfg]))
     ctx = _ctx(L_, X, q, L_.DCA_F64, L_.DCA_F64)
     w64 = ctx.weights().astype(np.float64)
     s_gpu = ctx.mf_run(0.5, True)
