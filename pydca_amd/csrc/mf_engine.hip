@@ -109,6 +109,7 @@ __device__ __forceinline__ void lds_add(double* p, double v)
 // Craw[(i,a)][(j,b)] for j > i.  Rows of the site's dominant state are skipped here and
 // completed by mf_complete_kernel from the single-site counts:
 // sum_a Craw[(i,a)][(j,b)] = cnt1[j][b].
+template <bool PREFETCH>
 __global__ __launch_bounds__(kCountThreads)
 void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ w, const uint32_t* __restrict__ perm,
                       const int* __restrict__ off, const uint8_t* __restrict__ dom, double* __restrict__ Craw,
@@ -134,12 +135,25 @@ void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ 
         if (j < L) {
             const uint8_t* Xj = X + j;
             int k = k0;
+            // PREFETCH: the list entries of batch b+1 are requested before the weights / alignment bytes of batch b -- one
+            // dependent round trip per batch instead of two.  It pays where the registers are free: E (q = 5, 10 KB of
+            // LDS per workgroup) 5.5 -> 4.1 ms; D (q = 21: 43 KB of LDS already limit the CU to 12 waves) 4.2 -> 4.6 ms,
+            // so the protein alphabet runs without it.
+            uint32_t nn[U];
+            if (PREFETCH && k + U <= k1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) nn[u] = p[k + u];
+            }
             for (; k + U <= k1; k += U) {
                 uint32_t n[U];
                 double wv[U];
                 int bb[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) n[u] = p[k + u];
+                for (int u = 0; u < U; ++u) n[u] = PREFETCH ? nn[u] : p[k + u];
+                if (PREFETCH && k + 2 * U <= k1) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) nn[u] = p[k + U + u];
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) { wv[u] = w[n[u]]; bb[u] = Xj[(size_t)n[u] * Ls]; }
 #pragma unroll
@@ -325,8 +339,12 @@ static int mf_counts(MfEngine* m)
     {
         ScopedKernelClock kc(ctx, "mf_counts");
         const size_t lds = (size_t)m->q * kCountThreads * sizeof(double);
-        hipLaunchKernelGGL(mf_counts_kernel, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, ctx->dX, ctx->dWd,
-                           m->dPerm, m->dOff, m->dDom, m->dCraw, m->N, m->L, m->Ls, m->q, m->Lq);
+        if (m->q <= 8)
+            hipLaunchKernelGGL(mf_counts_kernel<true>, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, ctx->dX, ctx->dWd,
+                               m->dPerm, m->dOff, m->dDom, m->dCraw, m->N, m->L, m->Ls, m->q, m->Lq);
+        else
+            hipLaunchKernelGGL(mf_counts_kernel<false>, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, ctx->dX, ctx->dWd,
+                               m->dPerm, m->dOff, m->dDom, m->dCraw, m->N, m->L, m->Ls, m->q, m->Lq);
         hipLaunchKernelGGL(mf_complete_kernel, dim3(m->L, m->L), dim3(64), 0, ctx->stream, m->dCraw, m->dCnt1, m->dDom,
                            m->L, m->q, m->Lq);
     }
