@@ -245,6 +245,105 @@ void gemm_nt_f64_kernel(GemmArgs g)
             }
 }
 
+// The deep-k product on 32 x 32 output tiles, for launches that are far fewer than one 64 x 64 tile per CU: a tile's
+// time is its k loop on the matrix pipe (64 cycles per 16 x 16 x 4 MFMA, one wave per SIMD) and 256 CUs are there, so a
+// quarter of the work per workgroup on four times as many CUs is what shortens the chain of small products in the
+// recursion (plain product of n = 640: 34 -> 21 us, n = 256: 16 -> 8, the 2 x 2-tile products of the 256-nodes 10.6 -> 5.2 us;
+// inverse at n = 10 048: 27.1 -> 24.2 ms, at n = 4000: 4.96 -> 3.95 ms).  Same staging as gemm_nt_f64_kernel<64> (one pass of 32 rows per operand), each wave
+// one 16 x 16 accumulator.
+__global__ __launch_bounds__(256)
+void gemm_nt_f64_small_kernel(GemmArgs g)
+{
+    constexpr int TM = 32, BK = 64;
+    constexpr int LDS_STRIDE = BK + 2;
+    constexpr int PG = BK / 16;
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];
+    double* const As = reinterpret_cast<double*>(dca_gemm_smem);      // [2][TM * LDS_STRIDE]
+    double* const Bs = As + 2 * TM * LDS_STRIDE;
+    const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int tj = g.walk == WALK_COLUMNS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x;
+    if (g.lowerOnly && tj > ti) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int kLo = 0, kHi = g.K;
+    if (g.maskA == MASK_LOWER) kHi = min(kHi, (ti + 1) * TM);
+    if (g.maskA == MASK_UPPER) kLo = max(kLo, ti * TM);
+    if (g.maskB == MASK_LOWER) kHi = min(kHi, (tj + 1) * TM);
+    if (g.maskB == MASK_UPPER) kLo = max(kLo, tj * TM);
+    kLo = kLo / BK * BK;
+    const int nk = (kHi - kLo + BK - 1) / BK;
+
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int sr = tid >> 3, sp = (tid & 7) * 2;                      // row 0 .. 31, doubles sp + 16 pg, + 1 of the k-tile
+    const double* Ap = g.A + (size_t)(ti * TM + sr) * g.lda + sp;
+    const double* Bp = g.B + (size_t)(tj * TM + sr) * g.ldb + sp;
+    double2_t ra[PG], rb[PG];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) {
+            ra[pg] = *reinterpret_cast<const double2_t*>(Ap + k0 + 16 * pg);
+            rb[pg] = *reinterpret_cast<const double2_t*>(Bp + k0 + 16 * pg);
+        }
+    };
+    auto store_tile = [&](int buf, int k0) {
+        const bool diagA = g.maskA != MASK_NONE && k0 + BK > ti * TM && k0 < (ti + 1) * TM;
+        const bool diagB = g.maskB != MASK_NONE && k0 + BK > tj * TM && k0 < (tj + 1) * TM;
+        if (diagA || diagB) {
+            const int aRow = ti * TM + sr, bRow = tj * TM + sr;
+            const int aLo = g.maskA == MASK_UPPER ? aRow : INT_MIN, aHi = g.maskA == MASK_LOWER ? aRow : INT_MAX;
+            const int bLo = g.maskB == MASK_UPPER ? bRow : INT_MIN, bHi = g.maskB == MASK_LOWER ? bRow : INT_MAX;
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = k0 + 16 * pg + sp + u;
+                    ra[pg][u] = (k < aLo || k > aHi) ? 0.0 : ra[pg][u];
+                    rb[pg][u] = (k < bLo || k > bHi) ? 0.0 : rb[pg][u];
+                }
+        }
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) {
+            *reinterpret_cast<double2_t*>(As + buf * TM * LDS_STRIDE + sr * LDS_STRIDE + 16 * pg + sp) = ra[pg];
+            *reinterpret_cast<double2_t*>(Bs + buf * TM * LDS_STRIDE + sr * LDS_STRIDE + 16 * pg + sp) = rb[pg];
+        }
+    };
+    auto mma_tile = [&](int buf) {
+        const double* as = As + buf * TM * LDS_STRIDE;
+        const double* bs = Bs + buf * TM * LDS_STRIDE;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const int kcol = kk * 8 + 2 * (lane >> 4);
+            const double2_t a = *reinterpret_cast<const double2_t*>(&as[(wm * 16 + (lane & 15)) * LDS_STRIDE + kcol]);
+            const double2_t b = *reinterpret_cast<const double2_t*>(&bs[(wn * 16 + (lane & 15)) * LDS_STRIDE + kcol]);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc, 0, 0, 0);
+        }
+    };
+    if (nk > 0) { load_tile(kLo); store_tile(0, kLo); }
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) load_tile(kLo + (t + 1) * BK);
+        mma_tile(buf);
+        if (t + 1 < nk) store_tile(buf ^ 1, kLo + (t + 1) * BK);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = ti * TM + wm * 16 + (lane >> 4) + 4 * r;
+        const int j = tj * TM + wn * 16 + (lane & 15);
+        if (g.lowerOnly && j > i) continue;
+        double v = g.alpha * acc[r];
+        double* cp = g.C + (size_t)i * g.ldc + j;
+        if (g.beta != 0.0) v += g.beta * (*cp);
+        *cp = v;
+        if (g.Cm && !(g.lowerOnly && i == j)) g.Cm[(size_t)j * g.ldcm + i] = v;
+    }
+}
+
 // The same product with the operand tiles brought into LDS by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight
 // from global memory into LDS, no staging registers and no ds_write).  In the kernel above a quarter of the matrix-core
 // time is lost around the register -> LDS stores (tools/experiments/gemm_bench.hip -DDCA_GEMM_ABLATE=2: 59.6 -> 66.2 TF
@@ -850,6 +949,19 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
     dim3 grid(g.N / BN, g.M / BM);
     if (g.walk == WALK_COLUMNS_REVERSED) grid = dim3(g.M / BM, g.N / BN);
     static const int deepMaxTiles = getenv("DCA_GEMM_DEEP_MAX_TILES") ? atoi(getenv("DCA_GEMM_DEEP_MAX_TILES")) : 400;
+    static const int small32Max = getenv("DCA_GEMM_SMALL32_MAX") ? atoi(getenv("DCA_GEMM_SMALL32_MAX")) : 400;     // 0: the 64 x 64 deep kernel below
+    // inverse at n = 10 048 / 4000 by this bound: 0 -> 27.1 / 4.96 ms, 16 -> 25.8 / 4.36, 128 -> 24.7 / 4.08, 400 -> 24.2 / 3.95, 1200 -> 23.9 / 4.01, 1600 -> 24.8 / 3.99
+    if ((long long)grid.x * grid.y <= small32Max) {          // far fewer tiles than CUs: 32 x 32 tiles on four times as many CUs
+        dim3 g32(grid.x * 2, grid.y * 2);
+        const size_t lds = (size_t)2 * (32 + 32) * (64 + 2) * sizeof(double);
+        static bool attr32 = false;
+        if (!attr32) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr32 = true;
+        }
+        hipLaunchKernelGGL(gemm_nt_f64_small_kernel, g32, dim3(256), lds, ctx->stream, g);
+        return DCA_OK;
+    }
     if ((long long)grid.x * grid.y <= deepMaxTiles) {       // under two workgroups per CU: latency bound (measured: 0 -> 37.7, 128 -> 37.0, 400 -> 36.4, 1600 -> 36.9 ms)
         static bool attr = false;
         if (!attr) {
