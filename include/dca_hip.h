@@ -137,6 +137,9 @@ int dca_comm_destroy(dca_ctx* ctx);
  *   mode 1: all-reduce(sum) of the gradient and of fx after every evaluation, optimiser vectors replicated;
  *   mode 2: sharded optimiser vectors -- reduce-scatter(g) per evaluation, all-gather(x) per step, scalar all-reduces
  *           (the scheme of dca_plm_set_vector_sharding; rank / world are the communicator's);
+ *   mode 3: mode 2 with the two vector collectives as a DIRECT EXCHANGE -- grouped ncclSend / ncclRecv of slice j
+ *           straight to rank j (every xGMI link of the mesh busy at once) and a local sum of the received pieces in
+ *           rank order -- for topologies / sizes where RCCL would run its reduce-scatter and all-gather as rings;
  *   mode 0: off.  Replaces any hook set with dca_plm_set_reduce_hook / dca_plm_set_vector_sharding. */
 int dca_plm_set_native_comm(dca_ctx* ctx, int mode);
 

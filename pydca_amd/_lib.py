@@ -213,10 +213,10 @@ class Context:
         assert w.shape == (self.N,)
         check(self._l.dca_set_weights(self._h, _ptr(w)))
 
-    def compute_weights_sharded(self, seqid, compare_precision=None):
-        """Weights with the comparisons divided over the ranks of the context's communicator (comm_init first)."""
-        cp = self.precision if compare_precision is None else compare_precision
-        check(self._l.dca_compute_weights_sharded(self._h, float(seqid), int(cp)))
+    def compute_weights_sharded(self, seqid, compare_precision=DCA_F32):
+        """Weights with the comparisons divided over the ranks of the context's communicator (comm_init first).
+        Same default compare precision as compute_weights, so the two give the same counts at threshold ties."""
+        check(self._l.dca_compute_weights_sharded(self._h, float(seqid), int(compare_precision)))
         return self.weights()
 
     def weights_partial_counts(self, seqid, compare_precision, part, parts):
@@ -240,7 +240,8 @@ class Context:
         check(self._l.dca_comm_destroy(self._h))
 
     def plm_set_native_comm(self, mode):
-        """0 off, 1 all-reduce of g and fx per evaluation, 2 sharded optimiser vectors."""
+        """0 off, 1 all-reduce of g and fx per evaluation, 2 sharded optimiser vectors (RCCL reduce-scatter / all-gather),
+        3 sharded optimiser vectors by direct exchange (grouped send / recv + rank-ordered local sum)."""
         check(self._l.dca_plm_set_native_comm(self._h, int(mode)))
 
     def mf_set_native_comm(self, on=True):

@@ -331,10 +331,12 @@ int dca_set_msa(dca_ctx* ctx, const uint8_t* X, int N, int L, int q)
 
 // Everything the engines derived from the weights (the plmDCA engine's copy, frequencies, counts, correlation matrix,
 // couplings) is dropped when the weights change: the next call recomputes it instead of answering for the old weights.
+// The engines themselves stay (with their reduce / comm hooks, native-comm mode and vector sharding): a sharded context that
+// is re-weighted must not fall back to unreduced local sums.  The plmDCA engine has to be configured again.
 static void weights_changed(dca_ctx* ctx)
 {
-    delete ctx->plm; ctx->plm = nullptr;
-    if (ctx->mf) { dca_free_mf_engine(ctx->mf); ctx->mf = nullptr; }
+    if (ctx->plm) ctx->plm->weights_changed();
+    if (ctx->mf) dca_mf_engine_invalidate(ctx->mf);
 }
 
 int dca_compute_weights(dca_ctx* ctx, double seqid, int compare_precision)
@@ -506,6 +508,11 @@ int dca_comm_init(dca_ctx* ctx, const char* rccl_path, const void* id128, int wo
 {
     CHECK_CTX(ctx);
     if (!id128) return DCA_ERR_ARG;
+    // slices and reductions configured for the previous communicator's world / rank do not carry over
+    if (ctx->comm) {
+        if (ctx->plm) ctx->plm->set_native_comm(0);
+        if (ctx->mf) dca_mf_engine_set_native(ctx->mf, false);
+    }
     return dca_comm_init_impl(ctx, rccl_path, id128, world, rank);
 }
 int dca_comm_destroy(dca_ctx* ctx)
@@ -520,8 +527,7 @@ int dca_plm_set_native_comm(dca_ctx* ctx, int mode)
 {
     CHECK_CTX(ctx);
     if (!ctx->plm) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
-    ctx->plm->hook = nullptr; ctx->plm->hook_user = nullptr;
-    return ctx->plm->set_native_comm(mode);
+    return ctx->plm->set_native_comm(mode);        // drops the caller's hook only once the mode has been validated
 }
 int dca_mf_set_native_comm(dca_ctx* ctx, int on)
 {

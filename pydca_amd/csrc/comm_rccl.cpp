@@ -6,6 +6,9 @@
 // No reference counterpart: pydca is single-process.
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <mutex>
+
 #include "dca_internal.h"
 
 namespace {
@@ -26,12 +29,14 @@ struct RcclApi {
     int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
 };
 RcclApi g_api;
 
-template <typename F> bool bind(F& fn, const char* name)
+template <typename F> bool bind(void* handle, F& fn, const char* name)
 {
-    fn = reinterpret_cast<F>(dlsym(g_api.handle, name));
+    fn = reinterpret_cast<F>(dlsym(handle, name));
     if (!fn) dca_set_error("librccl lacks %s", name);
     return fn != nullptr;
 }
@@ -50,22 +55,31 @@ std::string rccl_next_to_hip(const char* file)
     return dir.substr(0, slash + 1) + file;
 }
 
+// One thread binds the API; the table is published (handle set) only when every entry point is resolved, so a second
+// thread never sees a handle with null function pointers behind it (ctypes releases the GIL around these calls).
+std::mutex g_api_mu;
 int load_api(const char* path)
 {
+    std::lock_guard<std::mutex> lk(g_api_mu);
     if (g_api.handle) return DCA_OK;
     const std::string near1 = rccl_next_to_hip("librccl.so.1"), near2 = rccl_next_to_hip("librccl.so");
     const char* candidates[] = {path, getenv("DCA_RCCL_PATH"), near1.c_str(), near2.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
     for (const char* c : candidates) {
         if (!c || !*c) continue;
-        g_api.handle = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
-        if (g_api.handle) break;
+        h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
     }
-    if (!g_api.handle) { dca_set_error("cannot open librccl.so (%s)", dlerror()); return DCA_ERR_IO; }
-    bool ok = bind(g_api.GetUniqueId, "ncclGetUniqueId") && bind(g_api.CommInitRank, "ncclCommInitRank") &&
-              bind(g_api.CommDestroy, "ncclCommDestroy") && bind(g_api.GetErrorString, "ncclGetErrorString") &&
-              bind(g_api.AllReduce, "ncclAllReduce") && bind(g_api.ReduceScatter, "ncclReduceScatter") &&
-              bind(g_api.AllGather, "ncclAllGather") && bind(g_api.GroupStart, "ncclGroupStart") && bind(g_api.GroupEnd, "ncclGroupEnd");
-    if (!ok) { dlclose(g_api.handle); g_api = RcclApi(); return DCA_ERR_IO; }
+    if (!h) { dca_set_error("cannot open librccl.so (%s)", dlerror()); return DCA_ERR_IO; }
+    RcclApi api;
+    bool ok = bind(h, api.GetUniqueId, "ncclGetUniqueId") && bind(h, api.CommInitRank, "ncclCommInitRank") &&
+              bind(h, api.CommDestroy, "ncclCommDestroy") && bind(h, api.GetErrorString, "ncclGetErrorString") &&
+              bind(h, api.AllReduce, "ncclAllReduce") && bind(h, api.ReduceScatter, "ncclReduceScatter") &&
+              bind(h, api.AllGather, "ncclAllGather") && bind(h, api.GroupStart, "ncclGroupStart") && bind(h, api.GroupEnd, "ncclGroupEnd") &&
+              bind(h, api.Send, "ncclSend") && bind(h, api.Recv, "ncclRecv");
+    if (!ok) { dlclose(h); return DCA_ERR_IO; }
+    api.handle = h;
+    g_api = api;
     return DCA_OK;
 }
 
@@ -92,8 +106,8 @@ int dca_comm_init_impl(dca_ctx* ctx, const char* rccl_path, const void* id128, i
 {
     if (world < 1 || rank < 0 || rank >= world) { dca_set_error("dca_comm_init: bad rank / world"); return DCA_ERR_ARG; }
     DCA_TRY(load_api(rccl_path));
-    if (ctx->comm) { g_api.CommDestroy(static_cast<RcclComm>(ctx->comm)); ctx->comm = nullptr; }
     HIP_TRY(hipSetDevice(ctx->device));
+    dca_comm_destroy_impl(ctx);       // drains the stream first: collectives of the old communicator may still be queued
     RcclUniqueId id;
     memcpy(id.internal, id128, sizeof(id.internal));
     RcclComm comm = nullptr;
@@ -112,11 +126,82 @@ void dca_comm_destroy_impl(dca_ctx* ctx)
     }
     ctx->comm = nullptr;
     ctx->comm_world = 0;
+    dca_dev_free(ctx->commStage); ctx->commStage = nullptr; ctx->commStageBytes = 0;
 }
 
 // ---- the three collectives of the sharded optimiser, enqueued on ctx->stream (dca_comm_hook semantics: in place,
 // `count` = whole vector; slices are count / world elements, rank r owns [r * slice, (r + 1) * slice))
-int dca_comm_native(dca_ctx* ctx, int op, void* buf, size_t count, int dtype)
+namespace {
+// mine[e] = sum over the ranks, IN RANK ORDER, of their pieces of this rank's slice: piece r comes from `stage` (the
+// pieces received from the other ranks, packed in rank order without this rank's own) or, for r == rank, from `mine`
+// itself.  A fixed order makes the owner's sum reproducible from run to run whatever order the pieces arrived in.
+template <typename T>
+__global__ __launch_bounds__(256)
+void comm_sum_pieces_kernel(T* __restrict__ mine, const T* __restrict__ stage, size_t slice, int world, int rank)
+{
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < slice; e += (size_t)gridDim.x * blockDim.x) {
+        T acc = rank == 0 ? mine[e] : stage[e];
+        for (int r = 1; r < world; ++r)
+            acc += r == rank ? mine[e] : stage[(size_t)(r < rank ? r : r - 1) * slice + e];
+        mine[e] = acc;
+    }
+}
+}  // namespace
+
+// Direct exchange (dca_plm_set_native_comm mode 3).  xGMI is a full mesh of point-to-point links, so a reduce-scatter can
+// send slice j straight to rank j over the link that joins the two GPUs -- world - 1 concurrent transfers of
+// count / world elements per rank, every link busy at once -- where a ring pushes (world - 1) / world of the vector
+// through ONE link per hop.  The pieces land in a staging buffer ((world - 1) slices) and are summed locally in rank order;
+// the all-gather is the same pattern with no sum and no staging (slice j of rank j lands in place).
+static int comm_direct(dca_ctx* ctx, int op, void* buf, size_t count, int dtype)
+{
+    RcclComm comm = static_cast<RcclComm>(ctx->comm);
+    const int world = ctx->comm_world, rank = ctx->comm_rank;
+    const size_t esz = dtype == DCA_F32 ? 4 : 8;
+    const size_t slice = count / (size_t)world;
+    char* base = static_cast<char*>(buf);
+    if (world == 1) return DCA_OK;
+    if (op == DCA_COMM_REDUCE_SCATTER) {
+        const size_t need = (size_t)(world - 1) * slice * esz;
+        if (ctx->commStageBytes < need) {
+            dca_dev_free(ctx->commStage); ctx->commStage = nullptr; ctx->commStageBytes = 0;
+            HIP_TRY(dca_dev_malloc(&ctx->commStage, need, false));
+            ctx->commStageBytes = need;
+        }
+        char* stage = static_cast<char*>(ctx->commStage);
+        RCCL_TRY(g_api.GroupStart());
+        int bad = 0;
+        for (int k = 1; k < world && !bad; ++k) {               // partner order rotated by rank: no two ranks start on the same peer
+            const int to = (rank + k) % world, from = (rank - k + world) % world;
+            bad = g_api.Send(base + (size_t)to * slice * esz, slice, rccl_type(dtype), to, comm, ctx->stream);
+            if (!bad) bad = g_api.Recv(stage + (size_t)(from < rank ? from : from - 1) * slice * esz, slice, rccl_type(dtype), from, comm, ctx->stream);
+        }
+        RCCL_TRY(g_api.GroupEnd());
+        RCCL_TRY(bad);
+        const unsigned blocks = (unsigned)std::min<size_t>((slice + 255) / 256, 256 * 8);
+        if (dtype == DCA_F32)
+            hipLaunchKernelGGL(comm_sum_pieces_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<float*>(base + (size_t)rank * slice * esz), reinterpret_cast<const float*>(stage), slice, world, rank);
+        else
+            hipLaunchKernelGGL(comm_sum_pieces_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<double*>(base + (size_t)rank * slice * esz), reinterpret_cast<const double*>(stage), slice, world, rank);
+        HIP_TRY(hipGetLastError());
+        return DCA_OK;
+    }
+    // all-gather: this rank's slice to every peer, every peer's slice into its place
+    RCCL_TRY(g_api.GroupStart());
+    int bad = 0;
+    for (int k = 1; k < world && !bad; ++k) {
+        const int to = (rank + k) % world, from = (rank - k + world) % world;
+        bad = g_api.Send(base + (size_t)rank * slice * esz, slice, rccl_type(dtype), to, comm, ctx->stream);
+        if (!bad) bad = g_api.Recv(base + (size_t)from * slice * esz, slice, rccl_type(dtype), from, comm, ctx->stream);
+    }
+    RCCL_TRY(g_api.GroupEnd());
+    RCCL_TRY(bad);
+    return DCA_OK;
+}
+
+int dca_comm_native(dca_ctx* ctx, int op, void* buf, size_t count, int dtype, bool direct)
 {
     if (!ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
     RcclComm comm = static_cast<RcclComm>(ctx->comm);
@@ -125,6 +210,7 @@ int dca_comm_native(dca_ctx* ctx, int op, void* buf, size_t count, int dtype)
         RCCL_TRY(g_api.AllReduce(buf, buf, count, rccl_type(dtype), kRcclSum, comm, ctx->stream));
         return DCA_OK;
     }
+    if (direct) return comm_direct(ctx, op, buf, count, dtype);
     const size_t slice = count / (size_t)ctx->comm_world;
     char* mine = static_cast<char*>(buf) + (size_t)ctx->comm_rank * slice * esz;      // the in-place forms of both collectives
     if (op == DCA_COMM_REDUCE_SCATTER) RCCL_TRY(g_api.ReduceScatter(buf, mine, slice, rccl_type(dtype), kRcclSum, comm, ctx->stream));

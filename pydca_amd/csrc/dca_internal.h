@@ -82,6 +82,8 @@ struct dca_ctx {
     // native communicator (comm_rccl.cpp): an RCCL communicator whose collectives run on `stream`
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 0;
+    void* commStage = nullptr;        // pieces received by the direct-exchange reduce-scatter ((world - 1) slices)
+    size_t commStageBytes = 0;
 
     bool profiling = false;
     std::map<std::string, KernelClock> clocks;
@@ -124,7 +126,7 @@ int dca_weights_finish(dca_ctx* ctx);     // w = 1 / count, Meff from ctx->dCoun
 int dca_comm_unique_id_impl(const char* rccl_path, void* id128);
 int dca_comm_init_impl(dca_ctx* ctx, const char* rccl_path, const void* id128, int world, int rank);
 void dca_comm_destroy_impl(dca_ctx* ctx);
-int dca_comm_native(dca_ctx* ctx, int op, void* buf, size_t count, int dtype);
+int dca_comm_native(dca_ctx* ctx, int op, void* buf, size_t count, int dtype, bool direct = false);   // direct: grouped send / recv + local sum
 int dca_comm_native_reduce(dca_ctx* ctx, void* vec, size_t count, int dtype, double* scalar_dev);
 int dca_comm_native_sum_u32(dca_ctx* ctx, uint32_t* buf, size_t count);
 
@@ -151,7 +153,8 @@ struct PlmEngineBase {
     virtual int set_vector_sharding(int rank, int world, dca_comm_hook hook, void* user) = 0;
     dca_reduce_hook hook = nullptr;
     void* hook_user = nullptr;
-    virtual int set_native_comm(int mode) = 0;     // 0 off, 1 all-reduce of g and fx, 2 sharded optimiser vectors
+    virtual void weights_changed() = 0;            // dca_compute_weights* / dca_set_weights ran: configure again, exchange scheme kept
+    virtual int set_native_comm(int mode) = 0;     // 0 off, 1 all-reduce of g and fx, 2 sharded optimiser vectors, 3 the same by direct exchange
     int native_mode = 0;                           // ... through ctx->comm (RCCL) on the context's stream
 };
 PlmEngineBase* dca_make_plm_engine(dca_ctx* ctx);
@@ -184,6 +187,7 @@ int dca_mf_engine_di(MfEngine*, int apc, double* out);
 int dca_mf_engine_fields(MfEngine*, double* out);
 void dca_mf_engine_set_hook(MfEngine*, dca_reduce_hook hook, void* user);
 void dca_mf_engine_set_native(MfEngine*, bool on);
+void dca_mf_engine_invalidate(MfEngine*);      // weights changed: counts, frequencies, C and J are recomputed on demand
 int dca_mf_engine_pair_couplings(MfEngine*, const int* pairs, int npairs, int shift, double* out);
 
 // ---- cholinv.hip : scale * inverse of an SPD matrix on the device (f64 MFMA)

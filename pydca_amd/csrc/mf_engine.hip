@@ -300,6 +300,8 @@ struct MfEngine {
     dca_reduce_hook hook = nullptr;   // sequence sharding: sums Craw and Meff over the shards
     void* hook_user = nullptr;
     bool native_reduce = false;       // the same sum through ctx->comm (RCCL on the context's stream)
+    double meff = 0.0;                // Meff the frequencies are normalised by: ctx->meff (this context's weights) summed over
+                                      // the shards when a hook / the native reduction is set; ctx->meff itself stays local
     ~MfEngine() { dca_dev_free(dRegFi); dca_dev_free(dPerm); dca_dev_free(dOff); dca_dev_free(dXT); dca_dev_free(dDom); dca_dev_free(dCnt1); dca_dev_free(dCraw); dca_dev_free(dFi); dca_dev_free(dC); dca_dev_free(dWork); }
 };
 
@@ -348,10 +350,11 @@ static int mf_counts(MfEngine* m)
         hipLaunchKernelGGL(mf_complete_kernel, dim3(m->L, m->L), dim3(64), 0, ctx->stream, m->dCraw, m->dCnt1, m->dDom,
                            m->L, m->q, m->Lq);
     }
+    m->meff = ctx->meff;
     if (m->hook || m->native_reduce) {
         // the counts are linear in the sequences: shards hold contiguous blocks of the alignment with the
         // GLOBAL weights, the hook sums the Lq x Lq raw counts and the effective sequence number in place
-        HIP_TRY(hipMemcpyAsync(ctx->dScal, &ctx->meff, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->dScal, &m->meff, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         if (m->native_reduce) {
             DCA_TRY(dca_comm_native_reduce(ctx, m->dCraw, (size_t)m->Lq * m->Lq, DCA_F64, ctx->dScal));
         } else {
@@ -361,10 +364,10 @@ static int mf_counts(MfEngine* m)
                 return DCA_ERR_ARG;
             }
         }
-        HIP_TRY(hipMemcpyAsync(&ctx->meff, ctx->dScal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(&m->meff, ctx->dScal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));      // Meff is a kernel argument below
     }
-    hipLaunchKernelGGL(mf_fi_kernel, dim3(ceil_div(m->Lq, 256)), dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->Lq, m->Lq, ctx->meff);
+    hipLaunchKernelGGL(mf_fi_kernel, dim3(ceil_div(m->Lq, 256)), dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->Lq, m->Lq, m->meff);
     HIP_TRY(hipGetLastError());
     m->have_counts = true;
     return DCA_OK;
@@ -385,7 +388,7 @@ int dca_mf_engine_pair_freqs(MfEngine* m, double* fij_out)
     const size_t total = (size_t)m->L * (m->L - 1) / 2 * qm * qm;
     double* dOut = nullptr;
     HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dOut), total * sizeof(double)));
-    hipLaunchKernelGGL(mf_fij_export_kernel, dim3(m->L, m->L), dim3(64), 0, m->ctx->stream, m->dCraw, dOut, m->L, m->q, m->Lq, m->ctx->meff);
+    hipLaunchKernelGGL(mf_fij_export_kernel, dim3(m->L, m->L), dim3(64), 0, m->ctx->stream, m->dCraw, dOut, m->L, m->q, m->Lq, m->meff);
     hipError_t e = hipStreamSynchronize(m->ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(fij_out, dOut, total * sizeof(double), hipMemcpyDeviceToHost);
     dca_dev_free(dOut);
@@ -407,9 +410,9 @@ static int mf_build_corr(MfEngine* m, double theta)
     dca_ctx* ctx = m->ctx;
     if (!m->dC) HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dC), (size_t)m->np * m->np * sizeof(double), false));
     dim3 grid(ceil_div(m->np, 256), m->np);
-    if (m->q == 21) hipLaunchKernelGGL(mf_corr_kernel<21>, grid, dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->dC, m->L, m->q, m->Lq, m->np, ctx->meff, theta);
-    else if (m->q == 5) hipLaunchKernelGGL(mf_corr_kernel<5>, grid, dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->dC, m->L, m->q, m->Lq, m->np, ctx->meff, theta);
-    else hipLaunchKernelGGL(mf_corr_kernel<0>, grid, dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->dC, m->L, m->q, m->Lq, m->np, ctx->meff, theta);
+    if (m->q == 21) hipLaunchKernelGGL(mf_corr_kernel<21>, grid, dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->dC, m->L, m->q, m->Lq, m->np, m->meff, theta);
+    else if (m->q == 5) hipLaunchKernelGGL(mf_corr_kernel<5>, grid, dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->dC, m->L, m->q, m->Lq, m->np, m->meff, theta);
+    else hipLaunchKernelGGL(mf_corr_kernel<0>, grid, dim3(256), 0, ctx->stream, m->dCraw, m->dFi, m->dC, m->L, m->q, m->Lq, m->np, m->meff, theta);
     HIP_TRY(hipGetLastError());
     m->corr_on_device = true;
     return DCA_OK;
@@ -568,11 +571,19 @@ int dca_mf_engine_pair_couplings(MfEngine* m, const int* pairs, int npairs, int 
     return dca_pair_blocks(m->ctx, m->dJ, 1, DCA_F64, m->L, m->q, m->np, pairs, npairs, shift, out);
 }
 
-void dca_mf_engine_set_native(MfEngine* m, bool on) { m->native_reduce = on; if (on) { m->hook = nullptr; m->hook_user = nullptr; } }
+// Counts, frequencies, correlation matrix and couplings cached so far were summed under the previous exchange scheme (or the
+// previous weights): they are recomputed by the next query instead of answering for a single shard.
+void dca_mf_engine_invalidate(MfEngine* m) { m->have_counts = m->have_corr = m->have_J = m->corr_on_device = false; }
+void dca_mf_engine_set_native(MfEngine* m, bool on)
+{
+    if (on != m->native_reduce || (on && m->hook)) dca_mf_engine_invalidate(m);
+    m->native_reduce = on;
+    if (on) { m->hook = nullptr; m->hook_user = nullptr; }
+}
 void dca_mf_engine_set_hook(MfEngine* m, dca_reduce_hook hook, void* user)
 {
     m->hook = hook;
     m->hook_user = user;
     m->native_reduce = false;
-    m->have_counts = m->have_corr = m->have_J = m->corr_on_device = false;
+    dca_mf_engine_invalidate(m);
 }

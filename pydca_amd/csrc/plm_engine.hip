@@ -1036,6 +1036,7 @@ struct PlmEngine : PlmEngineBase {
     size_t vlo = 0, vn = 0, Ppad = 0;
     dca_comm_hook comm = nullptr;
     void* comm_user = nullptr;
+    int comm_rank = 0, comm_world = 0;      // of the hook-driven sharding, so that configure() can cut the slices again
 
     // optimiser state (resumable)
     struct {
@@ -1063,6 +1064,10 @@ struct PlmEngine : PlmEngineBase {
     ~PlmEngine() override { freeall(); }
 
     int jt() const { return logits_jt(q); }
+
+    // the engine's copy of the weights (dw, made by configure) is stale: everything answers DCA_ERR_STATE until the caller
+    // configures again; hooks, native mode and vector sharding are kept (configure re-applies them)
+    void weights_changed() override { configured = false; o = decltype(o)(); }
 
     int configure(double lh, double lJ, int cmode, int chunk_, int warm_, int halo_, int add_reg_) override
     {
@@ -1169,7 +1174,16 @@ struct PlmEngine : PlmEngineBase {
 
         HIP_TRY(hipMemsetAsync(dx, 0, (P + kVecPad) * sizeof(T), ctx->stream));
         HIP_TRY(hipMemsetAsync(dg, 0, (P + kVecPad) * sizeof(T), ctx->stream));
-        vlo = 0; vn = P; Ppad = P; comm = nullptr; comm_user = nullptr;
+        // the exchange scheme (reduce hook, vector-sharding hook, native mode) survives a re-configuration -- a context whose
+        // weights changed must be configured again and would otherwise silently fall back to unreduced local sums
+        vlo = 0; vn = P; Ppad = P;
+        if (native_mode >= 2) {
+            if (!ctx->comm) native_mode = 0;
+            else DCA_TRY(set_slices(ctx->comm_rank, ctx->comm_world));
+        } else if (comm) {
+            DCA_TRY(set_slices(comm_rank, comm_world));
+        }
+        if (native_mode == 1 && !ctx->comm) native_mode = 0;
         HIP_TRY(hipMemsetAsync(dWt, 0, (size_t)Wrows * Cs * sizeof(T), ctx->stream));
         HIP_TRY(hipMemsetAsync(dG, 0, (size_t)std::max(scatSplit, scatRemSplit) * Grows * Cs * sizeof(T), ctx->stream));
 
@@ -1362,7 +1376,7 @@ struct PlmEngine : PlmEngineBase {
         int rc = (q == 21) ? launch_eval<21>() : launch_eval<5>();
         if (rc != DCA_OK) return rc;
         o.evals += 1;
-        if (comm || native_mode == 2) {
+        if (comm || native_mode >= 2) {
             // sharded vectors: sum the shards' gradients, keep this rank's slice; fx is summed with the
             // scalars of the caller (eval_scalars / gradient)
             DCA_TRY(do_comm(DCA_COMM_REDUCE_SCATTER, dg, Ppad, (int)sizeof(T) * 8, "reduce-scatter"));
@@ -1383,30 +1397,30 @@ struct PlmEngine : PlmEngineBase {
     // or through the caller's hook (the stream is drained first: the hook works outside it)
     int do_comm(int op, void* buf, size_t count, int dtype, const char* what)
     {
-        if (native_mode == 2) return dca_comm_native(ctx, op, buf, count, dtype);
+        if (native_mode >= 2) return dca_comm_native(ctx, op, buf, count, dtype, native_mode == 3);
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (comm(comm_user, op, buf, count, dtype) != 0) { dca_set_error("comm hook failed (%s)", what); return DCA_ERR_ARG; }
         return DCA_OK;
     }
     int reduce_scalars(int first, int count)
     {
-        if (!comm && native_mode != 2) return DCA_OK;
+        if (!comm && native_mode < 2) return DCA_OK;
         return do_comm(DCA_COMM_ALL_REDUCE, ctx->dScal + first, (size_t)count, DCA_F64, "all-reduce");
     }
     // make a P-vector whose slices are valid on their owners valid everywhere
     int gather_vector(T* v)
     {
-        if (!comm && native_mode != 2) return DCA_OK;
+        if (!comm && native_mode < 2) return DCA_OK;
         return do_comm(DCA_COMM_ALL_GATHER, v, Ppad, (int)sizeof(T) * 8, "all-gather");
     }
     int set_vector_sharding(int rank, int world, dca_comm_hook h, void* user) override
     {
         if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
         if (o.begun && !o.finished) { dca_set_error("vector sharding cannot change during an optimisation"); return DCA_ERR_STATE; }
-        if (native_mode == 2) native_mode = 0;
-        if (!h || world < 1) { vlo = 0; vn = P; Ppad = P; comm = nullptr; comm_user = nullptr; return DCA_OK; }
+        if (native_mode >= 2) native_mode = 0;
+        if (!h || world < 1) { vlo = 0; vn = P; Ppad = P; comm = nullptr; comm_user = nullptr; comm_rank = comm_world = 0; return DCA_OK; }
         DCA_TRY(set_slices(rank, world));
-        comm = h; comm_user = user;
+        comm = h; comm_user = user; comm_rank = rank; comm_world = world;
         return DCA_OK;
     }
     int set_slices(int rank, int world)
@@ -1424,10 +1438,11 @@ struct PlmEngine : PlmEngineBase {
         if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
         if (o.begun && !o.finished) { dca_set_error("the exchange scheme cannot change during an optimisation"); return DCA_ERR_STATE; }
         if (mode != 0 && !ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
-        if (mode < 0 || mode > 2) return DCA_ERR_ARG;
-        comm = nullptr; comm_user = nullptr;
-        vlo = 0; vn = P; Ppad = P;
-        if (mode == 2) DCA_TRY(set_slices(ctx->comm_rank, ctx->comm_world));
+        if (mode < 0 || mode > 3) return DCA_ERR_ARG;
+        if (mode >= 2) DCA_TRY(set_slices(ctx->comm_rank, ctx->comm_world));      // validate before anything is dropped
+        else { vlo = 0; vn = P; Ppad = P; }
+        comm = nullptr; comm_user = nullptr; comm_rank = comm_world = 0;
+        if (mode != 0) { hook = nullptr; hook_user = nullptr; }                   // the native exchange replaces the caller's hook
         native_mode = mode;
         return DCA_OK;
     }
@@ -1548,7 +1563,7 @@ struct PlmEngine : PlmEngineBase {
             if (!have_dginit) {
                 have_dginit = true;
                 dginit = o.dginit;
-                if (0 < dginit) { o.evals -= 1; return LB_INCREASEGRADIENT; }    // the reference returns before evaluating (lbfgs.cpp:858-861); the caller restores x, g
+                if (0 < dginit) { o.evals -= 1; *f = finit; return LB_INCREASEGRADIENT; }    // the reference returns before evaluating (lbfgs.cpp:858-861); the caller restores x, g
                 dgtest = ftol * dginit;
                 bx.d = by.d = dginit;
             }

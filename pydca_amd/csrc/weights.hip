@@ -253,19 +253,26 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int p
         const int G = ctx->Ls / 32;
         const bool small = ctx->q <= 8;
         const int PLP = small ? 4 : 6;
-        uint32_t* dP = nullptr;
-        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dP), (size_t)N * G * PLP * sizeof(uint32_t)));
-        // column order (most variable sites first), from unweighted single-site counts
-        uint32_t* dHist = nullptr; int* dPerm = nullptr;
-        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dHist), (size_t)L * 32 * sizeof(uint32_t)));
-        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dPerm), (size_t)ctx->Ls * sizeof(int)));
-        HIP_TRY(hipMemsetAsync(dHist, 0, (size_t)L * 32 * sizeof(uint32_t), ctx->stream));
-        constexpr int kSeqPerBlock = 256;
+        // column order (most variable sites first), from unweighted single-site counts:
         // worth its two small kernels and the gathered plane build only for large problems (C, N = 10k: 0.15 -> 0.22 ms with it)
         // (DCA_WEIGHTS_ORDER=file / variable forces one or the other)
+        constexpr int kSeqPerBlock = 256;
         const char* orderEnv = getenv("DCA_WEIGHTS_ORDER");
         const bool wantRanked = orderEnv ? (orderEnv[0] == 'v') : (double)N * N * L >= 2e11;
         const bool ranked = wantRanked && (size_t)L * sizeof(unsigned long long) <= 60000;
+        uint32_t *dP = nullptr, *dHist = nullptr;
+        int* dPerm = nullptr;
+        hipError_t ea = dca_dev_malloc(reinterpret_cast<void**>(&dP), (size_t)N * G * PLP * sizeof(uint32_t));
+        if (ea == hipSuccess) ea = dca_dev_malloc(reinterpret_cast<void**>(&dPerm), (size_t)ctx->Ls * sizeof(int));
+        if (ea == hipSuccess && ranked) {            // the site histogram only exists for the ranked order
+            ea = dca_dev_malloc(reinterpret_cast<void**>(&dHist), (size_t)L * 32 * sizeof(uint32_t));
+            if (ea == hipSuccess) ea = hipMemsetAsync(dHist, 0, (size_t)L * 32 * sizeof(uint32_t), ctx->stream);
+        }
+        if (ea != hipSuccess) {                      // nothing of the scratch is left behind
+            dca_dev_free(dP); dca_dev_free(dHist); dca_dev_free(dPerm);
+            dca_set_error("weights scratch: %s", hipGetErrorString(ea));
+            return DCA_ERR_HIP;
+        }
         if (ranked)
             hipLaunchKernelGGL(weights_column_hist_kernel, dim3(ceil_div(L, 256), ceil_div(N, kSeqPerBlock)), dim3(256), 0, ctx->stream,
                                ctx->dX, dHist, N, L, ctx->Ls, kSeqPerBlock);
@@ -289,7 +296,7 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int p
         if (e != hipSuccess) { dca_set_error("weights kernel: %s", hipGetErrorString(e)); return DCA_ERR_HIP; }
     }
     ctx->have_weights = false;
-    ctx->have_counts = true;           // (partial) counts are in ctx->dCounts
+    ctx->have_counts = false;          // ctx->dCounts holds this part's counts only; dca_weights_finish declares them complete
     return finish ? dca_weights_finish(ctx) : DCA_OK;
 }
 

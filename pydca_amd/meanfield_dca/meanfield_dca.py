@@ -285,8 +285,27 @@ class MeanFieldDCA:
         couplings_ranked = [(pair, blocks[k].reshape(-1)) for k, pair in enumerate(names)]
         return tuple(fields_mapped), tuple(couplings_ranked)
 
+    def compute_two_site_model_fields(self, couplings, reg_fi):
+        """meanfield_dca.py:556-585 -> float64[pairs, 2, q]: the fields h_i, h_j of every pair's
+        two-site model, fitted to the regularised single-site frequencies (fixed point on the
+        device, one workgroup per pair; pair order as in the pair-site frequencies)."""
+        logger.info('\n\tFitting the two-site model fields of every site pair')
+        return msa_numerics.compute_two_site_model_fields(
+            couplings=couplings, reg_fi=reg_fi, seqs_len=self.__sequences_len,
+            num_site_states=self.__num_site_states)
+
+    def get_site_pair_di_score(self):
+        """meanfield_dca.py:793-830 -> {(i, j): DI} for i < j, in pair order.  The chain frequencies ->
+        correlation matrix -> couplings -> two-site fields -> DI stays on the device (the context keeps
+        the couplings of the current pseudocount resident); only the pairs' DI values come back."""
+        self._device_scores(False)
+        logger.info('\n\tComputing direct information')
+        di = self.__ctx.mf_di_scores(False)
+        iu, ju = np.triu_indices(self.__sequences_len, k=1)
+        return {(int(i), int(j)): di[k] for k, (i, j) in enumerate(zip(iu, ju))}
+
     def compute_sorted_DI(self, seqbackmapper=None):
-        """meanfield_dca.py:793-845 (two-site model fields + direct information, msa_numerics.py:378-533,
+        """meanfield_dca.py:832-855 (two-site model fields + direct information, msa_numerics.py:378-533,
         one workgroup per site pair on the device)."""
         self._device_scores(False)
         logger.info('\n\tComputing direct information')

@@ -46,8 +46,10 @@ def shard_with_halo(n_seqs, world, rank, warmup):
 def init_native_comm(ctx, lib_mod, rank, world, dist=None, group=None, rccl_path=None):
     """Give `ctx` its own RCCL communicator (csrc/comm_rccl.cpp): rank 0 makes the unique id, it travels through the
     process group `dist` already has (any backend: it is 128 bytes), every rank joins.  After this the context's
-    exchange steps run as RCCL collectives on its own stream -- no Python callback, no device synchronisation:
-        ctx.plm_set_native_comm(1 | 2),  ctx.mf_set_native_comm(),  ctx.compute_weights_sharded(seqid)."""
+    exchange steps run as RCCL collectives on its own stream -- no Python callback, no device synchronisation.
+    Call order on every rank:  ctx.compute_weights_sharded(seqid)  (or set_weights), then  ctx.plm_configure(...),
+    then  ctx.plm_set_native_comm(1 | 2 | 3)  /  ctx.mf_set_native_comm().  The exchange scheme survives later weight
+    changes and re-configurations (the engines are invalidated, not dropped); a new comm_init resets it."""
     # rccl_path None: the library picks the librccl that belongs to the HIP runtime it is bound to (comm_rccl.cpp)
     path = rccl_path
     if world == 1 or dist is None:

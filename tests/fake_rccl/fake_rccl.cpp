@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY -- a stand-in for librccl.so that implements the nine entry points csrc/comm_rccl.cpp binds
+// TEST INFRASTRUCTURE ONLY -- a stand-in for librccl.so that implements the eleven entry points csrc/comm_rccl.cpp binds
 // (same names, same signatures) between THREADS of one process, so that the product's native exchange path (in-place
 // reduce-scatter / all-gather / all-reduce on the context's stream, sharded weights, mfDCA counts) can be driven with
 // world sizes 2 and 3 on the single GPU a test box has; real RCCL refuses two ranks on one device.
@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -101,8 +102,64 @@ int ncclCommInitRank(void** comm, int nranks, ncclUniqueId id, int rank)
 
 int ncclCommDestroy(void* comm) { delete static_cast<Comm*>(comm); return 0; }
 const char* ncclGetErrorString(int r) { return r == 0 ? "no error" : r == 4 ? "invalid argument" : "fake rccl: hip error"; }
-int ncclGroupStart() { return 0; }
-int ncclGroupEnd() { return 0; }
+
+// Point-to-point: only inside ncclGroupStart / ncclGroupEnd, the way the product issues its direct exchange (every rank
+// posts its sends and receives, the group end carries them out).  Sends are staged in a host mailbox keyed (from, to);
+// all ranks of the communicator must end a group with point-to-point operations together.
+namespace {
+struct P2P { bool send; void* buf; size_t bytes; int peer; Comm* comm; hipStream_t stream; };
+thread_local int t_depth = 0;
+thread_local std::vector<P2P> t_ops;
+std::mutex g_mail_mu;
+std::map<std::pair<Group*, std::pair<int, int>>, std::vector<char>> g_mail;
+}  // namespace
+
+int ncclGroupStart() { ++t_depth; return 0; }
+int ncclGroupEnd()
+{
+    if (--t_depth > 0 || t_ops.empty()) return 0;
+    std::vector<P2P> ops;
+    ops.swap(t_ops);
+    Group* g = ops[0].comm->group;
+    for (const P2P& o : ops) {
+        if (!o.send) continue;
+        if (hipStreamSynchronize(o.stream) != hipSuccess) return 1;
+        std::vector<char> box(o.bytes);
+        if (hipMemcpy(box.data(), o.buf, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        std::lock_guard<std::mutex> lk(g_mail_mu);
+        g_mail[{g, {o.comm->rank, o.peer}}].swap(box);
+    }
+    barrier(g);
+    int rc = 0;
+    for (const P2P& o : ops) {
+        if (o.send) continue;
+        std::vector<char> box;
+        {
+            std::lock_guard<std::mutex> lk(g_mail_mu);
+            auto it = g_mail.find({g, {o.peer, o.comm->rank}});
+            if (it == g_mail.end() || it->second.size() != o.bytes) { rc = 4; continue; }
+            box.swap(it->second);
+            g_mail.erase(it);
+        }
+        if (hipMemcpy(o.buf, box.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) rc = 1;
+    }
+    barrier(g);
+    return rc;
+}
+
+int ncclSend(const void* buf, size_t count, int type, int peer, void* comm, hipStream_t stream)
+{
+    if (t_depth <= 0 || !type_size(type)) return 4;
+    t_ops.push_back(P2P{true, const_cast<void*>(buf), count * type_size(type), peer, static_cast<Comm*>(comm), stream});
+    return 0;
+}
+
+int ncclRecv(void* buf, size_t count, int type, int peer, void* comm, hipStream_t stream)
+{
+    if (t_depth <= 0 || !type_size(type)) return 4;
+    t_ops.push_back(P2P{false, buf, count * type_size(type), peer, static_cast<Comm*>(comm), stream});
+    return 0;
+}
 
 int ncclAllReduce(const void* send, void* recv, size_t count, int type, int op, void* comm, hipStream_t stream)
 {

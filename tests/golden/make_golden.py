@@ -193,6 +193,14 @@ def di_golden(tag, path, bio, pseudocount, seqid, plm_seqid=None):
     L, q = inst.sequences_len, inst.num_site_states
     out = dict(L=L, q=q, pseudocount=pseudocount, seqid=seqid,
                mf_di=pair_order(inst.compute_sorted_DI(), L), mf_di_apc=pair_order(inst.compute_sorted_DI_APC(), L))
+    # the two remaining public DI methods of the class (meanfield_dca.py:556, :793), called as a user would
+    reg_fi = inst.get_reg_single_site_freqs()
+    couplings = inst.compute_couplings(inst.construct_corr_mat(reg_fi, inst.get_reg_pair_site_freqs()))
+    out["mf_reg_fi"] = np.array(reg_fi)
+    out["mf_fields"] = np.array(inst.compute_two_site_model_fields(couplings, reg_fi))
+    d = inst.get_site_pair_di_score()
+    out["mf_di_dict_keys"] = np.array(list(d.keys()), dtype=np.int32)
+    out["mf_di_dict_values"] = np.array(list(d.values()))
     g = np.load(os.path.join(HERE, "plm_%s.npz" % tag))
     x = g["run_a"]
     sid = float(g["seqid"]) if plm_seqid is None else plm_seqid

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Drives the product's NATIVE exchange path (csrc/comm_rccl.cpp: RCCL entry points on the context's stream) with
 `world` ranks as THREADS on one GPU.  librccl.so is replaced by tests/fake_rccl/libfake_rccl.so (test infrastructure: the
-same nine symbols between threads) because real RCCL refuses two ranks on one device; the library itself is the product
+same entry points between threads) because real RCCL refuses two ranks on one device; the library itself is the product
 build, unmodified -- it only receives another path for dlopen.  Run in its own process (the library binds the first
 librccl it opens):   python tests/native_comm_threads.py WORLD  -> prints one JSON line."""
 import json
@@ -41,7 +41,7 @@ def main():
     M = golden("mf_toy_protein")
     XM = (M["X"] - 1).astype(np.uint8)
 
-    uid_w, uid_p1, uid_p2, uid_m = (_lib.comm_unique_id(FAKE) for _ in range(4))
+    uid_w, uid_p1, uid_p2, uid_p3, uid_m = (_lib.comm_unique_id(FAKE) for _ in range(5))
     out = [None] * world
 
     def run(rank):
@@ -54,7 +54,7 @@ def main():
             ws = c.compute_weights_sharded(0.8, _lib.DCA_F64)
             res["weights_equal"] = bool(np.array_equal(ws, w) and np.array_equal(c.weight_counts(), counts))
             c.close()
-            for mode, uid in ((1, uid_p1), (2, uid_p2)):
+            for mode, uid in ((1, uid_p1), (2, uid_p2), (3, uid_p3)):
                 s = parallel.make_sharded_plm_context(_lib, X, q, w, 1.0, 20.0, rank, world, 0, precision=64)
                 s.comm_init(uid, world, rank, FAKE)
                 s.plm_set_native_comm(mode)
@@ -72,7 +72,12 @@ def main():
             # mfDCA pair counts summed through the communicator
             m = parallel.make_sharded_mf_context(_lib, XM, int(M["q"]), M["w"], rank, world, 0)
             m.comm_init(uid_m, world, rank, FAKE)
-            m.mf_set_native_comm(True)
+            fi_local = m.mf_single_site_freqs()          # a query BEFORE the reduction is switched on caches this shard's counts ...
+            m.mf_set_native_comm(True)                   # ... which switching it on must drop (round-2 advisor finding)
+            fi_global = m.mf_single_site_freqs()
+            res["mf_stale_counts_dropped"] = bool(world == 1 or not np.array_equal(fi_local, fi_global))
+            res["mf_fi_err"] = float(np.max(np.abs(fi_global - M["fi"])))
+            m.set_weights(m.weights())                   # re-weighting keeps the exchange scheme (engines invalidated, not dropped)
             scores = m.mf_run(float(M["pseudocount"]), True)
             ranked = sorted(zip(scores, range(len(scores))), key=lambda t: (-t[0], t[1]))
             res["mf_err"] = float(np.max(np.abs(np.array([sc for sc, _ in ranked]) - M["apc_scores"]) / np.maximum(np.abs(M["apc_scores"]), 1e-3)))

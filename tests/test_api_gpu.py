@@ -258,7 +258,7 @@ def test_native_rccl_communicator_single_rank():
     st0 = ref.plm_lbfgs_iterate(6)
     x0 = ref.plm_get_x(np.float32)
     ref.close()
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         ctx = _lib.Context(0, _lib.DCA_F32)
         ctx.set_msa(X, q)
         with pytest.raises(_lib.DcaBackendError):
@@ -378,6 +378,30 @@ def test_direct_information_through_the_classes(tmp_path):
     out = plmdca_main.run_plm_dca(["compute_di", "rna", data_file("toy_rna.fa"), "--max_iterations", "5",
                                    "--output_dir", str(tmp_path / "p")])
     assert os.path.basename(out) == "PLMDCA_raw_di_scores_toy_rna.txt"
+
+
+@pytest.mark.parametrize("tag,fname,bio", [("toy_rna", "toy_rna.fa", "rna"), ("toy_protein", "toy_protein.fa", "protein"),
+                                           ("rf71", "MSA_RF00167_trimmed71.fa", "rna")])
+def test_meanfield_two_site_fields_and_di_dict_vs_reference(tag, fname, bio):
+    """MeanFieldDCA.compute_two_site_model_fields(couplings, reg_fi) (meanfield_dca.py:556) and
+    get_site_pair_di_score() (:793), called the way the reference's own get_site_pair_di_score chains them,
+    against what the reference's class returned for the same calls (di_<tag>.npz: mf_fields, mf_di_dict_*)."""
+    from pydca_amd.meanfield_dca.meanfield_dca import MeanFieldDCA
+    G = golden("di_" + tag)
+    inst = MeanFieldDCA(data_file(fname), bio, pseudocount=float(G["pseudocount"]), seqid=float(G["seqid"]))
+    reg_fi = inst.get_reg_single_site_freqs()
+    np.testing.assert_allclose(reg_fi, G["mf_reg_fi"], rtol=1e-13)
+    couplings = inst.compute_couplings(inst.construct_corr_mat(reg_fi, inst.get_reg_pair_site_freqs()))
+    fields = inst.compute_two_site_model_fields(couplings, reg_fi)
+    assert fields.shape == G["mf_fields"].shape and fields.dtype == np.float64
+    np.testing.assert_allclose(fields, G["mf_fields"], rtol=1e-7, atol=1e-12)
+    d = inst.get_site_pair_di_score()
+    assert isinstance(d, dict)
+    assert [tuple(k) for k in d.keys()] == [tuple(int(v) for v in k) for k in G["mf_di_dict_keys"]]    # pair order kept
+    np.testing.assert_allclose(np.array(list(d.values())), G["mf_di_dict_values"], rtol=1e-7, atol=1e-12)
+    # and it is what compute_sorted_DI ranks
+    ranked = inst.compute_sorted_DI()
+    assert ranked[0][1] == max(d.values()) and d[ranked[0][0]] == ranked[0][1]
 
 
 def test_compute_params_and_frequency_outputs(tmp_path, oracle_mf):
@@ -522,7 +546,7 @@ def test_sharded_optimiser_vectors_with_thread_comm(oracle_plm, world):
         assert np.array_equal(x_end, out[0][6]) and np.array_equal(scores, out[0][7])
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_native_exchange_path_with_several_ranks(world):
     """The product's native exchange path -- RCCL entry points enqueued on the context's stream, in place: all-reduce of
     g / fx, reduce-scatter + all-gather of the sharded optimiser vectors, the integer all-reduce of the sharded weights,
@@ -541,13 +565,14 @@ def test_native_exchange_path_with_several_ranks(world):
     for r in res["ranks"]:
         assert r is not None and "error" not in r, r
         assert r["weights_equal"]
-        for mode in ("mode1", "mode2"):
+        for mode in ("mode1", "mode2", "mode3"):          # 3: direct exchange (grouped send / recv + rank-ordered local sum)
             m = r[mode]
             assert m["fx_err"] <= 1e-11 and m["g_err"] < 1e-11, m
             assert m["status"] == res["reference_status"], m
             assert m["fx_end_err"] <= 1e-9 and m["x_err"] < 1e-7, m
             assert m["x_sum"] == res["ranks"][0][mode]["x_sum"]           # every rank ends with the same x
         assert r["mf_err"] < 1e-9
+        assert r["mf_stale_counts_dropped"] and r["mf_fi_err"] < 1e-13, r      # reduction switched on after a query; re-weighted afterwards
 
 
 @pytest.mark.parametrize("mode", ["vectors", "allreduce"])

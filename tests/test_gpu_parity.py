@@ -192,18 +192,33 @@ def _topL_same(a, b, L):
     return list(np.argsort(-a, kind="stable")[:L]) == list(np.argsort(-b, kind="stable")[:L])
 
 
+_ORACLE_RUNS = {}
+
+
+def _oracle_run(oracle_plm, tag, iters):
+    """The float64 oracle's L-BFGS run of a golden alignment to the given cap (made once per module run)."""
+    if (tag, iters) not in _ORACLE_RUNS:
+        G = golden("plm_" + tag)
+        q = int(G["q"])
+        w64 = oracle_plm.weights(G["X"], 0.8, np.float64)
+        _ORACLE_RUNS[(tag, iters)] = oracle_plm.lbfgs(G["X"], w64, q, float(G["lambda_h"]), float(G["lambda_J"]), iters,
+                                                     oracle_plm.init_x(G["X"], w64, q), carry=True)
+    return _ORACLE_RUNS[(tag, iters)]
+
+
 @pytest.mark.parametrize("mode", ["serial", "chunked"])
-@pytest.mark.parametrize("tag,iters", [("toy_rna", 60), ("toy_protein", 30), ("rf71", 40), ("rf00167", 25), ("pf02826", 8)])
-def test_lbfgs_float64_matches_oracle_at_equal_iteration_cap(L_, oracle_plm, oracle_mf, tag, iters, mode):
-    """P3 of SURVEY 8c4 / north_star: same restated optimiser, same semantics, same cap =>
-    FN and FN_APC within 1e-4 relative and identical top-L order (float64), with the strictly serial
-    carry chain and with the chunk-parallel scan the product ships."""
+@pytest.mark.parametrize("tag", ["toy_rna", "toy_protein", "rf71", "rf00167", "pf02826"])
+def test_lbfgs_float64_matches_oracle_at_equal_iteration_cap(L_, oracle_plm, oracle_mf, tag, mode):
+    """P3 of SURVEY 8c4 / north_star AT THE REFERENCE'S DEFAULT CAP (max_iterations = 100, plmdca.py:72): same
+    restated optimiser, same semantics, same cap => same exit status / iterations / evaluations, FN and FN_APC
+    within 1e-4 relative and identical top-L order (float64), with the strictly serial carry chain and with the
+    chunk-parallel scan the product ships.  PF02826 (the reference's own protein test input) runs into the cap
+    (-997); the small RNA sets stop earlier in the line search, at the same iteration on both sides."""
+    iters = 100
     G = golden("plm_" + tag)
     L, q = int(G["L"]), int(G["q"])
     lh, lJ = float(G["lambda_h"]), float(G["lambda_J"])
-    w64 = oracle_plm.weights(G["X"], 0.8, np.float64)
-    x0 = oracle_plm.init_x(G["X"], w64, q)
-    ref = oracle_plm.lbfgs(G["X"], w64, q, lh, lJ, iters, x0, carry=True)
+    ref = _oracle_run(oracle_plm, tag, iters)
     ctx = make_ctx(L_, G["X"], q, L_.DCA_F64, 0.8, L_.DCA_F64)
     ctx.plm_configure(lh, lJ, L_.CARRY_SERIAL if mode == "serial" else L_.CARRY_CHUNKED)
     ctx.plm_init_x()
