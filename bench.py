@@ -133,6 +133,51 @@ def cpu_baseline(X, q, lh, lJ, evals_per_iter, sample_rows):
     return out
 
 
+def end_to_end(X, L, q, lh, lJ, device):
+    """SURVEY 8 d2's end-to-end figures, outside the headline's timed region: what `plmdca compute_fn <bio> <file> --apc`
+    (plmdca_main.py:136-256; max_iterations = the reference's default 100) and `mfdca compute_fn <bio> <file> --apc` do, from
+    the FASTA FILE to the ranked list on the host, through the same classes the command lines use, with the split
+    reader / setup / compute / ranking.  The file is the synthetic alignment written to /tmp (page-cache hot, as after
+    any first read); the plmDCA run is also the bench's full 100-iteration figure with its evaluations per iteration."""
+    from pydca_amd.meanfield_dca.meanfield_dca import MeanFieldDCA
+    from pydca_amd.plmdca.plmdca import PlmDCA
+    from tools.gen_msa import write_fasta
+    bio = "protein" if q == 21 else "rna"
+    path = "/tmp/bench_e2e_%d.fa" % os.getpid()
+    write_fasta(path, X, q)
+    npairs = L * (L - 1) // 2
+    res = {"file_bytes": os.path.getsize(path), "pairs": npairs}
+    try:
+        best = None
+        for rep in range(2):                      # the second pass is reported (first-use effects of the classes in the first)
+            t0 = time.perf_counter()
+            inst = PlmDCA(path, bio, seqid=0.8, lambda_h=lh, lambda_J=lJ, max_iterations=100, device=device)
+            t1 = time.perf_counter()
+            ranked = inst.compute_sorted_FN_APC()
+            t2 = time.perf_counter()
+            ls = inst.last_status
+            best = {"seconds": t2 - t0, "plm_pairs_per_s": npairs / (t2 - t0), "iterations": ls["iterations"], "evaluations": ls["evaluations"],
+                    "evaluations_per_iteration": ls["evaluations"] / max(ls["iterations"], 1), "lbfgs_status": ls["status"],
+                    "iterations_per_s_full_run": ls["iterations"] / ls["stages_s"]["optimise"],
+                    "stages_s": dict(ls["stages_s"], constructor_file_scan=t1 - t0), "top_pair": [int(v) for v in ranked[0][0]],
+                    "unique_sequences": ls["unique_sequences"]}
+            del inst
+        res["plmdca_compute_fn"] = best
+        best = None
+        for rep in range(2):
+            t0 = time.perf_counter()
+            m = MeanFieldDCA(path, bio, pseudocount=0.5, seqid=0.8, device=device)
+            ranked = m.compute_sorted_FN_APC()
+            t1 = time.perf_counter()
+            best = {"seconds": t1 - t0, "mf_pairs_per_s": npairs / (t1 - t0), "stages_s": dict(m.last_timings),
+                    "top_pair": [int(v) for v in ranked[0][0]], "unique_sequences": m.num_sequences}
+            del m
+        res["mfdca_compute_fn"] = best
+    finally:
+        os.unlink(path)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +187,7 @@ def main():
     ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mfdca", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
     args = ap.parse_args()
 
@@ -380,6 +426,12 @@ def main():
                               "frac": inv_tf / 78.6, "flop_convention": "n^3", "n": L * (q - 1),
                               "avg_kernel_ms": mctx.kernel_time("mf_inverse")[0] / max(mctx.kernel_time("mf_inverse")[1], 1)}
         mctx.close()
+
+    if world == 1 and not args.no_e2e:
+        try:
+            out["e2e"] = end_to_end(X, L, q, lh, lJ, local_rank)
+        except Exception as exc:   # pragma: no cover
+            out["e2e"] = {"error": repr(exc)}
 
     if world == 1 and not args.no_cpu_baseline:
         sample = args.cpu_sample or max(200, min(N, int(4000 * (500.0 / L) ** 2 * (21.0 / q))))

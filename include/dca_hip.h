@@ -71,6 +71,15 @@ void freeFieldsAndCouplings(void* h_and_J);
 int dca_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count);
 int dca_count_msa_lines(const char* path);
 
+/* The mfDCA path's FASTA reader, pydca/fasta_reader/fasta_reader.py:81-163 (there through Biopython): multi-line
+ * records, upper-casing, every character outside the alphabet is the gap state (:138-149), exact duplicates dropped
+ * keeping the first occurrence (:153).  Codes are 0-based with gap = q-1 (the reference's Python states minus one).
+ * dca_fasta_shape: number of records with residues and their common length (DCA_ERR_ARG if lengths differ).
+ * dca_read_fasta: out = capacity x L bytes; returns the number of unique rows; raw_count = records read.  Files with
+ * non-ASCII bytes return DCA_ERR_RESIDUE (the Python side then reads them in text mode itself). */
+int dca_fasta_shape(const char* path, int* n_records, int* L_out);
+int dca_read_fasta(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count);
+
 /* ------------------------------------------------------------------ reference-sequence back-mapping (host)
  * Local pairwise alignment, Smith-Waterman with affine gaps (a gap of length n costs
  * gap_open + (n-1)*gap_extend), standing in for Bio.pairwise2.align.localds as called by

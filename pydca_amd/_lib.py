@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCA_LIB_PATH") or os.path.join(_HERE, "lib", "libdca_hip.so")
 
 DCA_OK = 0
+DCA_ERR_ARG, DCA_ERR_IO, DCA_ERR_RESIDUE = -1, -2, -3
 DCA_ERR_NOT_SPD = -7
 DCA_F32, DCA_F64 = 32, 64
 CARRY_EXACT, CARRY_CHUNKED, CARRY_SERIAL = 0, 1, 2
@@ -64,6 +65,8 @@ def lib():
         "dca_release_cached_memory": (sz, []),
         "dca_read_msa": (i, [C.c_char_p, i, i, vp, i, C.POINTER(i)]),
         "dca_count_msa_lines": (i, [C.c_char_p]),
+        "dca_fasta_shape": (i, [C.c_char_p, C.POINTER(i), C.POINTER(i)]),
+        "dca_read_fasta": (i, [C.c_char_p, i, i, vp, i, C.POINTER(i)]),
         "dca_create": (i, [C.POINTER(vp), i, i]),
         "dca_destroy": (None, [vp]),
         "dca_set_msa": (i, [vp, vp, i, i, i]),
@@ -129,7 +132,7 @@ def lib():
 
 EXPORTS = ["dca_compute_weights_sharded", "dca_weights_partial_counts", "dca_set_weight_counts", "dca_comm_unique_id",
            "dca_comm_init", "dca_comm_destroy", "dca_plm_set_native_comm", "dca_mf_set_native_comm",
-           "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_create",
+           "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_fasta_shape", "dca_read_fasta", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_num_params", "dca_plm_init_x",
            "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_di_from_arrays", "dca_di_from_fields", "dca_plm_set_vector_sharding",
@@ -168,12 +171,43 @@ def read_msa(path, biomolecule, L):
     cap = l.dca_count_msa_lines(os.fsencode(path))
     if cap < 0:
         check(cap)
-    out = np.zeros((max(cap, 1), L), dtype=np.uint8)
+    out = np.empty((max(cap, 1), L), dtype=np.uint8)         # every row handed back is written by the reader
     raw = C.c_int(0)
     n = l.dca_read_msa(os.fsencode(path), int(biomolecule), int(L), _ptr(out), cap, C.byref(raw))
     if n < 0:
         check(n)
     return np.ascontiguousarray(out[:n]), raw.value
+
+
+def fasta_shape(path):
+    """(records with residues, their common length) of a FASTA file, natively (dca_fasta_shape)."""
+    l = lib()
+    n, L = C.c_int(0), C.c_int(0)
+    rc = l.dca_fasta_shape(os.fsencode(path), C.byref(n), C.byref(L))
+    if rc == DCA_ERR_ARG:
+        raise ValueError(l.dca_last_error().decode("utf-8", "replace"))
+    check(rc)
+    return n.value, L.value
+
+
+def read_fasta(path, biomolecule):
+    """The mfDCA path's FASTA semantics (fasta_reader.py:81-163) natively -> (uint8[N', L] with 0-based codes, gap = q-1;
+    number of records read).  Raises DcaBackendError(DCA_ERR_RESIDUE) for files with non-ASCII bytes (the caller then
+    reads in text mode itself), ValueError for empty files / unequal lengths like the Python reader."""
+    l = lib()
+    n, L = C.c_int(0), C.c_int(0)
+    rc = l.dca_fasta_shape(os.fsencode(path), C.byref(n), C.byref(L))
+    if rc == DCA_ERR_ARG:
+        raise ValueError(l.dca_last_error().decode("utf-8", "replace"))
+    check(rc)
+    if n.value == 0:
+        raise ValueError("No sequences found in %s" % path)
+    out = np.empty((n.value, L.value), dtype=np.uint8)
+    raw = C.c_int(0)
+    k = l.dca_read_fasta(os.fsencode(path), int(biomolecule), L.value, _ptr(out), n.value, C.byref(raw))
+    if k < 0:
+        check(k)
+    return out[:k], raw.value
 
 
 class Context:

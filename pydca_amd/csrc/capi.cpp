@@ -179,20 +179,7 @@ int dca_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int cap
     return dca_read_msa_impl(path, biomolecule, L, out, capacity, raw_count);
 }
 
-int dca_count_msa_lines(const char* path)
-{
-    FILE* fp = fopen(path, "r");
-    if (!fp) { dca_set_error("Unable to open file %s", path); return DCA_ERR_IO; }
-    int n = 0, c, first = 1, is_seq = 0, nonempty = 0;
-    while ((c = fgetc(fp)) != EOF) {
-        if (c == '\n') { if (nonempty && is_seq) ++n; first = 1; nonempty = 0; is_seq = 0; continue; }
-        if (first) { is_seq = (c != '>'); first = 0; }
-        nonempty = 1;
-    }
-    if (nonempty && is_seq) ++n;
-    fclose(fp);
-    return n;
-}
+int dca_count_msa_lines(const char* path) { return dca_count_msa_lines_impl(path); }
 
 int dca_create(dca_ctx** out, int device, int precision)
 {
@@ -624,19 +611,19 @@ float* plmdcaBackend(unsigned short biomolecule, unsigned short num_site_states,
 {
     (void)num_threads;
     const int L = (int)seqs_len, q = (int)num_site_states;
-    int cap = dca_count_msa_lines(msa_file);
-    if (cap <= 0) { if (cap == 0) dca_set_error("no sequences in %s", msa_file); return nullptr; }
-    std::vector<uint8_t> X((size_t)cap * L);
+    uint8_t* X = nullptr;
     int raw = 0;
-    const int N = dca_read_msa_impl(msa_file, biomolecule, L, X.data(), cap, &raw);
-    if (N <= 0) return nullptr;
+    const int N = dca_read_msa_owned(msa_file, biomolecule, L, &X, &raw);       // one pass over the file
+    if (N <= 0) { free(X); if (N == 0) dca_set_error("no sequences in %s", msa_file); return nullptr; }
     dca_ctx* ctx = nullptr;
     float* result = nullptr;
     dca_plm_stats st;
     memset(&st, 0, sizeof(st));
     const size_t P = dca_plm_num_params(L, q);
-    if (dca_create(&ctx, 0, DCA_F32) != DCA_OK) return nullptr;
-    if (dca_set_msa(ctx, X.data(), N, L, q) == DCA_OK &&
+    if (dca_create(&ctx, 0, DCA_F32) != DCA_OK) { free(X); return nullptr; }
+    const int rc_msa = dca_set_msa(ctx, X, N, L, q);
+    free(X);
+    if (rc_msa == DCA_OK &&
         dca_compute_weights(ctx, (double)seqid, DCA_F32) == DCA_OK &&
         dca_plm_configure(ctx, (double)lambda_h, (double)lambda_J, DCA_CARRY_CHUNKED, 0, 0, 0, 1) == DCA_OK &&
         dca_plm_init_x(ctx) == DCA_OK &&

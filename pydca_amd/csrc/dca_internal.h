@@ -198,3 +198,5 @@ int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* 
 
 // ---- host_io.cpp
 int dca_read_msa_impl(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count);
+int dca_read_msa_owned(const char* path, int biomolecule, int L, uint8_t** rows /* malloc'd, caller frees */, int* raw_count);   // one pass, no capacity
+int dca_count_msa_lines_impl(const char* path);

@@ -1043,6 +1043,7 @@ struct PlmEngine : PlmEngineBase {
         bool begun = false, finished = false;
         int status = 0, k = 1, end = 0, iters = 0, evals = 0, max_iterations = 0, verbose = 0;
         double fx = 0, step = 0, xnorm = 0, gnorm = 0, seconds = 0;
+        double last_step = 0;                 // step length the last completed iteration accepted (lbfgs_progress_t's `step`)
         double dginit = 0;                    // g.d of the current search direction
         bool dginit_on_device = false;        // ... still in dScal[kSlotDginit]: read with the next evaluation's scalars
     } o;
@@ -1615,6 +1616,7 @@ struct PlmEngine : PlmEngineBase {
             }
             o.xnorm = std::sqrt(xx); o.gnorm = std::sqrt(gg);
             o.iters = o.k;
+            o.last_step = o.step;
             if (o.verbose) {
                 fprintf(stderr, "Iteration %d:\n", o.k);
                 fprintf(stderr, "fx = %f, xnorm = %f, gnorm = %f, step = %f\n\n", o.fx, o.xnorm, o.gnorm, o.step);
@@ -1651,7 +1653,7 @@ struct PlmEngine : PlmEngineBase {
         o.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (st) {
             st->status = o.status; st->iterations = o.iters; st->evaluations = o.evals; st->finished = o.finished ? 1 : 0;
-            st->fx = o.fx; st->xnorm = o.xnorm; st->gnorm = o.gnorm; st->step = o.step; st->seconds = o.seconds;
+            st->fx = o.fx; st->xnorm = o.xnorm; st->gnorm = o.gnorm; st->step = o.iters ? o.last_step : o.step; st->seconds = o.seconds;
         }
         return DCA_OK;
     }

@@ -84,9 +84,33 @@ def alignment_letter2int(alignment, biomolecule='protein'):
     return rows
 
 
+def get_alignment_int_array(file_name, biomolecule='protein'):
+    """The de-duplicated alignment of fasta_reader.py:166-188 as an int array [N', L] of the reference's 1-based states
+    (uint8; gap = q).  Read by the native reader in libdca_hip.so (one mmap, threaded encoding, hashed first-occurrence
+    de-duplication: milliseconds for 10^5 sequences where the per-record Python path needs a second); files the
+    native reader declines (non-ASCII bytes) go through the text-mode path below -- same result by construction,
+    tests/test_host_logic.py compares the two on every fixture."""
+    from .. import _lib
+    biomolecule = biomolecule.strip().upper()
+    if biomolecule not in ('PROTEIN', 'RNA'):
+        logger.error('\n\t{} entered. Biomolecule must be either PROTEIN or RNA'.format(biomolecule))
+        raise ValueError
+    try:
+        X0, raw = _lib.read_fasta(file_name, _lib.PROTEIN if biomolecule == 'PROTEIN' else _lib.RNA)
+    except _lib.DcaBackendError as exc:
+        if exc.code == _lib.DCA_ERR_IO:
+            logger.error('\n\tError occured while reading from fasta file: {}'.format(file_name))
+            raise FileNotFoundError(file_name)
+        if exc.code != _lib.DCA_ERR_RESIDUE:
+            raise
+        return np.array(alignment_letter2int(get_alignment_from_fasta_file(file_name), biomolecule), dtype=np.uint8)
+    logger.info('\n\tTotal number of sequences read from file: {}'.format(raw))
+    return X0 + np.uint8(1)
+
+
 def get_alignment_int_form(file_name, biomolecule='protein'):
-    """fasta_reader.py:166-188."""
-    return alignment_letter2int(get_alignment_from_fasta_file(file_name), biomolecule)
+    """fasta_reader.py:166-188 -> list of lists of 1-based states."""
+    return get_alignment_int_array(file_name, biomolecule).tolist()
 
 
 def sequences_to_char_form(seqs_lst, biomolecule):

@@ -2,6 +2,7 @@
 `mfdca compute_fn` path; numerics on the GPU (one resident context per instance: the
 alignment and the weighted pair counts stay in HBM between calls)."""
 import logging
+import time
 
 import numpy as np
 
@@ -23,7 +24,8 @@ def _ranked(scores, L, ctx=None):
     just produced, dca_scores_order); without it from numpy."""
     iu, ju = np.triu_indices(L, k=1)
     order = ctx.scores_order() if ctx is not None else np.argsort(-scores, kind='stable')
-    return [((int(iu[k]), int(ju[k])), scores[k]) for k in order]
+    # built without a Python-level loop over the pairs (124 750 at L = 500); the scores stay numpy scalars as in the reference
+    return list(zip(zip(iu[order].tolist(), ju[order].tolist()), list(scores[order])))
 
 
 class MeanFieldDCA:
@@ -47,26 +49,30 @@ class MeanFieldDCA:
         else:
             logger.error('\n\tUnknown biomolecule ... must be protein (PROTEIN) or rna (RNA)')
             raise ValueError
+        self.__sequences = None           # list-of-lists form of the reference's `alignment` property, made on demand
+        self.last_timings = {}            # seconds per stage of the most recent calls (reader, weights, scores, ranking)
+        t0 = time.perf_counter()
         if isinstance(msa, str):
-            self.__sequences = fasta_reader.get_alignment_int_form(msa, biomolecule=biomolecule)
+            self.__X = fasta_reader.get_alignment_int_array(msa, biomolecule=biomolecule)      # uint8 [N', L], 1-based states
         elif isinstance(msa, (list, tuple)) or hasattr(msa, '__iter__'):
             # an in-memory alignment: records with a .seq attribute (Bio.Align.MultipleSeqAlignment
             # in the reference, :102-104) or plain strings
             seqs = [str(getattr(rec, 'seq', rec)).strip().upper() for rec in msa]
             self.__sequences = fasta_reader.alignment_letter2int([s for s in seqs if s], biomolecule)
+            self.__X = np.array(self.__sequences, dtype=np.uint8)
         else:
             raise ValueError("Alignment input parameter is invalid")
-        self.__num_sequences = len(self.__sequences)
-        self.__sequences_len = len(self.__sequences[0])
+        self.__num_sequences, self.__sequences_len = (int(v) for v in self.__X.shape)
         self.__biomolecule = biomolecule
-        self.__X = np.array(self.__sequences, dtype=np.int32)
+        t1 = time.perf_counter()
         self.__ctx = _lib.Context(int(device), _lib.DCA_F64)
-        self.__ctx.set_msa((self.__X - 1).astype(np.uint8), self.__num_site_states)
+        self.__ctx.set_msa(self.__X - np.uint8(1), self.__num_site_states)
         if self.__seqid < 1.0:
             self.__sequences_weight = self.compute_sequences_weight()
         else:
             self.__sequences_weight = np.ones((self.__num_sequences,), dtype=np.float64)
             self.__ctx.set_weights(self.__sequences_weight)
+        self.last_timings.update(reader=t1 - t0, upload_and_weights=time.perf_counter() - t1)
         self.__effective_num_sequences = np.sum(self.__sequences_weight)
         self.__couplings = None
         logger.info('\n\tCreated a MeanFieldDCA object: biomolecule {}, states {}, pseudocount {}, seqid {}, '
@@ -88,6 +94,8 @@ class MeanFieldDCA:
     # ---- properties (meanfield_dca.py:193-347)
     @property
     def alignment(self):
+        if self.__sequences is None:
+            self.__sequences = self.__X.tolist()
         return self.__sequences
 
     @property
@@ -201,7 +209,12 @@ class MeanFieldDCA:
     def compute_sorted_FN_APC(self, seqbackmapper=None):
         """meanfield_dca.py:946-988."""
         logger.info('\n\tPerforming average product correction (APC) to Frobenius norm of couplings.')
-        return self._maybe_mapped(_ranked(self._device_scores(True), self.__sequences_len, self.__ctx), seqbackmapper)
+        t0 = time.perf_counter()
+        scores = self._device_scores(True)
+        t1 = time.perf_counter()
+        ranked = _ranked(scores, self.__sequences_len, self.__ctx)
+        self.last_timings.update(counts_inverse_scores=t1 - t0, ranking=time.perf_counter() - t1)
+        return self._maybe_mapped(ranked, seqbackmapper)
 
     def get_couplings(self):
         """-inv(C) of the current pseudocount as float64[L(q-1), L(q-1)] (device resident

@@ -4,6 +4,7 @@ plmdcaBackend); here that call goes to libdca_hip.so and the O(L^2 q^2) Python l
 follow it in the reference (gap stripping :246-268, Frobenius norm :437-481, APC :484-524)
 run as device kernels as well."""
 import logging
+import time
 
 import numpy as np
 
@@ -23,7 +24,8 @@ def _ranked(scores, L, ctx=None):
     just produced, dca_scores_order); without it from numpy."""
     iu, ju = np.triu_indices(L, k=1)
     order = ctx.scores_order() if ctx is not None else np.argsort(-scores, kind='stable')
-    return [((int(iu[k]), int(ju[k])), scores[k]) for k in order]
+    # built without a Python-level loop over the pairs (124 750 at L = 500); the scores stay numpy scalars as in the reference
+    return list(zip(zip(iu[order].tolist(), ju[order].tolist()), list(scores[order])))
 
 
 class PlmDCA:
@@ -105,6 +107,13 @@ class PlmDCA:
     def _get_num_and_len_of_seqs(self):
         """Raw number of records and alignment length (plmdca.py:163-180)."""
         from ..fasta_reader import fasta_reader
+        try:
+            n, L = _lib.fasta_shape(self.__msa_file)           # one native pass over the file (ms for 10^5 sequences)
+            if n > 0:
+                return n, L
+        except _lib.DcaBackendError as exc:
+            if exc.code != _lib.DCA_ERR_RESIDUE:               # non-ASCII bytes: text mode below
+                raise FileNotFoundError(self.__msa_file) if exc.code == _lib.DCA_ERR_IO else exc
         msa_data = fasta_reader.get_alignment_from_fasta_file(self.__msa_file)
         return len(msa_data), len(msa_data[0])
 
@@ -119,7 +128,9 @@ class PlmDCA:
     def _run_backend(self):
         """Read + de-duplicate (C++ reader semantics), weights, initial parameters and L-BFGS
         on the device; leaves the optimised parameters resident in the context."""
+        t0 = time.perf_counter()
         X, _raw = _lib.read_msa(self.__msa_file, self.__biomolecule_int, self.__seqs_len)
+        t1 = time.perf_counter()
         if self.__ctx is not None:
             self.__ctx.close()
         ctx = _lib.Context(self.__device, self.__precision)
@@ -129,10 +140,13 @@ class PlmDCA:
         ctx.compute_weights(self.__seqid, self.__precision)
         ctx.plm_configure(self.__lambda_h, self.__lambda_J, self.__carry)
         ctx.plm_init_x()
+        t2 = time.perf_counter()
         ctx.plm_lbfgs_begin(self.__max_iterations, self.__verbose)
         st = ctx.plm_lbfgs_iterate(self.__max_iterations if self.__max_iterations else 1 << 30)
+        t3 = time.perf_counter()
         self.last_status = dict(status=st.status, iterations=st.iterations, evaluations=st.evaluations, fx=st.fx,
-                                seconds=st.seconds)
+                                seconds=st.seconds, unique_sequences=int(X.shape[0]),
+                                stages_s=dict(reader=t1 - t0, setup=t2 - t1, optimise=t3 - t2))
         self.__ctx = ctx
         return ctx
 
@@ -201,7 +215,10 @@ class PlmDCA:
         """plmdca.py:484-524."""
         ctx = self._run_backend()
         logger.info('\n\tPerforming average product correction (APC) of FN  of DCA scores')
-        return self._maybe_mapped(_ranked(ctx.plm_scores(True), self.__seqs_len, ctx), seqbackmapper)
+        t0 = time.perf_counter()
+        ranked = _ranked(ctx.plm_scores(True), self.__seqs_len, ctx)
+        self.last_status['stages_s']['scores_and_ranking'] = time.perf_counter() - t0
+        return self._maybe_mapped(ranked, seqbackmapper)
 
     def compute_params(self, seqbackmapper=None, ranked_by=None, linear_dist=None, num_site_pairs=None):
         """plmdca.py:345-434: fields of every site (gap state dropped) and the gauge-shifted couplings

@@ -198,7 +198,7 @@ def test_config_C_lbfgs_P3_chunked_float64(L_, oracle_plm, oracle_mf, msa_C, ora
     ctx.plm_configure(LAMBDA_H, LAMBDA_J, L_.CARRY_CHUNKED)
     ctx.plm_init_x()
     st, trace = stepwise(ctx, REFERENCE_CAP)
-    div = first_divergence(trace, ref["trace"], 1e-9)
+    div = first_divergence(trace, ref["trace"], 1e-7)
     report = {"config": "C", "cap": REFERENCE_CAP, "gpu": [st.status, st.iterations, st.evaluations],
               "oracle": [ref["status"], ref["iterations"], ref["evaluations"]], "first_divergence": div,
               "fx_gpu": st.fx, "fx_oracle": ref["fx"],
@@ -296,7 +296,7 @@ def test_config_D_lbfgs_P3_five_iterations(L_, oracle_plm, oracle_mf):
     ctx.plm_init_x()
     st, trace = stepwise(ctx, iters)
     report = {"config": "D", "cap": iters, "gpu": [st.status, st.iterations, st.evaluations],
-              "oracle": [ref["status"], ref["iterations"], ref["evaluations"]], "first_divergence": first_divergence(trace, ref["trace"], 1e-9),
+              "oracle": [ref["status"], ref["iterations"], ref["evaluations"]], "first_divergence": first_divergence(trace, ref["trace"], 1e-7),
               "fx_gpu": st.fx, "fx_oracle": ref["fx"], "rel_err_x": rel_err(ctx.plm_get_x(np.float64), ref["x"])}
     scores_ref = {}
     for apc in (False, True):

@@ -118,6 +118,89 @@ def test_python_reader_matches_reference_reader(tag, fname, bio):
     assert np.array_equal(X, G["X"])
 
 
+def _text_mode_reader(path, bio):
+    from pydca_amd.fasta_reader import fasta_reader
+    return np.array(fasta_reader.alignment_letter2int(fasta_reader.get_alignment_from_fasta_file(path), bio), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("fname,bio", [("toy_rna.fa", "rna"), ("toy_protein.fa", "protein"), ("MSA_RF00167.fa", "rna"),
+                                       ("MSA_RF00167_trimmed71.fa", "rna"), ("PF02826.faa", "protein"),
+                                       ("MSA_RF00059_trimmed_gap_treshold_50.fa", "rna")])
+def test_native_fasta_reader_equals_text_mode_reader(fname, bio):
+    """dca_read_fasta (mmap, threaded encoding, hashed first-occurrence de-duplication) == the per-record Python
+    reader that test_python_reader_matches_reference_reader pins to the reference's Biopython-based reader."""
+    from pydca_amd.fasta_reader import fasta_reader
+    A = fasta_reader.get_alignment_int_array(data_file(fname), bio)
+    assert A.dtype == np.uint8 and np.array_equal(A, _text_mode_reader(data_file(fname), bio))
+    assert fasta_reader.get_alignment_int_form(data_file(fname), bio) == A.tolist()
+
+
+def test_native_fasta_reader_edge_cases(tmp_path):
+    """Multi-line records, CRLF and lone-CR line ends, surrounding blanks, lower case, characters outside the alphabet
+    (gap state, fasta_reader.py:138-149), text before the first header, empty records, duplicates across different
+    line wrapping, no trailing newline; unequal lengths and empty files raise ValueError, a missing file
+    FileNotFoundError; non-ASCII bytes take the text-mode path."""
+    from pydca_amd import _lib
+    from pydca_amd.fasta_reader import fasta_reader
+    p = tmp_path / "edge.fa"
+    p.write_bytes(b"junk before any header\n>a desc\r\nACGU\r\n-acg\r\n>b\n  ACGU-ACG\t\n>empty\n\n>c\rNNNN\r..~*\r>d\nACGU\n-ACG\n\n>e\nUUUUUUUU")
+    A = fasta_reader.get_alignment_int_array(str(p), "rna")
+    assert np.array_equal(A, _text_mode_reader(str(p), "rna"))
+    assert A.tolist() == [[1, 2, 3, 4, 5, 1, 2, 3], [5] * 8, [4] * 8]            # a == b == d; c is all gaps
+    X0, raw = _lib.read_fasta(str(p), _lib.RNA)
+    assert raw == 5 and np.array_equal(X0 + 1, A)
+    q = tmp_path / "prot.fa"
+    q.write_text(">x\nacdefghiklmnpqrstvwy-.~bjouxz*1\n")
+    assert fasta_reader.get_alignment_int_array(str(q), "protein").tolist() == [list(range(1, 21)) + [21] * 11]
+    bad = tmp_path / "ragged.fa"
+    bad.write_text(">a\nACGU\n>b\nACG\n")
+    with pytest.raises(ValueError):
+        fasta_reader.get_alignment_int_array(str(bad), "rna")
+    empty = tmp_path / "empty.fa"
+    empty.write_text("\n\n")
+    with pytest.raises(ValueError):
+        fasta_reader.get_alignment_int_array(str(empty), "rna")
+    with pytest.raises(FileNotFoundError):
+        fasta_reader.get_alignment_int_array(str(tmp_path / "missing.fa"), "rna")
+    with pytest.raises(ValueError):
+        fasta_reader.get_alignment_int_array(str(p), "lipid")
+    u = tmp_path / "utf8.fa"
+    u.write_bytes(b">a\nACXU\n>b\nACG\xc3\xa9\n")              # 'e' with an acute accent, UTF-8: one character, two bytes
+    with pytest.raises(_lib.DcaBackendError) as ei:
+        _lib.read_fasta(str(u), _lib.RNA)
+    assert ei.value.code == _lib.DCA_ERR_RESIDUE
+    assert fasta_reader.get_alignment_int_array(str(u), "rna").tolist() == _text_mode_reader(str(u), "rna").tolist()
+
+
+def test_readers_large_alignment_with_scattered_duplicates(tmp_path):
+    """Both native readers on 20 000 x 300 with 15 % duplicates scattered through the file: first occurrences kept in
+    file order (numpy reference), row hashes + memcmp, several host threads."""
+    from pydca_amd import _lib
+    from tools.gen_msa import ALPHABET, write_fasta
+    rng = np.random.default_rng(5)
+    N, L, q = 20000, 300, 21
+    base = rng.integers(0, q, size=(N, L), dtype=np.uint8)
+    dup = rng.random(N) < 0.15
+    dup[0] = False
+    src = rng.integers(0, np.maximum(np.arange(N), 1))          # an earlier row
+    X = base.copy()
+    for n in np.nonzero(dup)[0]:
+        X[n] = X[src[n]]
+    f = tmp_path / "big.fa"
+    write_fasta(str(f), X, q)
+    _, first = np.unique(X, axis=0, return_index=True)
+    expect = X[np.sort(first)]
+    got, raw = _lib.read_msa(str(f), _lib.PROTEIN, L)
+    assert raw == N and np.array_equal(got, expect)
+    got2, raw2 = _lib.read_fasta(str(f), _lib.PROTEIN)
+    assert raw2 == N and np.array_equal(got2, expect)
+    # first L' < L characters only (plmdca_numerics.cpp:750-753): more duplicates appear
+    Lp = 3
+    _, firstp = np.unique(X[:, :Lp], axis=0, return_index=True)
+    gotp, _ = _lib.read_msa(str(f), _lib.PROTEIN, Lp)
+    assert np.array_equal(gotp, X[np.sort(firstp), :Lp])
+
+
 def test_shard_bounds_partition_and_halo():
     from pydca_amd import parallel
     for n in (1, 7, 64, 1000, 50000):
