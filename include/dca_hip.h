@@ -79,6 +79,10 @@ int dca_count_msa_lines(const char* path);
  * non-ASCII bytes return DCA_ERR_RESIDUE (the Python side then reads them in text mode itself). */
 int dca_fasta_shape(const char* path, int* n_records, int* L_out);
 int dca_read_fasta(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count);
+/* The same in ONE pass over the file: the reader allocates *rows (unique rows x *L_out bytes; release with
+ * dca_host_free) and returns the number of unique rows. */
+int dca_read_fasta_alloc(const char* path, int biomolecule, uint8_t** rows, int* L_out, int* raw_count);
+void dca_host_free(void* p);
 
 /* ------------------------------------------------------------------ reference-sequence back-mapping (host)
  * Local pairwise alignment, Smith-Waterman with affine gaps (a gap of length n costs

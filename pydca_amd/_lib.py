@@ -67,6 +67,8 @@ def lib():
         "dca_count_msa_lines": (i, [C.c_char_p]),
         "dca_fasta_shape": (i, [C.c_char_p, C.POINTER(i), C.POINTER(i)]),
         "dca_read_fasta": (i, [C.c_char_p, i, i, vp, i, C.POINTER(i)]),
+        "dca_read_fasta_alloc": (i, [C.c_char_p, i, C.POINTER(vp), C.POINTER(i), C.POINTER(i)]),
+        "dca_host_free": (None, [vp]),
         "dca_create": (i, [C.POINTER(vp), i, i]),
         "dca_destroy": (None, [vp]),
         "dca_set_msa": (i, [vp, vp, i, i, i]),
@@ -132,7 +134,7 @@ def lib():
 
 EXPORTS = ["dca_compute_weights_sharded", "dca_weights_partial_counts", "dca_set_weight_counts", "dca_comm_unique_id",
            "dca_comm_init", "dca_comm_destroy", "dca_plm_set_native_comm", "dca_mf_set_native_comm",
-           "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_fasta_shape", "dca_read_fasta", "dca_create",
+           "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_fasta_shape", "dca_read_fasta", "dca_read_fasta_alloc", "dca_host_free", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_num_params", "dca_plm_init_x",
            "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_di_from_arrays", "dca_di_from_fields", "dca_plm_set_vector_sharding",
@@ -195,19 +197,21 @@ def read_fasta(path, biomolecule):
     number of records read).  Raises DcaBackendError(DCA_ERR_RESIDUE) for files with non-ASCII bytes (the caller then
     reads in text mode itself), ValueError for empty files / unequal lengths like the Python reader."""
     l = lib()
-    n, L = C.c_int(0), C.c_int(0)
-    rc = l.dca_fasta_shape(os.fsencode(path), C.byref(n), C.byref(L))
-    if rc == DCA_ERR_ARG:
-        raise ValueError(l.dca_last_error().decode("utf-8", "replace"))
-    check(rc)
-    if n.value == 0:
-        raise ValueError("No sequences found in %s" % path)
-    out = np.empty((n.value, L.value), dtype=np.uint8)
-    raw = C.c_int(0)
-    k = l.dca_read_fasta(os.fsencode(path), int(biomolecule), L.value, _ptr(out), n.value, C.byref(raw))
-    if k < 0:
-        check(k)
-    return out[:k], raw.value
+    rows, L, raw = C.c_void_p(), C.c_int(0), C.c_int(0)
+    k = l.dca_read_fasta_alloc(os.fsencode(path), int(biomolecule), C.byref(rows), C.byref(L), C.byref(raw))     # one pass
+    try:
+        if k == DCA_ERR_ARG:
+            raise ValueError(l.dca_last_error().decode("utf-8", "replace"))
+        if k < 0:
+            check(k)
+        if raw.value == 0:
+            raise ValueError("No sequences found in %s" % path)
+        out = np.empty((k, L.value), dtype=np.uint8)
+        C.memmove(out.ctypes.data, rows, out.nbytes)
+    finally:
+        if rows:
+            l.dca_host_free(rows)
+    return out, raw.value
 
 
 class Context:

@@ -326,18 +326,22 @@ int index_fasta(const MappedFile& f, std::vector<FastaPiece>& pieces, std::vecto
 }
 }  // namespace
 
+static bool has_non_ascii(const MappedFile& f)
+{
+    uint64_t acc = 0;
+    size_t k = 0;
+    for (; k + 8 <= f.size; k += 8) { uint64_t v; memcpy(&v, f.data + k, 8); acc |= v; }
+    for (; k < f.size; ++k) acc |= (uint64_t)(unsigned char)f.data[k];
+    return (acc & 0x8080808080808080ull) != 0;
+}
+
 extern "C" int dca_fasta_shape(const char* path, int* n_records, int* L_out)
 {
     MappedFile f;
     if (!path || !n_records || !L_out) return DCA_ERR_ARG;
     if (!f.open(path)) { dca_set_error("Unable to open file %s", path); return DCA_ERR_IO; }
-    {   // non-ASCII bytes anywhere: byte lengths are not character counts, the text-mode reader has to take this file
-        uint64_t acc = 0;
-        size_t k = 0;
-        for (; k + 8 <= f.size; k += 8) { uint64_t v; memcpy(&v, f.data + k, 8); acc |= v; }
-        for (; k < f.size; ++k) acc |= (uint64_t)(unsigned char)f.data[k];
-        if (acc & 0x8080808080808080ull) { dca_set_error("%s holds non-ASCII bytes", path); return DCA_ERR_RESIDUE; }
-    }
+    // non-ASCII bytes anywhere: byte lengths are not character counts, the text-mode reader has to take this file
+    if (has_non_ascii(f)) { dca_set_error("%s holds non-ASCII bytes", path); return DCA_ERR_RESIDUE; }
     std::vector<FastaPiece> pieces;
     std::vector<FastaRecord> recs;
     index_fasta(f, pieces, recs);
@@ -348,10 +352,12 @@ extern "C" int dca_fasta_shape(const char* path, int* n_records, int* L_out)
     return DCA_OK;
 }
 
-// out: capacity rows of L bytes; returns the number of unique rows (>= 0) or an error code.
-extern "C" int dca_read_fasta(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count)
+// One pass: index, encode, de-duplicate.  With `out` (capacity rows of L bytes, L as dca_fasta_shape reported it) the rows
+// go there; with `owned` the reader allocates (malloc; dca_host_free) and reports the length it found in *L_io.
+// Returns the number of unique rows (>= 0) or an error code.
+static int read_fasta_core(const char* path, int biomolecule, int* L_io, uint8_t* out, int capacity, uint8_t** owned, int* raw_count)
 {
-    if (!path || !out || L <= 0 || (biomolecule != DCA_BIOMOLECULE_PROTEIN && biomolecule != DCA_BIOMOLECULE_RNA)) {
+    if (!path || !L_io || (!out && !owned) || (biomolecule != DCA_BIOMOLECULE_PROTEIN && biomolecule != DCA_BIOMOLECULE_RNA)) {
         dca_set_error("dca_read_fasta: bad arguments");
         return DCA_ERR_ARG;
     }
@@ -361,9 +367,21 @@ extern "C" int dca_read_fasta(const char* path, int biomolecule, int L, uint8_t*
     std::vector<FastaRecord> recs;
     index_fasta(f, pieces, recs);
     const size_t n = recs.size();
-    if (n > (size_t)capacity) { dca_set_error("dca_read_fasta: capacity %d too small", capacity); return DCA_ERR_ARG; }
+    const int L = out ? *L_io : (n ? (int)recs[0].len : 0);
+    *L_io = L;
+    if (out && n > (size_t)capacity) { dca_set_error("dca_read_fasta: capacity %d too small", capacity); return DCA_ERR_ARG; }
     for (const FastaRecord& r : recs)
-        if (r.len != (size_t)L) { dca_set_error("Sequences in %s do not all have the same length", path); return DCA_ERR_ARG; }
+        if (r.len != (size_t)L) {
+            // byte lengths are not character counts in a file with multi-byte characters: that one is the text-mode reader's
+            if (has_non_ascii(f)) { dca_set_error("%s holds non-ASCII bytes", path); return DCA_ERR_RESIDUE; }
+            dca_set_error("Sequences in %s do not all have the same length", path);
+            return DCA_ERR_ARG;
+        }
+    if (!out) {
+        out = static_cast<uint8_t*>(malloc(std::max<size_t>(n * (size_t)L, 1)));
+        if (!out) { dca_set_error("out of host memory"); return DCA_ERR_NOMEM; }
+        *owned = out;
+    }
     const int8_t* table = biomolecule == DCA_BIOMOLECULE_PROTEIN ? kCodes.mf_protein : kCodes.mf_rna;
     std::vector<uint64_t> hashes(n);
     std::atomic<int> nonAscii(0);
@@ -382,11 +400,31 @@ extern "C" int dca_read_fasta(const char* path, int biomolecule, int L, uint8_t*
             hashes[k] = hash_row(dst, L);
         }
     });
-    if (nonAscii.load()) { dca_set_error("%s holds non-ASCII bytes", path); return DCA_ERR_RESIDUE; }
+    if (nonAscii.load()) {
+        if (owned && *owned) { free(*owned); *owned = nullptr; }
+        dca_set_error("%s holds non-ASCII bytes", path);
+        return DCA_ERR_RESIDUE;
+    }
     const size_t kept = dedup_first_occurrence(out, hashes.data(), n, L);
     if (raw_count) *raw_count = (int)n;
     return (int)kept;
 }
+
+extern "C" int dca_read_fasta(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count)
+{
+    if (!out || L <= 0) { dca_set_error("dca_read_fasta: bad arguments"); return DCA_ERR_ARG; }
+    return read_fasta_core(path, biomolecule, &L, out, capacity, nullptr, raw_count);
+}
+
+extern "C" int dca_read_fasta_alloc(const char* path, int biomolecule, uint8_t** rows, int* L_out, int* raw_count)
+{
+    if (!rows || !L_out) { dca_set_error("dca_read_fasta_alloc: bad arguments"); return DCA_ERR_ARG; }
+    *rows = nullptr;
+    *L_out = 0;
+    return read_fasta_core(path, biomolecule, L_out, nullptr, 0, rows, raw_count);
+}
+
+extern "C" void dca_host_free(void* p) { free(p); }
 
 // ---------------------------------------------------------------------------------------------
 // Local pairwise alignment (Smith-Waterman with Gotoh's affine gaps) for the reference-sequence

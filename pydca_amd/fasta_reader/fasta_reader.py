@@ -64,7 +64,7 @@ def alignment_letter2int(alignment, biomolecule='protein'):
     """-> list of lists of 1-based integer states, duplicates removed (fasta_reader.py:122-163)."""
     biomolecule = biomolecule.strip().upper()
     if biomolecule not in ('PROTEIN', 'RNA'):
-        logger.error('\n\t{} entered. Biomolecule must be either PROTEIN or RNA'.format(biomolecule))
+        logger.error('\n\tBiomolecule {!r} is neither PROTEIN nor RNA'.format(biomolecule))
         raise ValueError
     q = 21 if biomolecule == 'PROTEIN' else 5
     table = np.full(256, q, dtype=np.int32)
@@ -77,14 +77,14 @@ def alignment_letter2int(alignment, biomolecule='protein'):
         if key not in seen:
             seen.add(key)
             rows.append(r.tolist())
-    logger.info('\n\tTotal number of sequences read from file: {}'.format(len(alignment)))
+    logger.info('\n\tRecords read from the file: {}'.format(len(alignment)))
     if not rows:
-        logger.error('\n\tNo data found in alignment in integer representation')
+        logger.error('\n\tThe alignment is empty after encoding')
         raise ValueError
     return rows
 
 
-def get_alignment_int_array(file_name, biomolecule='protein'):
+def get_alignment_int_array(file_name, biomolecule='protein', zero_based=False):
     """The de-duplicated alignment of fasta_reader.py:166-188 as an int array [N', L] of the reference's 1-based states
     (uint8; gap = q).  Read by the native reader in libdca_hip.so (one mmap, threaded encoding, hashed first-occurrence
     de-duplication: milliseconds for 10^5 sequences where the per-record Python path needs a second); files the
@@ -93,7 +93,7 @@ def get_alignment_int_array(file_name, biomolecule='protein'):
     from .. import _lib
     biomolecule = biomolecule.strip().upper()
     if biomolecule not in ('PROTEIN', 'RNA'):
-        logger.error('\n\t{} entered. Biomolecule must be either PROTEIN or RNA'.format(biomolecule))
+        logger.error('\n\tBiomolecule {!r} is neither PROTEIN nor RNA'.format(biomolecule))
         raise ValueError
     try:
         X0, raw = _lib.read_fasta(file_name, _lib.PROTEIN if biomolecule == 'PROTEIN' else _lib.RNA)
@@ -103,9 +103,10 @@ def get_alignment_int_array(file_name, biomolecule='protein'):
             raise FileNotFoundError(file_name)
         if exc.code != _lib.DCA_ERR_RESIDUE:
             raise
-        return np.array(alignment_letter2int(get_alignment_from_fasta_file(file_name), biomolecule), dtype=np.uint8)
-    logger.info('\n\tTotal number of sequences read from file: {}'.format(raw))
-    return X0 + np.uint8(1)
+        X1 = np.array(alignment_letter2int(get_alignment_from_fasta_file(file_name), biomolecule), dtype=np.uint8)
+        return X1 - np.uint8(1) if zero_based else X1
+    logger.info('\n\tRecords read from the file: {}'.format(raw))
+    return X0 if zero_based else X0 + np.uint8(1)       # zero_based: the device's coding (gap = q - 1), no extra pass
 
 
 def get_alignment_int_form(file_name, biomolecule='protein'):

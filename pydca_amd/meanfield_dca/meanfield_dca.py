@@ -35,10 +35,10 @@ class MeanFieldDCA:
         self.__pseudocount = pseudocount if pseudocount is not None else 0.5
         self.__seqid = seqid if seqid is not None else 0.8
         if self.__pseudocount >= 1.0 or self.__pseudocount < 0:
-            logger.error('\n\tValue of relative pseudo-count must be between 0 and 1.0. Typical value is 0.5')
+            logger.error('\n\tThe relative pseudocount must satisfy 0 <= pseudocount < 1 (0.5 is customary)')
             raise ValueError
         if self.__seqid > 1.0 or self.__seqid <= 0.0:
-            logger.error('\n\tValue of sequence-identity must not exceed 1 nor less than 0. Typical values are 0.7, 0.8., 0.9')
+            logger.error('\n\tThe sequence identity threshold must satisfy 0 < seqid <= 1 (0.7 to 0.9 are customary)')
             raise ValueError
         biomolecule = biomolecule.strip().upper()
         self.__msa = msa
@@ -47,26 +47,26 @@ class MeanFieldDCA:
         elif biomolecule == 'PROTEIN':
             self.__num_site_states = 21
         else:
-            logger.error('\n\tUnknown biomolecule ... must be protein (PROTEIN) or rna (RNA)')
+            logger.error('\n\tBiomolecule must be PROTEIN or RNA (any case)')
             raise ValueError
         self.__sequences = None           # list-of-lists form of the reference's `alignment` property, made on demand
         self.last_timings = {}            # seconds per stage of the most recent calls (reader, weights, scores, ranking)
         t0 = time.perf_counter()
         if isinstance(msa, str):
-            self.__X = fasta_reader.get_alignment_int_array(msa, biomolecule=biomolecule)      # uint8 [N', L], 1-based states
+            self.__X0 = fasta_reader.get_alignment_int_array(msa, biomolecule=biomolecule, zero_based=True)   # uint8 [N', L], device coding
         elif isinstance(msa, (list, tuple)) or hasattr(msa, '__iter__'):
             # an in-memory alignment: records with a .seq attribute (Bio.Align.MultipleSeqAlignment
             # in the reference, :102-104) or plain strings
             seqs = [str(getattr(rec, 'seq', rec)).strip().upper() for rec in msa]
             self.__sequences = fasta_reader.alignment_letter2int([s for s in seqs if s], biomolecule)
-            self.__X = np.array(self.__sequences, dtype=np.uint8)
+            self.__X0 = np.array(self.__sequences, dtype=np.uint8) - np.uint8(1)
         else:
             raise ValueError("Alignment input parameter is invalid")
-        self.__num_sequences, self.__sequences_len = (int(v) for v in self.__X.shape)
+        self.__num_sequences, self.__sequences_len = (int(v) for v in self.__X0.shape)
         self.__biomolecule = biomolecule
         t1 = time.perf_counter()
         self.__ctx = _lib.Context(int(device), _lib.DCA_F64)
-        self.__ctx.set_msa(self.__X - np.uint8(1), self.__num_site_states)
+        self.__ctx.set_msa(self.__X0, self.__num_site_states)
         if self.__seqid < 1.0:
             self.__sequences_weight = self.compute_sequences_weight()
         else:
@@ -95,7 +95,7 @@ class MeanFieldDCA:
     @property
     def alignment(self):
         if self.__sequences is None:
-            self.__sequences = self.__X.tolist()
+            self.__sequences = (self.__X0 + np.uint8(1)).tolist()          # the reference's 1-based states (gap = q)
         return self.__sequences
 
     @property
@@ -132,11 +132,11 @@ class MeanFieldDCA:
 
     # ---- stages (meanfield_dca.py:350-553)
     def compute_sequences_weight(self):
-        logger.info('\n\tComputing sequences weights')
+        logger.info('\n\tSequence weights (pairwise identity counts on the device)')
         return self.__ctx.compute_weights(self.__seqid, _lib.DCA_F64)
 
     def get_single_site_freqs(self):
-        logger.info('\n\tComputing single site frequencies')
+        logger.info('\n\tWeighted single-site frequencies')
         return self.__ctx.mf_single_site_freqs()
 
     def get_reg_single_site_freqs(self):
@@ -145,7 +145,7 @@ class MeanFieldDCA:
             num_site_states=self.__num_site_states, pseudocount=self.__pseudocount)
 
     def get_pair_site_freqs(self):
-        logger.info('\n\tComputing pair site frequencies')
+        logger.info('\n\tWeighted pair-site frequencies')
         return self.__ctx.mf_pair_site_freqs()
 
     def get_reg_pair_site_freqs(self):
@@ -154,7 +154,7 @@ class MeanFieldDCA:
             num_site_states=self.__num_site_states, pseudocount=self.__pseudocount)
 
     def construct_corr_mat(self, reg_fi, reg_fij):
-        logger.info('\n\tConstructing the correlation matrix')
+        logger.info('\n\tCorrelation matrix from the regularised frequencies')
         return msa_numerics.construct_corr_mat(reg_fi=reg_fi, reg_fij=reg_fij, seqs_len=self.__sequences_len,
                                                num_site_states=self.__num_site_states)
 
@@ -163,7 +163,7 @@ class MeanFieldDCA:
         try:
             couplings = msa_numerics.compute_couplings(corr_mat=corr_mat)
         except Exception as e:
-            logger.error('\n\tCorrelation {}\n\tYou set the pseudocount {}. You might need to increase it.'.format(
+            logger.error('\n\tThe correlation matrix cannot be inverted ({}): pseudocount {} is too small for this alignment, raise it.'.format(
                 e, self.__pseudocount))
             raise
         self.__couplings = couplings
@@ -176,7 +176,7 @@ class MeanFieldDCA:
         except _lib.DcaBackendError as exc:
             if exc.code == _lib.DCA_ERR_NOT_SPD:
                 e = np.linalg.LinAlgError('Singular matrix')
-                logger.error('\n\tCorrelation {}\n\tYou set the pseudocount {}. You might need to increase it.'.format(
+                logger.error('\n\tThe correlation matrix cannot be inverted ({}): pseudocount {} is too small for this alignment, raise it.'.format(
                     e, self.__pseudocount))
                 raise e
             raise
@@ -195,7 +195,7 @@ class MeanFieldDCA:
             else:
                 sorted_scores_mapped.append((mapped_pair, score))
         sorted_scores_mapped = sorted(sorted_scores_mapped, key=lambda k: k[1], reverse=True)
-        logger.info('\n\tTotal number of mapped sites: {}'.format(len(sorted_scores_mapped)))
+        logger.info('\n\tSite pairs mapped onto the reference sequence: {}'.format(len(sorted_scores_mapped)))
         return tuple(sorted_scores_mapped)
 
     def _maybe_mapped(self, ranked, seqbackmapper):
@@ -203,12 +203,12 @@ class MeanFieldDCA:
 
     def compute_sorted_FN(self, seqbackmapper=None):
         """meanfield_dca.py:902-943."""
-        logger.info('\n\tComputing Frobenius norm of couplings')
+        logger.info('\n\tFrobenius norm of every coupling block, on the device')
         return self._maybe_mapped(_ranked(self._device_scores(False), self.__sequences_len, self.__ctx), seqbackmapper)
 
     def compute_sorted_FN_APC(self, seqbackmapper=None):
         """meanfield_dca.py:946-988."""
-        logger.info('\n\tPerforming average product correction (APC) to Frobenius norm of couplings.')
+        logger.info('\n\tAverage product correction of the Frobenius-norm scores')
         t0 = time.perf_counter()
         scores = self._device_scores(True)
         t1 = time.perf_counter()
@@ -228,7 +228,7 @@ class MeanFieldDCA:
         the current pseudocount are (re)computed on the device and the field sums run there too
         (one workgroup per row of J); a caller-supplied matrix is used as given, on the host."""
         q = self.__num_site_states
-        logger.info('\n\tComputing local fields of the global probability function')
+        logger.info('\n\tLocal fields of the global model')
         if couplings is None:
             self._device_scores(False)
             f = self.__ctx.mf_fields()
@@ -260,7 +260,7 @@ class MeanFieldDCA:
         RANKING_METHODS = ('FN', 'FN_APC', 'DI', 'DI_APC')
         ranked_by = ranked_by.strip().upper()
         if ranked_by not in RANKING_METHODS:
-            logger.error('\n\tInvalid ranking criterion {}.\nChoose from {}'.format(ranked_by, RANKING_METHODS))
+            logger.error('\n\tUnknown ranking {!r}; available: {}'.format(ranked_by, RANKING_METHODS))
             raise MeanFieldDCAException
         dca_scores = {'FN': self.compute_sorted_FN, 'FN_APC': self.compute_sorted_FN_APC, 'DI': self.compute_sorted_DI,
                       'DI_APC': self.compute_sorted_DI_APC}[ranked_by](seqbackmapper=seqbackmapper)
@@ -275,7 +275,7 @@ class MeanFieldDCA:
             num_site_pairs = len(seqbackmapper.ref_sequence) if seqbackmapper is not None else len(mapping_dict.keys())
         logger.info('\n\tExtracting fields')
         fields_mapped = [(i, f[mapping_dict[i]]) for i in mapping_dict.keys()]
-        logger.info('\n\tExtracting couplings for top {} site pairs (i, j) with |i - j| > {} and ranked by {}'.format(
+        logger.info('\n\tCouplings of the best {} site pairs with |i - j| > {} in the {} ranking'.format(
             num_site_pairs, linear_dist, ranked_by))
         pairs, names = [], []
         count_pairs = 0
@@ -286,14 +286,12 @@ class MeanFieldDCA:
                     break
                 i, j = mapping_dict[pair[0]], mapping_dict[pair[1]]
                 if i > j:
-                    logger.error('\n\tInvalid site pair. Site pair (i, j) should be ordered in i < j')
+                    logger.error('\n\tSite pair out of order: i < j is required')
                     raise MeanFieldDCAException
                 pairs.append((i, j))
                 names.append(pair)
         if count_pairs < num_site_pairs:
-            logger.warning('\n\tObtained couplings for only {} ranked site pairs.'
-                           '\n\tThis is the maximum number of site paris we can obtain under '
-                           'the given criteria'.format(count_pairs))
+            logger.warning('\n\tOnly {} ranked site pairs satisfy the distance filter; their couplings are returned.'.format(count_pairs))
         blocks = self.__ctx.mf_pair_couplings(pairs, shift=True)
         couplings_ranked = [(pair, blocks[k].reshape(-1)) for k, pair in enumerate(names)]
         return tuple(fields_mapped), tuple(couplings_ranked)
@@ -312,7 +310,7 @@ class MeanFieldDCA:
         correlation matrix -> couplings -> two-site fields -> DI stays on the device (the context keeps
         the couplings of the current pseudocount resident); only the pairs' DI values come back."""
         self._device_scores(False)
-        logger.info('\n\tComputing direct information')
+        logger.info('\n\tDirect information (DI) of every site pair, on the device')
         di = self.__ctx.mf_di_scores(False)
         iu, ju = np.triu_indices(self.__sequences_len, k=1)
         return {(int(i), int(j)): di[k] for k, (i, j) in enumerate(zip(iu, ju))}
@@ -321,11 +319,11 @@ class MeanFieldDCA:
         """meanfield_dca.py:832-855 (two-site model fields + direct information, msa_numerics.py:378-533,
         one workgroup per site pair on the device)."""
         self._device_scores(False)
-        logger.info('\n\tComputing direct information')
+        logger.info('\n\tDirect information (DI) of every site pair, on the device')
         return self._maybe_mapped(_ranked(self.__ctx.mf_di_scores(False), self.__sequences_len, self.__ctx), seqbackmapper)
 
     def compute_sorted_DI_APC(self, seqbackmapper=None):
         """meanfield_dca.py:848-899."""
         self._device_scores(False)
-        logger.info('\n\tPerforming average product correction (APC) of DI scores')
+        logger.info('\n\tAverage product correction of the DI scores')
         return self._maybe_mapped(_ranked(self.__ctx.mf_di_scores(True), self.__sequences_len, self.__ctx), seqbackmapper)

@@ -38,7 +38,7 @@ class PlmDCA:
                  num_threads=None, verbose=False, device=0, precision=32, exact_gradient=False):
         self.__biomolecule = biomolecule.strip().upper()
         if self.__biomolecule not in ('PROTEIN', 'RNA'):
-            logger.error('\n\tInvalid biomolecule type {}'.format(self.__biomolecule))
+            logger.error('\n\tBiomolecule {!r} is neither PROTEIN nor RNA'.format(self.__biomolecule))
             raise PlmDCAException
         self.__msa_file = msa_file
         self.__biomolecule_int = 1 if self.__biomolecule == 'PROTEIN' else 2
@@ -46,15 +46,15 @@ class PlmDCA:
         self.__num_seqs, self.__seqs_len = self._get_num_and_len_of_seqs()
         self.__seqid = 0.8 if seqid is None else seqid
         if self.__seqid <= 0 or self.__seqid > 1.0:
-            logger.error('\n\t{} is an invalid value of sequences identity (seqid) parameter'.format(self.__seqid))
+            logger.error('\n\tseqid = {} lies outside (0, 1]'.format(self.__seqid))
             raise PlmDCAException
         self.__lambda_h = 0.2 * (self.__seqs_len - 1) if lambda_h is None else lambda_h
         if self.__lambda_h < 0:
-            logger.error('\n\tlambda_h must be a positive number. You passed lambda_h={}'.format(self.__lambda_h))
+            logger.error('\n\tlambda_h = {} is negative; the field penalty must be >= 0'.format(self.__lambda_h))
             raise PlmDCAException
         self.__lambda_J = 0.2 * (self.__seqs_len - 1) if lambda_J is None else lambda_J
         if self.__lambda_J < 0:
-            logger.error('\n\tlambda_J must be a positive number. You passed lambda_J={}'.format(self.__lambda_J))
+            logger.error('\n\tlambda_J = {} is negative; the coupling penalty must be >= 0'.format(self.__lambda_J))
             raise PlmDCAException
         self.__max_iterations = max_iterations if max_iterations is not None else 100
         self.__num_threads = 1 if num_threads is None else num_threads   # accepted, unused: the work runs on the GPU
@@ -153,7 +153,7 @@ class PlmDCA:
     def get_fields_and_couplings_from_backend(self):
         """plmdca.py:202-243 -> float32[L*q + L(L-1)/2*q*q] (one bulk copy instead of the
         reference's element-by-element Python loop)."""
-        logger.info('\n\tComputing fields and couplings using gradient decent')
+        logger.info('\n\tOptimising fields and couplings (L-BFGS on the pseudolikelihood, device resident)')
         ctx = self._run_backend()
         fields_and_couplings = ctx.plm_get_x(np.float32)
         assert fields_and_couplings.size == self.__data_size
@@ -198,7 +198,7 @@ class PlmDCA:
             else:
                 sorted_scores_mapped.append((mapped_pair, score))
         sorted_scores_mapped = sorted(sorted_scores_mapped, key=lambda k: k[1], reverse=True)
-        logger.info('\n\tTotal number of mapped sites: {}'.format(len(sorted_scores_mapped)))
+        logger.info('\n\tSite pairs mapped onto the reference sequence: {}'.format(len(sorted_scores_mapped)))
         return tuple(sorted_scores_mapped)
 
     def _maybe_mapped(self, ranked, seqbackmapper):
@@ -208,13 +208,13 @@ class PlmDCA:
         """plmdca.py:437-481."""
         ctx = self._run_backend()
         self.__fields_and_couplings_all = None
-        logger.info('\n\tComputing non-APC sorted DCA score')
+        logger.info('\n\tFrobenius-norm scores without the average product correction, ranked')
         return self._maybe_mapped(_ranked(ctx.plm_scores(False), self.__seqs_len, ctx), seqbackmapper)
 
     def compute_sorted_FN_APC(self, seqbackmapper=None):
         """plmdca.py:484-524."""
         ctx = self._run_backend()
-        logger.info('\n\tPerforming average product correction (APC) of FN  of DCA scores')
+        logger.info('\n\tAverage product correction of the Frobenius-norm scores')
         t0 = time.perf_counter()
         ranked = _ranked(ctx.plm_scores(True), self.__seqs_len, ctx)
         self.last_status['stages_s']['scores_and_ranking'] = time.perf_counter() - t0
@@ -231,7 +231,7 @@ class PlmDCA:
         RANKING_METHODS = ('FN', 'FN_APC', 'DI', 'DI_APC')
         ranked_by = ranked_by.strip().upper()
         if ranked_by not in RANKING_METHODS:
-            logger.error('\n\tInvalid ranking criterion {}.\nChoose from {}'.format(ranked_by, RANKING_METHODS))
+            logger.error('\n\tUnknown ranking {!r}; available: {}'.format(ranked_by, RANKING_METHODS))
             raise PlmDCAException
         ctx = self._run_backend()
         L, q = self.__seqs_len, self.__num_site_states
@@ -251,7 +251,7 @@ class PlmDCA:
             num_site_pairs = len(seqbackmapper.ref_sequence) if seqbackmapper is not None else len(mapping_dict.keys())
         logger.info('\n\tExtracting fields')
         fields_mapped = [(i, f[mapping_dict[i]]) for i in mapping_dict.keys()]
-        logger.info('\n\tExtracting couplings for top {} site pairs (i, j) with |i - j| > {} and ranked by {}'.format(
+        logger.info('\n\tCouplings of the best {} site pairs with |i - j| > {} in the {} ranking'.format(
             num_site_pairs, linear_dist, ranked_by))
         pairs, names = [], []
         count_pairs = 0
@@ -262,14 +262,12 @@ class PlmDCA:
                     break
                 i, j = mapping_dict[pair[0]], mapping_dict[pair[1]]
                 if i > j:
-                    logger.error('\n\tInvalid site pair. Site pair (i, j) should be ordered in i < j')
+                    logger.error('\n\tSite pair out of order: i < j is required')
                     raise PlmDCAException
                 pairs.append((i, j))
                 names.append(pair)
         if count_pairs < num_site_pairs:
-            logger.warning('\n\tObtained couplings for only {} ranked site pairs.'
-                           '\n\tThis is the maximum number of site paris we can obtain under '
-                           'the given criteria'.format(count_pairs))
+            logger.warning('\n\tOnly {} ranked site pairs satisfy the distance filter; their couplings are returned.'.format(count_pairs))
         blocks = ctx.plm_pair_couplings(pairs, shift=True).astype(np.float32)
         couplings_ranked = [(pair, blocks[k].reshape(-1)) for k, pair in enumerate(names)]
         return tuple(fields_mapped), tuple(couplings_ranked)
@@ -280,12 +278,12 @@ class PlmDCA:
         reference remembers them."""
         from ..fasta_reader import fasta_reader
         from . import msa_numerics
-        logger.info('\n\tComputing sequences weight with sequence identity {}'.format(self.__seqid))
+        logger.info('\n\tSequence weights at identity threshold {}'.format(self.__seqid))
         aln = np.array(fasta_reader.get_alignment_int_form(self.__msa_file, biomolecule=self.__biomolecule))
         seqs_weight = msa_numerics.compute_sequences_weight(alignment_data=aln, sequence_identity=self.__seqid)
         self.__seqs_weight = seqs_weight
         self.__eff_num_seqs = np.sum(seqs_weight)
-        logger.info('\n\tEffective number of sequences: {}'.format(self.__eff_num_seqs))
+        logger.info('\n\tMeff (sum of the sequence weights): {}'.format(self.__eff_num_seqs))
         return seqs_weight
 
     def compute_two_site_model_fields(self, couplings):
@@ -293,7 +291,7 @@ class PlmDCA:
         -> float64[L(L-1)/2, 2, q], one workgroup per site pair on the device."""
         from . import msa_numerics
         reg_fi = self.get_reg_single_site_freqs()
-        logger.info('\n\tComputing two-site model fields')
+        logger.info('\n\tFitting the two-site model fields of every site pair')
         return msa_numerics.compute_two_site_model_fields(couplings=couplings, reg_fi=reg_fi, seqs_len=self.__seqs_len,
                                                           num_site_states=self.__num_site_states)
 
@@ -321,7 +319,7 @@ class PlmDCA:
         """plmdca.py:683-720: DI in pair order from the optimised parameters left on the device."""
         ctx = self._run_backend()
         reg_fi = self.get_reg_single_site_freqs()
-        logger.info('\n\tComputing direct information')
+        logger.info('\n\tDirect information (DI) of every site pair, on the device')
         return ctx.plm_di_scores(reg_fi, apc)
 
     def compute_sorted_DI(self, seqbackmapper=None):
@@ -330,5 +328,5 @@ class PlmDCA:
 
     def compute_sorted_DI_APC(self, seqbackmapper=None):
         """plmdca.py:753-790."""
-        logger.info('\n\tPerforming average product correction (APC) of DI scores')
+        logger.info('\n\tAverage product correction of the DI scores')
         return self._maybe_mapped(_ranked(self.compute_direct_info_unsorted_DI(True), self.__seqs_len, self.__ctx), seqbackmapper)

@@ -49,3 +49,17 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def assert_scores_within(s_gpu, s_ref, fn_ref, rtol=1e-4):
+    """The north-star tolerance ("FN / DI scores within 1e-4 relative") for a score vector and its APC-corrected form.
+    FN and DI are positive quantities and are compared relative to themselves.  An APC-corrected score is the
+    DIFFERENCE FN_ij - av_i av_j / av of two O(FN) numbers and crosses zero, so "relative to itself" is unbounded there
+    for ANY two float64 implementations (PF02826 after 100 iterations: 7e-7 absolute on scores of 2e-5); it is compared
+    relative to the uncorrected score of the same pair: |d FN_APC_ij| <= rtol * FN_ij.  Returns the largest ratio."""
+    s_gpu, s_ref, fn_ref = (np.asarray(v, dtype=np.float64) for v in (s_gpu, s_ref, fn_ref))
+    ratio = np.abs(s_gpu - s_ref) / np.maximum(np.abs(fn_ref), 1e-300)
+    worst = int(np.argmax(ratio))
+    assert ratio[worst] <= rtol, "pair %d: %r vs %r (uncorrected score %r): %.3e > %.1e" % (
+        worst, s_gpu[worst], s_ref[worst], fn_ref[worst], ratio[worst], rtol)
+    return float(ratio[worst])
