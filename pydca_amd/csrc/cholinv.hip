@@ -38,6 +38,7 @@ struct GemmArgs {
     int lowerOnly;                 // square output: only tiles with tj <= ti; strict mirror rule on the diagonal
     int walk;                      // order in which the tiles are started, so that with a triangular operand the tiles with the
                                    // longest k range are not the ones that start last (WALK_*)
+    int row0 = 0;                  // first tile row of this launch (WALK_ROWS only): a product issued as several row bands
 };
 
 // BK = 16: the throughput form (35 KB of LDS, three workgroups per CU).  BK = 64: for the many products of
@@ -56,7 +57,7 @@ void gemm_nt_f64_kernel(GemmArgs g)
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];
     double* const As = reinterpret_cast<double*>(dca_gemm_smem);      // [2][BM * LDS_STRIDE]
     double* const Bs = As + 2 * BM * LDS_STRIDE;                      // [2][BN * LDS_STRIDE]
-    const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y + g.row0;
     const int tj = g.walk == WALK_COLUMNS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x;
     if (g.lowerOnly && tj > ti) return;
     const int tid = threadIdx.x;
@@ -261,7 +262,7 @@ void gemm_nt_f64_small_kernel(GemmArgs g)
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];
     double* const As = reinterpret_cast<double*>(dca_gemm_smem);      // [2][TM * LDS_STRIDE]
     double* const Bs = As + 2 * TM * LDS_STRIDE;
-    const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y + g.row0;
     const int tj = g.walk == WALK_COLUMNS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x;
     if (g.lowerOnly && tj > ti) return;
     const int tid = threadIdx.x;
@@ -363,7 +364,7 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
     constexpr int OPB = BM * BK * (int)sizeof(double);       // bytes of one operand tile
     typedef double double2_t __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];   // [2][A | B]
-    const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y + g.row0;
     const int tj = g.walk == WALK_COLUMNS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x;
     if (g.lowerOnly && tj > ti) return;
     const int tid = threadIdx.x;
@@ -944,6 +945,29 @@ struct Arena {
     double* alloc(size_t n) { if (top + n > cap) return nullptr; double* p = base + top; top += n; return p; }
 };
 
+// Background form of a product (side stream of the recursion): 128 x 128 tiles, issued as bands of tile rows of at most
+// `maxWGs` workgroups each.  MI355X places one such workgroup per CU before it doubles up, so a launch of fewer
+// workgroups than CUs leaves whole CUs to the kernels of another stream: the chain of single-workgroup leaves and
+// few-tile products of a subtree runs next to it at its own pace (tools/experiments/overlap_bench.hip: 200 leaves
+// 45.6 us each alone, 45.7 next to 255-workgroup launches that sustain 54 TF, 49 -- and the product at 25 TF -- next to
+// 256).  WALK_ROWS only.
+int launch_gemm_banded(dca_ctx* ctx, hipStream_t stream, GemmArgs g, int maxWGs)
+{
+    static bool attr128 = false;
+    if (!attr128) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 16 * 8));
+        attr128 = true;
+    }
+    const int gx = (g.N + 127) / 128, gy = (g.M + 127) / 128;
+    const int band = std::max(1, maxWGs / gx);
+    for (int r = 0; r < gy; r += band) {
+        g.row0 = r;
+        hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<4>, dim3(gx, std::min(band, gy - r)), dim3(256), (size_t)4 * 128 * 16 * sizeof(double), stream, g);
+    }
+    HIP_TRY(hipGetLastError());
+    return DCA_OK;
+}
+
 int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
 {
     dim3 grid(g.N / BN, g.M / BM);
@@ -1008,7 +1032,26 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
     return DCA_OK;
 }
 
-int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws, int* dInfo)
+// Side streams of the recursion, one per depth (a node's background product must not queue behind its ancestors'); the
+// context's own stream carries the critical path.
+constexpr int kSideDepths = DCA_SIDE_DEPTHS;
+bool side_streams_ready(dca_ctx* ctx)
+{
+    if (ctx->sideState == 0) {
+        // plain streams: with stream priorities (context stream highest, these lowest) the chain's few-tile products ran 3 - 10
+        // times slower whenever a side stream had work (10-workgroup launches at depth 2 cost the inverse 10 ms)
+        bool good = true;
+        for (int d = 0; d < kSideDepths && good; ++d) {
+            good = hipStreamCreateWithFlags(&ctx->sideStream[d], hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&ctx->sideFork[d], hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&ctx->sideJoin[d], hipEventDisableTiming) == hipSuccess;
+        }
+        ctx->sideState = good ? 1 : -1;
+    }
+    return ctx->sideState > 0;
+}
+
+int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws, int* dInfo, int depth = 0)
 {
     static const bool leaf128 = !(getenv("DCA_CHOLINV_LEAF128") && atoi(getenv("DCA_CHOLINV_LEAF128")) == 0);
     static const bool leafMfma = !(getenv("DCA_CHOLINV_LEAF_MFMA") && atoi(getenv("DCA_CHOLINV_LEAF_MFMA")) == 0);
@@ -1029,7 +1072,7 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     double* M12 = M + n1;
     double* M21 = M + (size_t)n1 * ld;
     double* M22 = M + (size_t)n1 * ld + n1;
-    DCA_TRY(cholinv_rec(ctx, M11, ld, n1, pivotBase, ws, dInfo));
+    DCA_TRY(cholinv_rec(ctx, M11, ld, n1, pivotBase, ws, dInfo, depth + 1));
     const size_t mark = ws.top;
     double* L21 = ws.alloc((size_t)n2 * n1);
     double* Tt = ws.alloc((size_t)n1 * n2);
@@ -1038,13 +1081,37 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     DCA_TRY(launch_gemm(ctx, GemmArgs{M21, ld, MASK_NONE, M11, ld, MASK_LOWER, L21, n1, nullptr, 0, n2, n1, n1, 1.0, 0.0, 0, WALK_COLUMNS_REVERSED}));
     // A22 -= L21 * L21^T (lower tiles)
     DCA_TRY(launch_gemm(ctx, GemmArgs{L21, n1, MASK_NONE, L21, n1, MASK_NONE, M22, ld, nullptr, 0, n2, n2, n1, -1.0, 1.0, 1}));
-    DCA_TRY(cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo));
-    // T^T[j][i] = sum_k X11^T[j][k] * L21[i][k];  X11^T rows are the mirrored upper part of M11 (k >= j)
-    // (running this product on a side stream next to the A22 subtree was tried twice and gained nothing: plain streams in
-    // round 1, profiles/experiments/cholinv_gemm128_v2_and_overlap.hip.txt; in round 2 a CU-masked stream
-    // (hipExtStreamCreateWithCUMask, 2 / 4 / 8 / 16 CUs of every XCD kept free for the chain of small kernels) at the two
-    // top levels: 28.1 / 27.5 / 27.1 / 25.8 ms against 26.6 without)
-    DCA_TRY(launch_gemm(ctx, GemmArgs{M11, ld, MASK_UPPER, L21, n1, MASK_NONE, Tt, n2, nullptr, 0, n1, n2, n1, 1.0, 0.0, 0}));
+    // T^T[j][i] = sum_k X11^T[j][k] * L21[i][k];  X11^T rows are the mirrored upper part of M11 (k >= j).  It needs X11 and
+    // L21 only, so at the upper levels it runs on a side stream NEXT TO the A22 subtree, whose chain of leaves and few-tile
+    // products leaves the chip idle -- as launches of fewer workgroups than CUs (launch_gemm_banded), which is what makes the
+    // overlap work: full-grid launches on a side stream (round 1) and CU-masked streams (round 2) had gained nothing.
+    static const int sideMode = getenv("DCA_CHOLINV_SIDE") ? atoi(getenv("DCA_CHOLINV_SIDE")) : 1;
+    // workgroups per background launch at depth 0, 1, 2 (0: that depth runs its product in line).  Measured at n = 10 048
+    // (inverse, ms; 24.4 - 24.6 without): depth 0 alone 40 / 80 / 120 / 240 workgroups 32.3 / 26.1 / 24.6 / 23.7 (a slow
+    // background product is waited for at the join); any background at depths 1 or 2 loses -- their subtrees are chains of
+    // few-tile products that share CUs with it (0,40,10: 36.0, 0,0,10: 25.5 without stream priorities) -- so only the top
+    // level overlaps: n = 8000: 14.7 -> 14.5, n = 6000: 7.6 -> 7.5, n = 4000: unchanged
+    static int sideBudget[kSideDepths] = {240, 0, 0};
+    static bool budgetRead = false;
+    if (!budgetRead) {
+        if (const char* e = getenv("DCA_CHOLINV_SIDE_WGS")) sscanf(e, "%d,%d,%d", &sideBudget[0], &sideBudget[1], &sideBudget[2]);
+        budgetRead = true;
+    }
+    const GemmArgs ttArgs{M11, ld, MASK_UPPER, L21, n1, MASK_NONE, Tt, n2, nullptr, 0, n1, n2, n1, 1.0, 0.0, 0};
+    bool onSide = false;
+    static const int sideMinN1 = getenv("DCA_CHOLINV_SIDE_MIN") ? atoi(getenv("DCA_CHOLINV_SIDE_MIN")) : 1024;
+    if (sideMode && depth < kSideDepths && n1 >= sideMinN1 && sideBudget[depth] > 0) {
+        if (side_streams_ready(ctx)) {
+            HIP_TRY(hipEventRecord(ctx->sideFork[depth], ctx->stream));           // L21 (and X11) are complete
+            HIP_TRY(hipStreamWaitEvent(ctx->sideStream[depth], ctx->sideFork[depth], 0));
+            DCA_TRY(launch_gemm_banded(ctx, ctx->sideStream[depth], ttArgs, sideBudget[depth]));
+            HIP_TRY(hipEventRecord(ctx->sideJoin[depth], ctx->sideStream[depth]));
+            onSide = true;
+        }
+    }
+    DCA_TRY(cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo, depth + 1));
+    if (onSide) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->sideJoin[depth], 0));
+    else DCA_TRY(launch_gemm(ctx, ttArgs));
     // X21[i][j] = -sum_k X22[i][k] * T^T[j][k];  X22 lower (k <= i); mirrored into the (1,2) block
     DCA_TRY(launch_gemm(ctx, GemmArgs{M22, ld, MASK_LOWER, Tt, n2, MASK_NONE, M21, ld, M12, ld, n2, n1, n2, -1.0, 0.0, 0, WALK_ROWS_REVERSED}));
     ws.top = mark;
@@ -1070,7 +1137,25 @@ int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* 
         double* out = dWork + (size_t)n * n;
         // scale * inv(A)[i][j] = scale * sum_{k >= max(i,j)} X[k][i] X[k][j] = scale * sum_k Xt[i][k] Xt[j][k]
         ScopedKernelClock kx(ctx, "mf_inverse_xtx");
-        rc = launch_gemm(ctx, GemmArgs{dA, n, MASK_UPPER, dA, n, MASK_UPPER, out, n, out, n, n, n, n, scale, 0.0, 1});
+        // Opt-in (DCA_CHOLINV_XTX_SPLIT=1), measured and NOT adopted: with X = [[X11, 0], [X21, X22]] the product splits into
+        // out11 = X21^T X21 + X11^T X11,  out21 = X22^T X21,  out22 = X22^T X22, which puts half of the flop into products
+        // with no or one triangular operand (128 x 128 tiles) -- but four launches with four tails instead of one:
+        // 6.25 - 6.36 ms against 5.91 - 5.99 at n = 10 048, 1.62 against 1.32 at n = 6000.
+        static const bool split = getenv("DCA_CHOLINV_XTX_SPLIT") && atoi(getenv("DCA_CHOLINV_XTX_SPLIT")) != 0;
+        const int n1 = (n / 128 / 2) * 128, n2 = n - n1;
+        if (split && n1 >= 2048) {
+            const double* Xt12 = dA + n1;                                  // X21^T: rows 0 .. n1, k over n2
+            const double* Xt22 = dA + (size_t)n1 * n + n1;                 // X22^T (upper part: k >= row)
+            double* o21 = out + (size_t)n1 * n;
+            double* o12 = out + n1;
+            double* o22 = out + (size_t)n1 * n + n1;
+            rc = launch_gemm(ctx, GemmArgs{Xt12, n, MASK_NONE, Xt12, n, MASK_NONE, out, n, out, n, n1, n1, n2, scale, 0.0, 1});
+            if (rc == DCA_OK) rc = launch_gemm(ctx, GemmArgs{dA, n, MASK_UPPER, dA, n, MASK_UPPER, out, n, out, n, n1, n1, n1, scale, 1.0, 1});
+            if (rc == DCA_OK) rc = launch_gemm(ctx, GemmArgs{Xt22, n, MASK_UPPER, Xt12, n, MASK_NONE, o21, n, o12, n, n2, n1, n2, scale, 0.0, 0});
+            if (rc == DCA_OK) rc = launch_gemm(ctx, GemmArgs{Xt22, n, MASK_UPPER, Xt22, n, MASK_UPPER, o22, n, o22, n, n2, n2, n2, scale, 0.0, 1});
+        } else {
+            rc = launch_gemm(ctx, GemmArgs{dA, n, MASK_UPPER, dA, n, MASK_UPPER, out, n, out, n, n, n, n, scale, 0.0, 1});
+        }
         *result = out;
     }
     int info = 0;

@@ -53,6 +53,8 @@ struct KernelClock {
 struct PlmEngineBase;
 struct MfEngine;
 
+#define DCA_SIDE_DEPTHS 3
+
 struct dca_ctx {
     int device = 0;
     int precision = DCA_F32;
@@ -84,6 +86,11 @@ struct dca_ctx {
     int comm_rank = 0, comm_world = 0;
     void* commStage = nullptr;        // pieces received by the direct-exchange reduce-scatter ((world - 1) slices)
     size_t commStageBytes = 0;
+
+    // side streams of the inverse's recursion (cholinv.hip), one per depth, made on first use
+    hipStream_t sideStream[DCA_SIDE_DEPTHS] = {};
+    hipEvent_t sideFork[DCA_SIDE_DEPTHS] = {}, sideJoin[DCA_SIDE_DEPTHS] = {};
+    int sideState = 0;                // 0 not made yet, 1 ready, -1 creation failed (the products then run in line)
 
     bool profiling = false;
     std::map<std::string, KernelClock> clocks;
