@@ -269,11 +269,6 @@ void dca_destroy(dca_ctx* ctx)
     dca_comm_destroy_impl(ctx);
     dca_flush_clocks(ctx);
     free_msa(ctx);
-    for (int d = 0; d < DCA_SIDE_DEPTHS; ++d) {
-        if (ctx->sideStream[d]) { hipStreamSynchronize(ctx->sideStream[d]); hipStreamDestroy(ctx->sideStream[d]); }
-        if (ctx->sideFork[d]) hipEventDestroy(ctx->sideFork[d]);
-        if (ctx->sideJoin[d]) hipEventDestroy(ctx->sideJoin[d]);
-    }
     dca_dev_free(ctx->dScal);
     if (ctx->hScal) hipHostFree(ctx->hScal);
     if (ctx->stream) hipStreamDestroy(ctx->stream);

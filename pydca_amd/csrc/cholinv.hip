@@ -16,6 +16,7 @@
 // K-contiguous), which is why X is kept mirrored: X^T rows are then plain rows.
 // The 64x64 diagonal leaves (Cholesky + triangular inverse) run in one workgroup in LDS.
 #include <climits>
+#include <mutex>
 #include "dca_internal.h"
 
 namespace {
@@ -252,8 +253,7 @@ void gemm_nt_f64_kernel(GemmArgs g)
 // recursion (plain product of n = 640: 34 -> 21 us, n = 256: 16 -> 8, the 2 x 2-tile products of the 256-nodes 10.6 -> 5.2 us;
 // inverse at n = 10 048: 27.1 -> 24.2 ms, at n = 4000: 4.96 -> 3.95 ms).  Same staging as gemm_nt_f64_kernel<64> (one pass of 32 rows per operand), each wave
 // one 16 x 16 accumulator.
-__global__ __launch_bounds__(256)
-void gemm_nt_f64_small_kernel(GemmArgs g)
+__device__ __forceinline__ void gemm_nt_f64_small_tile(const GemmArgs& g, int bx, int by, int gy)
 {
     constexpr int TM = 32, BK = 64;
     constexpr int LDS_STRIDE = BK + 2;
@@ -262,8 +262,8 @@ void gemm_nt_f64_small_kernel(GemmArgs g)
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];
     double* const As = reinterpret_cast<double*>(dca_gemm_smem);      // [2][TM * LDS_STRIDE]
     double* const Bs = As + 2 * TM * LDS_STRIDE;
-    const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y + g.row0;
-    const int tj = g.walk == WALK_COLUMNS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x;
+    const int ti = g.walk == WALK_COLUMNS_REVERSED ? bx : g.walk == WALK_ROWS_REVERSED ? gy - 1 - by : by + g.row0;
+    const int tj = g.walk == WALK_COLUMNS_REVERSED ? gy - 1 - by : bx;
     if (g.lowerOnly && tj > ti) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -343,6 +343,24 @@ void gemm_nt_f64_small_kernel(GemmArgs g)
         *cp = v;
         if (g.Cm && !(g.lowerOnly && i == j)) g.Cm[(size_t)j * g.ldcm + i] = v;
     }
+}
+
+__global__ __launch_bounds__(256)
+void gemm_nt_f64_small_kernel(GemmArgs g)
+{
+    gemm_nt_f64_small_tile(g, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// Two INDEPENDENT few-tile products in one launch (blockIdx.z picks; the grid is the larger of the two): the recursion's
+// A22 -= L21 L21^T and T^T = X11^T L21^T both need L21 and nothing of each other, and at the lower levels a launch costs
+// what its handful of tiles cost.
+__global__ __launch_bounds__(256)
+void gemm_nt_f64_small_pair_kernel(GemmArgs g0, int gx0, int gy0, GemmArgs g1, int gx1, int gy1)
+{
+    const bool second = blockIdx.z != 0;
+    const int gx = second ? gx1 : gx0, gy = second ? gy1 : gy0;
+    if ((int)blockIdx.x >= gx || (int)blockIdx.y >= gy) return;
+    gemm_nt_f64_small_tile(second ? g1 : g0, (int)blockIdx.x, (int)blockIdx.y, gy);
 }
 
 // The same product with the operand tiles brought into LDS by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight
@@ -968,12 +986,36 @@ int launch_gemm_banded(dca_ctx* ctx, hipStream_t stream, GemmArgs g, int maxWGs)
     return DCA_OK;
 }
 
+static int small32_max()
+{
+    static const int v = getenv("DCA_GEMM_SMALL32_MAX") ? atoi(getenv("DCA_GEMM_SMALL32_MAX")) : 400;     // 0: the 64 x 64 deep kernel
+    return v;
+}
+static dim3 grid64(const GemmArgs& g) { return g.walk == WALK_COLUMNS_REVERSED ? dim3(g.M / BM, g.N / BN) : dim3(g.N / BN, g.M / BM); }
+
+// both products on 32 x 32 tiles in ONE launch when each is small enough for that kernel; false: launch them one by one
+bool launch_gemm_small_pair(dca_ctx* ctx, const GemmArgs& a, const GemmArgs& b)
+{
+    static const bool on = !(getenv("DCA_GEMM_PAIR") && atoi(getenv("DCA_GEMM_PAIR")) == 0);
+    const dim3 ga = grid64(a), gb = grid64(b);
+    if (!on || (long long)ga.x * ga.y > small32_max() || (long long)gb.x * gb.y > small32_max()) return false;
+    const size_t lds = (size_t)2 * (32 + 32) * (64 + 2) * sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        attr = true;
+    }
+    const dim3 grid(std::max(ga.x, gb.x) * 2, std::max(ga.y, gb.y) * 2, 2);
+    hipLaunchKernelGGL(gemm_nt_f64_small_pair_kernel, grid, dim3(256), lds, ctx->stream, a, (int)ga.x * 2, (int)ga.y * 2, b, (int)gb.x * 2, (int)gb.y * 2);
+    return true;
+}
+
 int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
 {
     dim3 grid(g.N / BN, g.M / BM);
     if (g.walk == WALK_COLUMNS_REVERSED) grid = dim3(g.M / BM, g.N / BN);
     static const int deepMaxTiles = getenv("DCA_GEMM_DEEP_MAX_TILES") ? atoi(getenv("DCA_GEMM_DEEP_MAX_TILES")) : 400;
-    static const int small32Max = getenv("DCA_GEMM_SMALL32_MAX") ? atoi(getenv("DCA_GEMM_SMALL32_MAX")) : 400;     // 0: the 64 x 64 deep kernel below
+    const int small32Max = small32_max();
     // inverse at n = 10 048 / 4000 by this bound: 0 -> 27.1 / 4.96 ms, 16 -> 25.8 / 4.36, 128 -> 24.7 / 4.08, 400 -> 24.2 / 3.95, 1200 -> 23.9 / 4.01, 1600 -> 24.8 / 3.99
     if ((long long)grid.x * grid.y <= small32Max) {          // far fewer tiles than CUs: 32 x 32 tiles on four times as many CUs
         dim3 g32(grid.x * 2, grid.y * 2);
@@ -1035,23 +1077,45 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
 // Side streams of the recursion, one per depth (a node's background product must not queue behind its ancestors'); the
 // context's own stream carries the critical path.
 constexpr int kSideDepths = DCA_SIDE_DEPTHS;
-bool side_streams_ready(dca_ctx* ctx)
+// Stream and event creation costs about a millisecond each -- more than the whole inverse of a small matrix -- so the sets are
+// made once per process and device and lent to one inverse at a time (contexts of several host threads get a set each).
+struct SideSet {
+    hipStream_t s[kSideDepths] = {};
+    hipEvent_t fork[kSideDepths] = {}, join[kSideDepths] = {};
+    int device = -1;
+    bool busy = false;
+};
+std::mutex g_sideMu;
+std::vector<SideSet*> g_sideSets;          // never destroyed: the HIP runtime may be gone at exit
+
+SideSet* side_set_acquire(int device)
 {
-    if (ctx->sideState == 0) {
-        // plain streams: with stream priorities (context stream highest, these lowest) the chain's few-tile products ran 3 - 10
-        // times slower whenever a side stream had work (10-workgroup launches at depth 2 cost the inverse 10 ms)
-        bool good = true;
-        for (int d = 0; d < kSideDepths && good; ++d) {
-            good = hipStreamCreateWithFlags(&ctx->sideStream[d], hipStreamNonBlocking) == hipSuccess &&
-                   hipEventCreateWithFlags(&ctx->sideFork[d], hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&ctx->sideJoin[d], hipEventDisableTiming) == hipSuccess;
-        }
-        ctx->sideState = good ? 1 : -1;
+    std::lock_guard<std::mutex> lk(g_sideMu);
+    for (SideSet* S : g_sideSets)
+        if (S->device == device && !S->busy) { S->busy = true; return S; }
+    SideSet* S = new SideSet();
+    S->device = device;
+    // plain streams: with stream priorities (context stream highest, these lowest) the chain's few-tile products ran 3 - 10
+    // times slower whenever a side stream had work (10-workgroup launches at depth 2 cost the inverse 10 ms)
+    bool good = true;
+    for (int d = 0; d < kSideDepths && good; ++d) {
+        good = hipStreamCreateWithFlags(&S->s[d], hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&S->fork[d], hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&S->join[d], hipEventDisableTiming) == hipSuccess;
     }
-    return ctx->sideState > 0;
+    if (!good) { delete S; return nullptr; }      // the products then run in line
+    S->busy = true;
+    g_sideSets.push_back(S);
+    return S;
+}
+void side_set_release(SideSet* S)
+{
+    if (!S) return;
+    std::lock_guard<std::mutex> lk(g_sideMu);
+    S->busy = false;
 }
 
-int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws, int* dInfo, int depth = 0)
+int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws, int* dInfo, SideSet* side, int depth = 0)
 {
     static const bool leaf128 = !(getenv("DCA_CHOLINV_LEAF128") && atoi(getenv("DCA_CHOLINV_LEAF128")) == 0);
     static const bool leafMfma = !(getenv("DCA_CHOLINV_LEAF_MFMA") && atoi(getenv("DCA_CHOLINV_LEAF_MFMA")) == 0);
@@ -1072,15 +1136,18 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     double* M12 = M + n1;
     double* M21 = M + (size_t)n1 * ld;
     double* M22 = M + (size_t)n1 * ld + n1;
-    DCA_TRY(cholinv_rec(ctx, M11, ld, n1, pivotBase, ws, dInfo, depth + 1));
+    DCA_TRY(cholinv_rec(ctx, M11, ld, n1, pivotBase, ws, dInfo, side, depth + 1));
     const size_t mark = ws.top;
     double* L21 = ws.alloc((size_t)n2 * n1);
     double* Tt = ws.alloc((size_t)n1 * n2);
     if (!L21 || !Tt) { dca_set_error("cholinv workspace exhausted"); return DCA_ERR_NOMEM; }
     // L21 = A21 * X11^T : C[i][j] = sum_k A21[i][k] * X11[j][k],  X11 lower (k <= j)
     DCA_TRY(launch_gemm(ctx, GemmArgs{M21, ld, MASK_NONE, M11, ld, MASK_LOWER, L21, n1, nullptr, 0, n2, n1, n1, 1.0, 0.0, 0, WALK_COLUMNS_REVERSED}));
-    // A22 -= L21 * L21^T (lower tiles)
-    DCA_TRY(launch_gemm(ctx, GemmArgs{L21, n1, MASK_NONE, L21, n1, MASK_NONE, M22, ld, nullptr, 0, n2, n2, n1, -1.0, 1.0, 1}));
+    // A22 -= L21 * L21^T (lower tiles); at the lower levels together with T^T in one launch
+    const GemmArgs syrkArgs{L21, n1, MASK_NONE, L21, n1, MASK_NONE, M22, ld, nullptr, 0, n2, n2, n1, -1.0, 1.0, 1};
+    const GemmArgs ttArgs{M11, ld, MASK_UPPER, L21, n1, MASK_NONE, Tt, n2, nullptr, 0, n1, n2, n1, 1.0, 0.0, 0};
+    const bool paired = launch_gemm_small_pair(ctx, syrkArgs, ttArgs);
+    if (!paired) DCA_TRY(launch_gemm(ctx, syrkArgs));
     // T^T[j][i] = sum_k X11^T[j][k] * L21[i][k];  X11^T rows are the mirrored upper part of M11 (k >= j).  It needs X11 and
     // L21 only, so at the upper levels it runs on a side stream NEXT TO the A22 subtree, whose chain of leaves and few-tile
     // products leaves the chip idle -- as launches of fewer workgroups than CUs (launch_gemm_banded), which is what makes the
@@ -1097,21 +1164,20 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
         if (const char* e = getenv("DCA_CHOLINV_SIDE_WGS")) sscanf(e, "%d,%d,%d", &sideBudget[0], &sideBudget[1], &sideBudget[2]);
         budgetRead = true;
     }
-    const GemmArgs ttArgs{M11, ld, MASK_UPPER, L21, n1, MASK_NONE, Tt, n2, nullptr, 0, n1, n2, n1, 1.0, 0.0, 0};
     bool onSide = false;
     static const int sideMinN1 = getenv("DCA_CHOLINV_SIDE_MIN") ? atoi(getenv("DCA_CHOLINV_SIDE_MIN")) : 1024;
-    if (sideMode && depth < kSideDepths && n1 >= sideMinN1 && sideBudget[depth] > 0) {
-        if (side_streams_ready(ctx)) {
-            HIP_TRY(hipEventRecord(ctx->sideFork[depth], ctx->stream));           // L21 (and X11) are complete
-            HIP_TRY(hipStreamWaitEvent(ctx->sideStream[depth], ctx->sideFork[depth], 0));
-            DCA_TRY(launch_gemm_banded(ctx, ctx->sideStream[depth], ttArgs, sideBudget[depth]));
-            HIP_TRY(hipEventRecord(ctx->sideJoin[depth], ctx->sideStream[depth]));
+    if (!paired && sideMode && depth < kSideDepths && n1 >= sideMinN1 && sideBudget[depth] > 0) {
+        if (side) {
+            HIP_TRY(hipEventRecord(side->fork[depth], ctx->stream));              // L21 (and X11) are complete
+            HIP_TRY(hipStreamWaitEvent(side->s[depth], side->fork[depth], 0));
+            DCA_TRY(launch_gemm_banded(ctx, side->s[depth], ttArgs, sideBudget[depth]));
+            HIP_TRY(hipEventRecord(side->join[depth], side->s[depth]));
             onSide = true;
         }
     }
-    DCA_TRY(cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo, depth + 1));
-    if (onSide) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->sideJoin[depth], 0));
-    else DCA_TRY(launch_gemm(ctx, ttArgs));
+    DCA_TRY(cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo, side, depth + 1));
+    if (onSide) HIP_TRY(hipStreamWaitEvent(ctx->stream, side->join[depth], 0));
+    else if (!paired) DCA_TRY(launch_gemm(ctx, ttArgs));
     // X21[i][j] = -sum_k X22[i][k] * T^T[j][k];  X22 lower (k <= i); mirrored into the (1,2) block
     DCA_TRY(launch_gemm(ctx, GemmArgs{M22, ld, MASK_LOWER, Tt, n2, MASK_NONE, M21, ld, M12, ld, n2, n1, n2, -1.0, 0.0, 0, WALK_ROWS_REVERSED}));
     ws.top = mark;
@@ -1131,7 +1197,11 @@ int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* 
     int rc;
     {
         ScopedKernelClock kr(ctx, "mf_inverse_recursion");
-        rc = cholinv_rec(ctx, dA, n, n, 0, ws, dInfo);
+        // a set of side streams only where the recursion will use one (see cholinv_rec); everything they run is joined
+        // into ctx->stream before the recursion returns, so the set can go back as soon as the launches are enqueued
+        SideSet* side = n >= 2048 ? side_set_acquire(ctx->device) : nullptr;
+        rc = cholinv_rec(ctx, dA, n, n, 0, ws, dInfo, side);
+        side_set_release(side);
     }
     if (rc == DCA_OK) {
         double* out = dWork + (size_t)n * n;

@@ -87,11 +87,6 @@ struct dca_ctx {
     void* commStage = nullptr;        // pieces received by the direct-exchange reduce-scatter ((world - 1) slices)
     size_t commStageBytes = 0;
 
-    // side streams of the inverse's recursion (cholinv.hip), one per depth, made on first use
-    hipStream_t sideStream[DCA_SIDE_DEPTHS] = {};
-    hipEvent_t sideFork[DCA_SIDE_DEPTHS] = {}, sideJoin[DCA_SIDE_DEPTHS] = {};
-    int sideState = 0;                // 0 not made yet, 1 ready, -1 creation failed (the products then run in line)
-
     bool profiling = false;
     std::map<std::string, KernelClock> clocks;
 };
