@@ -133,6 +133,51 @@ def cpu_baseline(X, q, lh, lJ, evals_per_iter, sample_rows):
     return out
 
 
+def rna_workload_block(device, steps=10, warmup=3):
+    """Config E (plmdca rna, L=150 N=200k q=5: BASELINE.json's "bandwidth-bound regime" case) on this GPU, beside the headline
+    configuration: iterations/s and what its two gather kernels reach of the same roofs.  q = 5 runs other kernel
+    variants than q = 21 (logits: 16 waves x 48 sequences, scatter: strips dealt to the XCDs by (strip, split))."""
+    from pydca_amd import _lib
+    from tools.gen_msa import dedup, generate
+    from tools.gen_plm_asm import LOGITS_CFG
+    L, N, q, seed, lh, lJ = WORKLOADS["E"]
+    X = dedup(generate(L, N, q, seed))
+    N = X.shape[0]
+    ctx = _lib.Context(device, _lib.DCA_F32)
+    ctx.set_msa(X, q)
+    ctx.set_profiling(True)
+    ctx.compute_weights(0.8, _lib.DCA_F32)
+    t_w, _ = ctx.kernel_time("weights")
+    ctx.plm_configure(lh, lJ, _lib.CARRY_CHUNKED)
+    ctx.plm_init_x()
+    ctx.plm_lbfgs_begin(steps + warmup + 1000)
+    st = ctx.plm_lbfgs_iterate(warmup)
+    it0, ev0 = st.iterations, st.evaluations
+    ctx.reset_kernel_times()
+    t0 = time.perf_counter()
+    st = ctx.plm_lbfgs_iterate(steps)
+    dt = time.perf_counter() - t0
+    done = st.iterations - it0
+    kt = {tag: ctx.kernel_time(tag) for tag in ("plm_expand", "plm_logits", "plm_softmax", "plm_scatter", "plm_fold", "lbfgs_vec")}
+    Lq, esz = L * q, 4
+    units = N * L * (Lq * esz / 512.0)
+    out = {"workload": "plmdca rna, synthetic MSA L=%d N=%d q=%d, lambda=%g" % (L, N, q, lh), "value": done / dt, "unit": "iterations/s",
+           "ms_per_step": dt / max(done, 1) * 1e3, "evaluations_per_iteration": (st.evaluations - ev0) / max(done, 1),
+           "weights_kernel_ms": t_w, "kernels": {k: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in kt.items()}, "roofline": {}}
+    alg = {"plm_logits": Lq * Lq * esz + N * L + N * Lq * esz, "plm_scatter": N * Lq * esz + Lq * Lq * esz + N * L * 2,
+           "plm_softmax": 2 * N * Lq * esz + N * L + 4 * N}
+    lds = {"plm_logits": units * q * 512.0 / LOGITS_CFG[q][1], "plm_scatter": units * 512.0 / 2}
+    for k in ("plm_logits", "plm_scatter", "plm_softmax"):
+        avg_s = kt[k][0] / max(kt[k][1], 1) / 1e3
+        r = {"avg_kernel_ms": avg_s * 1e3, "hbm": {"achieved": alg[k] / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg[k] / avg_s / 1e9 / HBM_PEAK_GBS}}
+        if k in lds:
+            r["valu"] = {"achieved": N * L * Lq / avg_s / 1e12, "peak": 78.6, "unit": "Tadd/s", "frac": N * L * Lq / avg_s / 1e12 / 78.6}
+            r["onchip"] = {"achieved": lds[k] / avg_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": lds[k] / avg_s / 1e9 / LDS_PEAK_GBS}
+        out["roofline"][k] = r
+    ctx.close()
+    return out
+
+
 def end_to_end(X, L, q, lh, lJ, device):
     """SURVEY 8 d2's end-to-end figures, outside the headline's timed region: what `plmdca compute_fn <bio> <file> --apc`
     (plmdca_main.py:136-256; max_iterations = the reference's default 100) and `mfdca compute_fn <bio> <file> --apc` do, from
@@ -188,6 +233,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mfdca", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-rna", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
     args = ap.parse_args()
 
@@ -270,6 +316,7 @@ def main():
     w32 = (np.float32(1.0) / counts.astype(np.float32)).astype(np.float32)
     t_weights_ms, _ = full.kernel_time("weights")
     hook = None
+    comm_selection = None
     scheme = "1 GPU"
     if world == 1:
         ctx = full
@@ -288,8 +335,38 @@ def main():
         allreduce = os.environ.get("DCA_BENCH_ALLREDUCE") == "1" or (small and os.environ.get("DCA_BENCH_VECTORS") != "1")
         if native:
             native = native_comm_up(ctx)
+        comm_selection = None
         if native:
-            ctx.plm_set_native_comm(1 if allreduce else 2)
+            # Which exchange scheme the wires like cannot be known before it runs on them: time the
+            # three native schemes once on this node -- all-reduce of g (1), RCCL reduce-scatter + all-gather with sharded
+            # optimiser vectors (2), the same as a direct exchange of grouped send / recv (3) -- and keep the fastest.
+            # DCA_BENCH_SCHEME=1|2|3 forces one; DCA_BENCH_ALLREDUCE / DCA_BENCH_VECTORS keep their meaning.
+            forced = os.environ.get("DCA_BENCH_SCHEME")
+            if forced:
+                chosen, timings = int(forced), {}
+            elif os.environ.get("DCA_BENCH_ALLREDUCE") == "1":
+                chosen, timings = 1, {}
+            else:
+                timings = {}
+                for mode in (1, 2, 3):
+                    ctx.plm_set_native_comm(mode)
+                    ctx.plm_gradient()                                   # warm: RCCL sets its channels up on first use
+                    barrier()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        ctx.plm_gradient()
+                    barrier()
+                    tm = torch.tensor([(time.perf_counter() - t1) / 3.0], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                    timings[mode] = float(tm.item()) * 1e3
+                # the sharded schemes also divide the optimiser's vector work by the world size: an evaluation-only timing
+                # is biased towards mode 1 by about that much, so mode 1 has to win by more than the vector work it keeps
+                chosen = min(timings, key=lambda m: timings[m] + (0.0 if m != 1 else 1.3 * (ctx.num_params() / 55e6) * (1.0 - 1.0 / world)))
+            ctx.plm_set_native_comm(chosen)
+            allreduce = chosen == 1
+            comm_selection = {"evaluation_plus_exchange_ms": timings, "chosen_mode": chosen, "rccl_ranks": world,
+                              "modes": {"1": "all-reduce(g)", "2": "RCCL reduce-scatter(g) + all-gather(x), sharded vectors",
+                                        "3": "direct exchange (grouped send / recv + rank-ordered local sum), sharded vectors"}}
         elif allreduce:
             hook = parallel.TorchAllReduceHook(local_rank)
             ctx.plm_set_reduce_hook(hook)
@@ -299,6 +376,8 @@ def main():
         scheme = ("sequences sharded x%d, all-reduce(g) over RCCL" % world if allreduce else
                   "sequences sharded x%d, reduce-scatter(g) + all-gather(x) over RCCL, L-BFGS vectors sharded x%d" % (world, world))
         scheme += ", native collectives on the library's stream" if native else ", torch.distributed hooks"
+        if comm_selection is not None:
+            scheme += "; exchange mode %d of 3 picked by a start-up timing, RCCL communicator of %d ranks" % (comm_selection["chosen_mode"], world)
     t_setup = time.perf_counter() - t0
 
     # ---- warm-up iterations, then exactly K timed iterations
@@ -391,6 +470,8 @@ def main():
         "kernels": kernels_ms, "roofline": roofline,
         "host_cores": os.cpu_count(),
     }
+    if world > 1 and comm_selection is not None:
+        out["comm_selection"] = comm_selection
 
     if world == 1 and not args.no_mfdca:
         # second half of the headline metric: mfDCA residue pairs/s, encoded MSA on host ->
@@ -432,6 +513,12 @@ def main():
             out["e2e"] = end_to_end(X, L, q, lh, lJ, local_rank)
         except Exception as exc:   # pragma: no cover
             out["e2e"] = {"error": repr(exc)}
+
+    if world == 1 and args.workload == "D" and not args.no_rna:
+        try:
+            out["workload_E"] = rna_workload_block(local_rank)
+        except Exception as exc:   # pragma: no cover
+            out["workload_E"] = {"error": repr(exc)}
 
     if world == 1 and not args.no_cpu_baseline:
         sample = args.cpu_sample or max(200, min(N, int(4000 * (500.0 / L) ** 2 * (21.0 / q))))
