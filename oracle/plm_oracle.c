@@ -147,6 +147,13 @@ int oracle_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int 
 #undef REAL_SQRT
 #undef REAL_ABS
 
+/* The float64 instantiation sums the OBJECTIVE with Neumaier compensation (ORACLE_COMPENSATED_FX): the reference has no
+ * float64 build -- its float32 summation order is kept bit for bit by the instantiation above -- and the float64 oracle
+ * is this repository's deterministic parity target.  With plain sums the objective of two float64
+ * implementations differs by ~1e-13 (N*L terms in two orders); the line search interpolates on DIFFERENCES of objective
+ * values, and over 100 iterations of an optimisation that does not converge that rounding noise grows to 6e-4 in the
+ * scores at config E (profiles/r03_e_sensitivity_cap100_plain_sums.json).  A compensated sum does not depend on the order. */
+#define ORACLE_COMPENSATED_FX 1
 #define REAL double
 #define FN(name) CAT(name, _f64)
 #define REAL_EXP exp

@@ -12,6 +12,15 @@
 #error "include from plm_oracle.c"
 #endif
 
+/* (s, c) += v : plain addition in the reference's order, or Neumaier's compensated sum (see plm_oracle.c) */
+#undef FX_ADD
+#ifdef ORACLE_COMPENSATED_FX
+#define FX_ADD(s, c, v) do { const REAL _v = (v); const REAL _t = (s) + _v; \
+        if (REAL_ABS(s) >= REAL_ABS(_v)) (c) += ((s) - _t) + _v; else (c) += (_v - _t) + (s); (s) = _t; } while (0)
+#else
+#define FX_ADD(s, c, v) do { (s) += (v); } while (0)
+#endif
+
 /* ---- sequence weights: plmdca_numerics.cpp:611-671 (OpenMP branch :627-645)
  * and meanfield_dca/msa_numerics.py:13-50 for the double variant.
  * count_n = #{m : (REAL)ident(n,m)/(REAL)L > seqid}, self included; w = 1/count. */
@@ -78,23 +87,23 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
     const size_t nh = (size_t)L * q;
     const size_t q2 = (size_t)q * q;
     const size_t npairs = (size_t)L * (L - 1) / 2;
-    REAL fx = 0;
+    REAL fx = 0, fxc = 0;      /* fxc: compensation term (stays 0 in the reference-order float instantiation) */
 
     /* L2 terms, :463-486 -- sequential REAL sums in parameter order */
     for (size_t k = 0; k < nh; ++k) {
         g[k] = (REAL)2 * lambda_h * x[k];
-        fx += lambda_h * x[k] * x[k];
+        FX_ADD(fx, fxc, lambda_h * x[k] * x[k]);
     }
     for (size_t k = nh; k < nh + npairs * q2; ++k) {
         g[k] = (REAL)2 * lambda_J * x[k];
-        fx += lambda_J * x[k] * x[k];
+        FX_ADD(fx, fxc, lambda_J * x[k] * x[k]);
     }
 
     /* per-site scratch: cg[i] holds L*q*q entries in pair orientation
      * (state of the smaller site first), as :494,:541-567 */
     REAL* cg = (REAL*)malloc((size_t)L * L * q2 * sizeof(REAL));     /* every block a site owns is written below; [i][i] is never read */
     REAL* hg = (REAL*)calloc(nh, sizeof(REAL));
-    REAL* fsite = (REAL*)calloc(L, sizeof(REAL));
+    REAL* fsite = (REAL*)calloc(2 * (size_t)L, sizeof(REAL));      /* per site: sum, compensation */
     if (!cg || !hg || !fsite) { free(cg); free(hg); free(fsite); return (REAL)NAN; }
 
     /* Per site the reference walks x with stride q for the partners j > i (:515, :553-563).  Here every thread first copies
@@ -119,7 +128,7 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
             REAL p[64];
             REAL* cgi = cg + (size_t)i * L * q2;
             REAL* hgi = hg + (size_t)i * q;
-            REAL fi = 0;
+            REAL fi = 0, fic = 0;
             for (int j = 0; j < i; ++j) memcpy(Wi + (size_t)j * q2, x + nh + plm_pair_index(L, j, i) * q2, q2 * sizeof(REAL));
             for (int j = i + 1; j < L; ++j) {
                 const REAL* Jij = x + nh + plm_pair_index(L, i, j) * q2;
@@ -150,7 +159,7 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
 
                 const REAL wn = w[n];
                 const int ri = s[i];
-                fi -= wn * REAL_LOG(p[ri]);
+                FX_ADD(fi, fic, -(wn * REAL_LOG(p[ri])));
                 hgi[ri] -= wn;
                 for (int a = 0; a < q; ++a) hgi[a] += wn * p[a];
                 REAL wp[64];
@@ -169,7 +178,8 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
                 REAL* c = cgi + (size_t)j * q2;
                 for (int a = 0; a < q; ++a) for (int b = 0; b < q; ++b) c[(size_t)a * q + b] = Tj[(size_t)b * q + a];
             }
-            fsite[i] = fi;
+            fsite[2 * i] = fi;
+            fsite[2 * i + 1] = fic;
         }
         free(Wi); free(Ti);
     }
@@ -177,7 +187,8 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
 
     /* merge, :570-602, in ascending site order (deterministic) */
     for (int i = 0; i < L; ++i) {
-        fx += fsite[i];
+        FX_ADD(fx, fxc, fsite[2 * i]);
+        fxc += fsite[2 * i + 1];
         for (int a = 0; a < q; ++a) g[(size_t)i * q + a] += hg[(size_t)i * q + a];
     }
 #pragma omp parallel for schedule(static) num_threads(threads)
@@ -190,7 +201,7 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
         }
     }
     free(cg); free(hg); free(fsite);
-    return fx;
+    return fx + fxc;
 }
 
 /* ======================================================================

@@ -239,7 +239,7 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
 // starts `warm` sequences early from a zero carry: the carry enters the logits with
 // weight <= 1 and d softmax has 1-norm <= 1/2, so the start-up error shrinks by >= 2x
 // per step (2^-40 after the default 40) -- far below float/double rounding.
-// In: S (logit sums).  Out: R = w_n (p - delta) in a SEPARATE array, fxPart[wave] = -sum w_n log p(x_ni).
+// In: S (logit sums).  Out: R = w_n (p - delta) in a SEPARATE array, fxPart[2 wave], [2 wave + 1] = -sum w_n log p(x_ni) (hi, lo).
 // (Not in place: a chunk's warm-up rows belong to its predecessors, which would be overwriting them with R at
 // the same time -- chunk 0 has no warm-up and writes row t at its step t while chunk 1 reads it at its step t.)
 //
@@ -248,6 +248,27 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
 // through a wave-private LDS buffer (lane l then reads its q values at stride q: conflict free
 // for odd q) and written back the same way, instead of q strided 4-byte accesses per lane.
 typedef uint4 __attribute__((may_alias)) dca_u4a;
+
+// The objective is summed in double-double (error-free TwoSum): N*L terms in whatever order the kernels meet them
+// would otherwise leave ~1e-13 of rounding noise in fx, the line search interpolates on DIFFERENCES of fx, and over 100
+// iterations of an optimisation that does not converge that noise grew to 6e-4 in the scores at config E
+// (profiles/r03_e_sensitivity_cap100_plain_sums.json).  An (almost) exact sum does not depend on the order: chunked scan, serial
+// chain, any sharding and the float64 oracle (Neumaier sums) then see the same fx to the last bit or two.
+__device__ __forceinline__ void dd_add(double& hi, double& lo, double v)
+{
+    const double s = hi + v;
+    const double bb = s - hi;
+    lo += (hi - (s - bb)) + (v - bb);
+    hi = s;
+}
+__device__ __forceinline__ void dd_add2(double& hi, double& lo, double vh, double vl) { dd_add(hi, lo, vh); lo += vl; }
+__device__ __forceinline__ void dd_wave_reduce(double& hi, double& lo)       // fixed tree over the 64 lanes; lane 0 holds the sum
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const double vh = __shfl_down(hi, off), vl = __shfl_down(lo, off);
+        dd_add2(hi, lo, vh, vl);
+    }
+}
 
 template <typename T, int Q>
 __global__ __launch_bounds__(256)
@@ -267,7 +288,7 @@ void plm_softmax_kernel(const T* __restrict__ SR, T* __restrict__ Rout, const T*
     unsigned char* sIn = dca_smem + (size_t)wv * (2 * NP * 1024);
     unsigned char* sOut = sIn + NP * 1024;
     const int rowBytes = (min(64, L - i0) * Q * (int)sizeof(T) + 15) & ~15;
-    double facc = 0.0;
+    double facc = 0.0, flo = 0.0;
     if (chunkId < numChunks) {
         const int s = halo + chunkId * chunk;
         const int e = min(s + chunk, N);
@@ -323,7 +344,7 @@ void plm_softmax_kernel(const T* __restrict__ SR, T* __restrict__ Rout, const T*
                         T px = p[0];
 #pragma unroll
                         for (int a = 1; a < Q; ++a) px = (a == xi) ? p[a] : px;
-                        if (i < L) facc -= (double)(wn * t_log(px));
+                        if (i < L) dd_add(facc, flo, -(double)(wn * t_log(px)));
 #pragma unroll
                         for (int a = 0; a < Q; ++a) {
                             T r = wn * p[a];
@@ -343,9 +364,13 @@ void plm_softmax_kernel(const T* __restrict__ SR, T* __restrict__ Rout, const T*
             }
         }
     }
-    // fixed-order wave reduction, one partial per wave
-    for (int off = 32; off > 0; off >>= 1) facc += __shfl_down(facc, off);
-    if (lane == 0) fxPart[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv] = facc;
+    // fixed-order wave reduction, one (hi, lo) partial per wave
+    dd_wave_reduce(facc, flo);
+    if (lane == 0) {
+        const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv;
+        fxPart[2 * slot] = facc;
+        fxPart[2 * slot + 1] = flo;
+    }
 }
 
 // ------------------------------------------------------------------ scatter (as a gather)
@@ -576,7 +601,7 @@ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const size_t base = (size_t)L * q + (size_t)p * q2;
-    double reg = 0.0;
+    double reg = 0.0, regLo = 0.0;
     for (int t = lane; t < q2; t += 64) {
         const int a = t / q, b = t % q;
         const T xv = x[base + t];
@@ -584,10 +609,10 @@ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* 
         gv += slab_sum(G, (size_t)(i * q + a) * Cs + j * q + b, slabElems, nsplit);
         gv += tile[b * q + a];
         g[base + t] = gv;
-        if (addReg) reg += (double)lambdaJ * (double)xv * (double)xv;
+        if (addReg) dd_add(reg, regLo, (double)lambdaJ * (double)xv * (double)xv);
     }
-    for (int off = 32; off > 0; off >>= 1) reg += __shfl_down(reg, off);      // fixed tree
-    if (lane == 0) regPart[p] = reg;
+    dd_wave_reduce(reg, regLo);                                               // fixed tree
+    if (lane == 0) { regPart[2 * (size_t)p] = reg; regPart[2 * (size_t)p + 1] = regLo; }
 }
 
 // g[h_i(a)] = 2 lambda_h h + sum_n R[n][(i,a)]; the column sum of R is the sum over b of
@@ -608,13 +633,15 @@ __global__ void plm_fold_fields_kernel(const T* __restrict__ x, const T* __restr
         g[c] = gv + s;
         if (addReg) reg = (double)lambdaH * (double)xv * (double)xv;
     }
+    __shared__ double redLo[256];
     red[threadIdx.x] = reg;
+    redLo[threadIdx.x] = 0.0;
     __syncthreads();
     for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        if ((int)threadIdx.x < s) dd_add2(red[threadIdx.x], redLo[threadIdx.x], red[threadIdx.x + s], redLo[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) regPart[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) { regPart[2 * (size_t)blockIdx.x] = red[0]; regPart[2 * (size_t)blockIdx.x + 1] = redLo[0]; }
 }
 
 // ------------------------------------------------------------------ L-BFGS vector kernels
@@ -887,6 +914,44 @@ __global__ void sum_partials_kernel(const double* __restrict__ partials, int n, 
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = (add ? out[0] : 0.0) + red[0];
+}
+
+// ---- the same for (hi, lo) pairs (the objective's partial sums)
+__device__ __forceinline__ void dd_block_reduce(double& hi, double& lo, double* redHi, double* redLo)      // result in thread 0
+{
+    redHi[threadIdx.x] = hi;
+    redLo[threadIdx.x] = lo;
+    __syncthreads();
+    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) dd_add2(redHi[threadIdx.x], redLo[threadIdx.x], redHi[threadIdx.x + st], redLo[threadIdx.x + st]);
+        __syncthreads();
+    }
+    hi = redHi[0];
+    lo = redLo[0];
+    __syncthreads();
+}
+// block b sums its contiguous chunk of the n pairs into pair b of out
+__global__ __launch_bounds__(256)
+void dd_sum_chunks_kernel(const double* __restrict__ parts, int n, double* __restrict__ out)
+{
+    __shared__ double redHi[256], redLo[256];
+    const int chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int lo_ = blockIdx.x * chunk, hi_ = min(n, lo_ + chunk);
+    double hi = 0.0, lo = 0.0;
+    for (int b = lo_ + threadIdx.x; b < hi_; b += blockDim.x) dd_add2(hi, lo, parts[2 * (size_t)b], parts[2 * (size_t)b + 1]);
+    dd_block_reduce(hi, lo, redHi, redLo);
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = hi; out[2 * blockIdx.x + 1] = lo; }
+}
+// out[0] = the sum of the nA pairs of A and the nB pairs of B, rounded once
+__global__ __launch_bounds__(1024)
+void dd_sum_final_kernel(const double* __restrict__ A, int nA, const double* __restrict__ B, int nB, double* __restrict__ out)
+{
+    __shared__ double redHi[1024], redLo[1024];
+    double hi = 0.0, lo = 0.0;
+    for (int b = threadIdx.x; b < nA; b += blockDim.x) dd_add2(hi, lo, A[2 * (size_t)b], A[2 * (size_t)b + 1]);
+    for (int b = threadIdx.x; b < nB; b += blockDim.x) dd_add2(hi, lo, B[2 * (size_t)b], B[2 * (size_t)b + 1]);
+    dd_block_reduce(hi, lo, redHi, redLo);
+    if (threadIdx.x == 0) out[0] = hi + lo;
 }
 
 // first stage for long partial vectors: block b sums its contiguous chunk (fixed tree) into out[b]
@@ -1169,8 +1234,8 @@ struct PlmEngine : PlmEngineBase {
         DCA_TRY(dalloc(&dPairs, npairs));
         nFxPart = ceil_div(L, 64) * ceil_div(numScanChunks, 4) * 4;
         nRegPart = (int)npairs + ceil_div(Lq, 256);
-        DCA_TRY(dalloc(&dFxPart, nFxPart));
-        DCA_TRY(dalloc(&dRegPart, nRegPart + kSumStageBlocks));      // + the first-stage sums of the regulariser partials
+        DCA_TRY(dalloc(&dFxPart, 2 * (size_t)nFxPart));                       // (hi, lo) pairs
+        DCA_TRY(dalloc(&dRegPart, 2 * (size_t)(nRegPart + kSumStageBlocks)));      // pairs; + the first-stage sums of the regulariser partials
         DCA_TRY(dalloc(&dVecPart, 27 * kVecBlocks));
 
         HIP_TRY(hipMemsetAsync(dx, 0, (P + kVecPad) * sizeof(T), ctx->stream));
@@ -1359,13 +1424,12 @@ struct PlmEngine : PlmEngineBase {
             hipLaunchKernelGGL(plm_fold_pairs_kernel<T>, dim3((unsigned)ceil_div((int)npairs, kFoldWaves)), dim3(64 * kFoldWaves), lds, st, dx, dG, dg, dPairs,
                                dRegPart, L, q, Cs, (T)lambda_J, add_reg, (size_t)Grows * Cs, foldSlabs, (int)npairs);
             hipLaunchKernelGGL(plm_fold_fields_kernel<T>, dim3(ceil_div(Lq, 256)), dim3(256), 0, st, dx, dG, dg,
-                               dRegPart + npairs, Lq, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, foldSlabs);
+                               dRegPart + 2 * npairs, Lq, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, foldSlabs);
         }
         // fx = regulariser + data term  -> ctx->dScal[0]
         // (one partial per site pair: summed in two stages, a single workgroup needs 28 us for the 125 000 of config D)
-        hipLaunchKernelGGL(sum_chunks_kernel, dim3(kSumStageBlocks), dim3(256), 0, st, dRegPart, nRegPart, dRegPart + nRegPart);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, dRegPart + nRegPart, kSumStageBlocks, ctx->dScal, 0);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, st, dFxPart, nFxPart, ctx->dScal, 1);
+        hipLaunchKernelGGL(dd_sum_chunks_kernel, dim3(kSumStageBlocks), dim3(256), 0, st, dRegPart, nRegPart, dRegPart + 2 * (size_t)nRegPart);
+        hipLaunchKernelGGL(dd_sum_final_kernel, dim3(1), dim3(1024), 0, st, dRegPart + 2 * (size_t)nRegPart, kSumStageBlocks, dFxPart, nFxPart, ctx->dScal);
         HIP_TRY(hipGetLastError());
         return DCA_OK;
     }
