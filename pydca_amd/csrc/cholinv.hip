@@ -1147,7 +1147,6 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     const GemmArgs syrkArgs{L21, n1, MASK_NONE, L21, n1, MASK_NONE, M22, ld, nullptr, 0, n2, n2, n1, -1.0, 1.0, 1};
     const GemmArgs ttArgs{M11, ld, MASK_UPPER, L21, n1, MASK_NONE, Tt, n2, nullptr, 0, n1, n2, n1, 1.0, 0.0, 0};
     const bool paired = launch_gemm_small_pair(ctx, syrkArgs, ttArgs);
-    if (!paired) DCA_TRY(launch_gemm(ctx, syrkArgs));
     // T^T[j][i] = sum_k X11^T[j][k] * L21[i][k];  X11^T rows are the mirrored upper part of M11 (k >= j).  It needs X11 and
     // L21 only, so at the upper levels it runs on a side stream NEXT TO the A22 subtree, whose chain of leaves and few-tile
     // products leaves the chip idle -- as launches of fewer workgroups than CUs (launch_gemm_banded), which is what makes the
@@ -1166,15 +1165,21 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     }
     bool onSide = false;
     static const int sideMinN1 = getenv("DCA_CHOLINV_SIDE_MIN") ? atoi(getenv("DCA_CHOLINV_SIDE_MIN")) : 1024;
-    if (!paired && sideMode && depth < kSideDepths && n1 >= sideMinN1 && sideBudget[depth] > 0) {
-        if (side) {
-            HIP_TRY(hipEventRecord(side->fork[depth], ctx->stream));              // L21 (and X11) are complete
-            HIP_TRY(hipStreamWaitEvent(side->s[depth], side->fork[depth], 0));
-            DCA_TRY(launch_gemm_banded(ctx, side->s[depth], ttArgs, sideBudget[depth]));
-            HIP_TRY(hipEventRecord(side->join[depth], side->s[depth]));
-            onSide = true;
-        }
-    }
+    // the fork comes BEFORE the SYRK: that product's 820 lower 128 x 128 tiles fill 512 slots 1.6 times (47 TF), and the
+    // background bands take what its ragged second round leaves idle
+    static const bool forkBeforeSyrk = !(getenv("DCA_CHOLINV_SIDE_FORK") && atoi(getenv("DCA_CHOLINV_SIDE_FORK")) == 0);
+    const bool useSide = !paired && side && sideMode && depth < kSideDepths && n1 >= sideMinN1 && sideBudget[depth] > 0;
+    auto fork_side = [&]() -> int {
+        HIP_TRY(hipEventRecord(side->fork[depth], ctx->stream));                  // L21 (and X11) are complete
+        HIP_TRY(hipStreamWaitEvent(side->s[depth], side->fork[depth], 0));
+        DCA_TRY(launch_gemm_banded(ctx, side->s[depth], ttArgs, sideBudget[depth]));
+        HIP_TRY(hipEventRecord(side->join[depth], side->s[depth]));
+        onSide = true;
+        return DCA_OK;
+    };
+    if (useSide && forkBeforeSyrk) DCA_TRY(fork_side());
+    if (!paired) DCA_TRY(launch_gemm(ctx, syrkArgs));
+    if (useSide && !forkBeforeSyrk) DCA_TRY(fork_side());
     DCA_TRY(cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo, side, depth + 1));
     if (onSide) HIP_TRY(hipStreamWaitEvent(ctx->stream, side->join[depth], 0));
     else if (!paired) DCA_TRY(launch_gemm(ctx, ttArgs));

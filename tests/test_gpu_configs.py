@@ -287,7 +287,7 @@ def test_config_D_lbfgs_P3_five_iterations(L_, oracle_plm, oracle_mf):
     if (os.cpu_count() or 1) < 64:
         pytest.skip("needs the GPU box's host cores: six oracle evaluations at D")
     L, N, q, lh, lJ = FULL_SIZE["D"]
-    iters = 5
+    iters = int(os.environ.get("DCA_TEST_D_CAP", "5"))        # 25 once per round for profiles/ (half a minute per oracle evaluation)
     X = dedup(generate(L, N, q, SEEDS["D"]))
     ctx = _ctx(L_, X, q, L_.DCA_F64, L_.DCA_F64)
     w64 = ctx.weights()                                      # counts checked against the oracle elsewhere (sampled rows, bit for bit)
@@ -296,7 +296,7 @@ def test_config_D_lbfgs_P3_five_iterations(L_, oracle_plm, oracle_mf):
     ctx.plm_configure(lh, lJ, L_.CARRY_CHUNKED)
     ctx.plm_init_x()
     st, trace = stepwise(ctx, iters)
-    report = {"config": "D", "cap": iters, "gpu": [st.status, st.iterations, st.evaluations],
+    report = {"config": "D", "cap": iters, "max_rel_fx_diff_over_trajectory": float(np.max(np.abs(trace[:len(ref["trace"]), 0] - ref["trace"][:len(trace), 0]) / np.abs(ref["trace"][:len(trace), 0]))), "gpu": [st.status, st.iterations, st.evaluations],
               "oracle": [ref["status"], ref["iterations"], ref["evaluations"]], "first_divergence": first_divergence(trace, ref["trace"], 1e-7),
               "fx_gpu": st.fx, "fx_oracle": ref["fx"], "rel_err_x": rel_err(ctx.plm_get_x(np.float64), ref["x"])}
     scores_ref = {}
@@ -319,7 +319,7 @@ def test_config_D_lbfgs_P3_five_iterations(L_, oracle_plm, oracle_mf):
                          "max_rel_dev_topL_fn_apc": float(np.max(np.abs(s32[top] - scores_ref[True][top]) / np.abs(scores_ref[True][top]))),
                          "topL_overlap": len(set(top) & set(_top(s32, L)))}
     c32.close()
-    _write_report("p3_config_D_cap5.json", report)
+    _write_report("p3_config_D_cap%d.json" % iters, report)
     assert report["first_divergence"] is None, report
     assert (st.status, st.iterations, st.evaluations) == (ref["status"], ref["iterations"], ref["evaluations"]), report
     assert abs(st.fx - ref["fx"]) <= 1e-9 * abs(ref["fx"])
