@@ -26,7 +26,11 @@ template <> struct V16<float> { using type = float4; };
 template <> struct V16<double> { using type = double2; };
 
 
+#ifdef DCA_FAST_EXP
+__device__ __forceinline__ float t_exp(float v) { return __expf(v); }
+#else
 __device__ __forceinline__ float t_exp(float v) { return expf(v); }
+#endif
 __device__ __forceinline__ double t_exp(double v) { return exp(v); }
 __device__ __forceinline__ float t_log(float v) { return logf(v); }
 __device__ __forceinline__ double t_log(double v) { return log(v); }
