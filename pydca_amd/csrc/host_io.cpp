@@ -300,10 +300,18 @@ int index_fasta(const MappedFile& f, std::vector<FastaPiece>& pieces, std::vecto
         if (cur.len > 0) recs.push_back(cur);
         else pieces.resize(cur.first);
     };
+    // universal newlines, as Python's text mode: '\n', '\r\n' and a lone '\r' all end a line.  Files without any '\r' (the
+    // usual case; one memchr over the file tells) are split with memchr instead of byte by byte
+    const bool anyCR = f.size && memchr(f.data, '\r', f.size) != nullptr;
     while (p < end) {
-        // universal newlines, as Python's text mode: '\n', '\r\n' and a lone '\r' all end a line
-        const char* e = p;
-        while (e < end && *e != '\n' && *e != '\r') ++e;
+        const char* e;
+        if (anyCR) {
+            e = p;
+            while (e < end && *e != '\n' && *e != '\r') ++e;
+        } else {
+            e = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+            if (!e) e = end;
+        }
         const char* a = p;
         const char* b = e;
         while (a < b && py_space((unsigned char)*a)) ++a;

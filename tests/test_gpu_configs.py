@@ -235,10 +235,12 @@ def _write_report(name, obj):
 def test_config_C_shipped_float32_deviation_reported(L_, oracle_plm, oracle_mf, msa_C, oracle_run_C):
     """The default product mode at config C (float32 storage, chunked scan -- what `plmdcaBackend` and bench.py run)
     against the float64 oracle, both run to the reference's cap of 100 iterations: the deviation is measured at
-    iterations 10, 25, 50 and 100, written to gpurun_out/f32_deviation_config_C.json (committed under profiles/) and bounded."""
+    iterations 10 and 100 (10, 25, 50, 100 in the committed report), written to gpurun_out/f32_deviation_config_C.json and bounded."""
     X, q, L, ref = msa_C, Q_C, L_C, oracle_run_C
     w64 = ref["w64"]
-    marks = (10, 25, 50, REFERENCE_CAP)
+    # every mark below the cap costs one more oracle run to that cap; the suite checks 10 and 100, DCA_TEST_F32_MARKS=10,25,50
+    # regenerates the committed report (profiles/r03_f32_deviation_config_C_cap100.json)
+    marks = tuple(int(v) for v in os.environ.get("DCA_TEST_F32_MARKS", "10").split(",")) + (REFERENCE_CAP,)
     refs = {REFERENCE_CAP: ref}
     for m in marks[:-1]:                 # the oracle at the intermediate caps (same trajectory, stopped earlier)
         refs[m] = oracle_plm.lbfgs(X, w64, q, LAMBDA_H, LAMBDA_J, m, oracle_plm.init_x(X, w64, q), carry=True)
