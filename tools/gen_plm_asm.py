@@ -40,6 +40,9 @@ STAGE_AT = os.environ.get("DCA_GEN_STAGE_AT", "pre")
 SC_DMA_AUX = os.environ.get("DCA_GEN_SC_DMA_AUX", "")       # cache-policy bits of the scatter / logits LDS-DMA loads (experiments: " nt", " sc1" ...)
 LG_DMA_AUX = os.environ.get("DCA_GEN_LG_DMA_AUX", "")
 SC_DMA_PLAN = [int(c) for c in os.environ.get("DCA_GEN_SC_DMA_PLAN", "1111")]      # LDS-DMA pieces of the next tile issued per quarter
+# timing-only ablations of the scatter block (WRONG results): 1 no per-row lgkmcnt waits, 2 no quarter-boundary drain and
+# no state-word refresh after the first quarter, 4 no LDS row reads, 8 no M0 writes
+SC_EXP = int(os.environ.get("DCA_GEN_SC_EXP", "0"))
 assert len(SC_DMA_PLAN) == 4 and sum(SC_DMA_PLAN) == 4
 S0, T0 = 40, 72
 
@@ -116,8 +119,9 @@ def body_smem(q, f64):
                         ".Ldca_sc_skip%d_%%=:" % piece]
             if STAGE_AT == "pre":
                 o += dma
-            o.append("s_waitcnt lgkmcnt(0)")
-            if qk + 1 < 4:
+            if not (SC_EXP & 2) or qk == 0:
+                o.append("s_waitcnt lgkmcnt(0)")
+            if qk + 1 < 4 and not (SC_EXP & 2):
                 o += sload(qk + 1, sets[(qk + 1) % 2])
             if STAGE_AT == "post":
                 o += dma
@@ -127,19 +131,23 @@ def body_smem(q, f64):
             o.append("s_set_gpr_idx_off")
             o += dma
             o.append("s_set_gpr_idx_on s%d, 0x9" % sets[qk % 2])
-        o.append("s_waitcnt lgkmcnt(%d)" % min(DEPTH - 1, ROWS - 1 - r))
+        if not (SC_EXP & 1):
+            o.append("s_waitcnt lgkmcnt(%d)" % min(DEPTH - 1, ROWS - 1 - r))
         k = r % DEPTH
-        cur = sets[(r // quarter) % 2]
+        cur = sets[0 if (SC_EXP & 2) else (r // quarter) % 2]
         for jj in range(2):
             w = cur + jj * 16 + (r % quarter) // 2
-            if r % 2 == 0:
-                o.append("s_pack_ll_b32_b16 m0, s%d, 0" % w)
-            else:
-                o.append("s_lshr_b32 m0, s%d, 16" % w)
+            if not (SC_EXP & 8):
+                if r % 2 == 0:
+                    o.append("s_pack_ll_b32_b16 m0, s%d, 0" % w)
+                else:
+                    o.append("s_lshr_b32 m0, s%d, 16" % w)
             o.append("%s v[%d:%d], v[%d:%d], v[%d:%d]" % (add, acc[jj], acc[jj] + 1, acc[jj], acc[jj] + 1,
                                                          d0 + 2 * k, d0 + 2 * k + 1))
-        if r + DEPTH < ROWS:
+        if r + DEPTH < ROWS and not (SC_EXP & 4):
             o.append(ds(r + DEPTH))
+    if SC_EXP:
+        o.append("s_waitcnt lgkmcnt(0)")
     o.append("s_set_gpr_idx_off")
     o.append("s_mov_b32 m0, vcc_lo")
     return o
