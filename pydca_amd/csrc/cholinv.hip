@@ -372,19 +372,22 @@ void gemm_nt_f64_small_pair_kernel(GemmArgs g0, int gx0, int gy0, GemmArgs g1, i
 // slot s of row R is k-piece s ^ ((R >> 1) & 7) -- chosen on the global side, where every lane may fetch what it likes.
 // A fragment read (16 rows x 4 lane groups, ds_read_b128) then touches 16 different slots of the 256-byte bank window in
 // each of its four lane groups.  Triangular operands: masked on the fragments of the k-tiles that cross the diagonal.
-template <int TW>      // MFMA tiles per wave and side: 2 -> 64 x 64 output tile per workgroup, 4 -> 128 x 128 (twice the flop per operand byte)
-__global__ __launch_bounds__(256, TW == 4 ? 2 : 4)
+// MFMA tiles per wave along M and N: <2,2> -> 64 x 64 output tile per workgroup, <4,4> -> 128 x 128 (twice the flop per
+// operand byte), <4,2> -> 128 x 64 (10.7 instead of 8 flop per operand byte at three workgroups per CU: for the products
+// with two triangular operands, where the 128 x 128 form loses to its tails)
+template <int TWM, int TWN = TWM>
+__global__ __launch_bounds__(256, (TWM == 4 && TWN == 4) ? 2 : (TWM == 4 || TWN == 4) ? 3 : 4)
 void gemm_nt_f64_dma_kernel(GemmArgs g)
 {
     constexpr int BK = 16;
-    constexpr int BM = 32 * TW, BN = 32 * TW;                 // shadow the file-level 64 x 64
-    constexpr int PW = BM / 8 / 4;                            // 1 KiB DMA pieces (8 tile rows) per wave and operand
-    constexpr int OPB = BM * BK * (int)sizeof(double);       // bytes of one operand tile
+    constexpr int BM = 32 * TWM, BN = 32 * TWN;               // shadow the file-level 64 x 64
+    constexpr int PWA = BM / 8 / 4, PWB = BN / 8 / 4;         // 1 KiB DMA pieces (8 tile rows) per wave and operand
+    constexpr int OPA = BM * BK * (int)sizeof(double), OPB = BN * BK * (int)sizeof(double);       // bytes of the operand tiles
     typedef double double2_t __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];   // [2][A | B]
     const int ti = g.walk == WALK_COLUMNS_REVERSED ? (int)blockIdx.x : g.walk == WALK_ROWS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y + g.row0;
     const int tj = g.walk == WALK_COLUMNS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x;
-    if (g.lowerOnly && tj > ti) return;
+    if (g.lowerOnly && tj * BN >= (ti + 1) * BM) return;       // the tile lies entirely above the diagonal
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -397,57 +400,61 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
     kLo = kLo / BK * BK;
     const int nk = (kHi - kLo + BK - 1) / BK;
 
-    double4_t acc[TW][TW];
+    double4_t acc[TWM][TWN];
 #pragma unroll
-    for (int m = 0; m < TW; ++m)
+    for (int m = 0; m < TWM; ++m)
 #pragma unroll
-        for (int n = 0; n < TW; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int n = 0; n < TWN; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
     // DMA role of the lane: pieces PW wave .. PW wave + PW - 1 of each operand (piece = 8 tile rows); row-in-piece lane >> 3,
     // slot lane & 7.  Rows past the end of the operand (M, N multiples of 64, not of 128) are fetched from its last row:
     // their results are not stored.
-    const double* srcA[PW];
-    const double* srcB[PW];
+    const double* srcA[PWA];
+    const double* srcB[PWB];
 #pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        const int R = 8 * (PW * wave + i) + (lane >> 3);
+    for (int i = 0; i < PWA; ++i) {
+        const int R = 8 * (PWA * wave + i) + (lane >> 3);
         const int piece = (lane & 7) ^ ((R >> 1) & 7);
         srcA[i] = g.A + (size_t)min(ti * BM + R, g.M - 1) * g.lda + 2 * piece;
+    }
+#pragma unroll
+    for (int i = 0; i < PWB; ++i) {
+        const int R = 8 * (PWB * wave + i) + (lane >> 3);
+        const int piece = (lane & 7) ^ ((R >> 1) & 7);
         srcB[i] = g.B + (size_t)min(tj * BN + R, g.N - 1) * g.ldb + 2 * piece;
     }
     auto issue = [&](int buf, int k0) {
 #pragma unroll
-        for (int i = 0; i < PW; ++i) {
+        for (int i = 0; i < PWA; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * 2 * OPB + (PW * wave + i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * (OPA + OPB) + (PWA * wave + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PWB; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * 2 * OPB + OPB + (PW * wave + i) * 1024), 16, 0, 0);
-        }
+                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * (OPA + OPB) + OPA + (PWB * wave + i) * 1024), 16, 0, 0);
     };
     const int fr = lane & 15, fg = lane >> 4, swz = (fr >> 1) & 7;
     auto mma_tile = [&](int buf, int k0) {
-        const unsigned char* as = dca_gemm_smem + buf * 2 * OPB;
-        const unsigned char* bs = as + OPB;
+        const unsigned char* as = dca_gemm_smem + buf * (OPA + OPB);
+        const unsigned char* bs = as + OPA;
         const bool diagA = g.maskA != MASK_NONE && k0 + BK > ti * BM && k0 < (ti + 1) * BM;    // wave-uniform
         const bool diagB = g.maskB != MASK_NONE && k0 + BK > tj * BN && k0 < (tj + 1) * BN;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             const int slot = (4 * kk + fg) ^ swz;             // lane group fg holds k = 8 kk + 2 fg, + 1
-            double2_t a[TW], b[TW];
+            double2_t a[TWM], b[TWN];
 #pragma unroll
-            for (int m = 0; m < TW; ++m) {
-                a[m] = *reinterpret_cast<const double2_t*>(as + (wm * 16 * TW + 16 * m + fr) * 128 + slot * 16);
-                b[m] = *reinterpret_cast<const double2_t*>(bs + (wn * 16 * TW + 16 * m + fr) * 128 + slot * 16);
-            }
+            for (int m = 0; m < TWM; ++m) a[m] = *reinterpret_cast<const double2_t*>(as + (wm * 16 * TWM + 16 * m + fr) * 128 + slot * 16);
+#pragma unroll
+            for (int m = 0; m < TWN; ++m) b[m] = *reinterpret_cast<const double2_t*>(bs + (wn * 16 * TWN + 16 * m + fr) * 128 + slot * 16);
             if (diagA || diagB) {
                 // only the 16-row fragments whose rows the 8 k values of this slab actually cross need the per-element test
                 // (wave-uniform per fragment): the masking is vector-ALU work in front of the MFMAs
                 const int kmin = k0 + 8 * kk, kmax = kmin + 7;
 #pragma unroll
-                for (int m = 0; m < TW; ++m) {
-                    const int aBase = ti * BM + wm * 16 * TW + 16 * m, bBase = tj * BN + wn * 16 * TW + 16 * m;
+                for (int m = 0; m < TWM; ++m) {
+                    const int aBase = ti * BM + wm * 16 * TWM + 16 * m;
                     const bool needA = diagA && ((g.maskA == MASK_UPPER && kmin < aBase + 15) || (g.maskA == MASK_LOWER && kmax > aBase));
-                    const bool needB = diagB && ((g.maskB == MASK_UPPER && kmin < bBase + 15) || (g.maskB == MASK_LOWER && kmax > bBase));
                     if (needA) {
                         const int aRow = aBase + fr;
                         const int aLo = g.maskA == MASK_UPPER ? aRow : INT_MIN, aHi = g.maskA == MASK_LOWER ? aRow : INT_MAX;
@@ -457,6 +464,11 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
                             a[m][h] = (k < aLo || k > aHi) ? 0.0 : a[m][h];
                         }
                     }
+                }
+#pragma unroll
+                for (int m = 0; m < TWN; ++m) {
+                    const int bBase = tj * BN + wn * 16 * TWN + 16 * m;
+                    const bool needB = diagB && ((g.maskB == MASK_UPPER && kmin < bBase + 15) || (g.maskB == MASK_LOWER && kmax > bBase));
                     if (needB) {
                         const int bRow = bBase + fr;
                         const int bLo = g.maskB == MASK_UPPER ? bRow : INT_MIN, bHi = g.maskB == MASK_LOWER ? bRow : INT_MAX;
@@ -471,9 +483,9 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int m = 0; m < TW; ++m)
+                for (int m = 0; m < TWM; ++m)
 #pragma unroll
-                    for (int n = 0; n < TW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][h], b[n][h], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < TWN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][h], b[n][h], acc[m][n], 0, 0, 0);
         }
     };
 
@@ -489,13 +501,13 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
     }
 
 #pragma unroll
-    for (int m = 0; m < TW; ++m)
+    for (int m = 0; m < TWM; ++m)
 #pragma unroll
-        for (int n = 0; n < TW; ++n)
+        for (int n = 0; n < TWN; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = ti * BM + wm * 16 * TW + m * 16 + (lane >> 4) + 4 * r;
-                const int j = tj * BN + wn * 16 * TW + n * 16 + (lane & 15);
+                const int i = ti * BM + wm * 16 * TWM + m * 16 + (lane >> 4) + 4 * r;
+                const int j = tj * BN + wn * 16 * TWN + n * 16 + (lane & 15);
                 if (i >= g.M || j >= g.N) continue;
                 if (g.lowerOnly && j > i) continue;
                 double v = g.alpha * acc[m][n][r];
@@ -1055,7 +1067,17 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
             else if (masks == 1) use128 = t128 >= 1024;
             if (dma128 == 0) use128 = false;
             if (dma128 == 2) use128 = true;
-            if (use128) {
+            static const int rect = getenv("DCA_GEMM_RECT") ? atoi(getenv("DCA_GEMM_RECT")) : 1;     // 0 never, 1 two triangular operands, 2 also one
+            const bool walkOk = g.walk != WALK_COLUMNS_REVERSED;
+            if (!use128 && walkOk && rect && (masks == 2 || (rect == 2 && masks == 1)) && (long long)grid.x * grid.y >= 2048) {
+                // 128 x 64 tiles: grid.y counts 128-row tiles
+                static bool attrR = false;
+                if (!attrR) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 16 * 8));
+                    attrR = true;
+                }
+                hipLaunchKernelGGL((gemm_nt_f64_dma_kernel<4, 2>), dim3(grid.x, gy), dim3(256), (size_t)2 * (128 + 64) * 16 * sizeof(double), ctx->stream, g);
+            } else if (use128) {
                 static bool attr128 = false;
                 if (!attr128) {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 16 * 8));
