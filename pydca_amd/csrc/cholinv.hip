@@ -813,6 +813,13 @@ __device__ __forceinline__ void factor_diag_block(double (&c)[4][4], double* __r
         for (int cc = 0; cc < 4; ++cc) dinvOut[r * 4 + cc] = xi[r][cc];
 }
 
+// Barrier of the leaf's steps: what the waves exchange goes through LDS, so only the LDS counter is drained.  __syncthreads()
+// also waits for the global stores of the finished X rows (step c.), which nobody in the kernel reads: ~120 ns of the 1.4 us step.
+__device__ __forceinline__ void leaf_step_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int NB>
 __global__ __launch_bounds__(NB == 128 ? 512 : 320)
 void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info)
@@ -891,11 +898,14 @@ void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int
             }
         }
         LEAF_T(1);
-        __syncthreads();
+        leaf_step_barrier();
         LEAF_T(2);
         // ---- c. panel below the block, X rows up to it (one lane per (m, index))
         if (tid < 4 * NB) {
-            const int m = tid / NB, idx = tid % NB;
+            // indices dealt from the top: wave 0 -- whose serial chain bounds the step -- then holds the rows BELOW the block
+            // for most of the leaf (four FMAs and two LDS stores) instead of the X rows with their global stores
+            // (phase stamps: 280 -> 160 ns of its 1.44 us step)
+            const int m = tid / NB, idx = NB - 1 - tid % NB;
             double d[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) d[p] = dinv[cur][m * 4 + p];           // row m of D (lower: d[p] = 0 for p > m)
@@ -923,7 +933,7 @@ void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int
             }
         }
         LEAF_T(3);
-        __syncthreads();
+        leaf_step_barrier();
         LEAF_T(4);
         // ---- b. (wave 0, look-ahead) the next diagonal block and its D
         if (tid == 0 && kb + 1 < STEPS) {
