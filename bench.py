@@ -277,7 +277,7 @@ def main():
 
     # ---- setup (untimed, reported): weights on the full alignment, shard, lists, x0
     t0 = time.perf_counter()
-    full = _lib.Context(local_rank, _lib.DCA_F32)
+    full = _lib.Context(local_rank, _lib.DCA_F64 if args.precision == 64 else _lib.DCA_F32)     # --precision 64: the float64 checking mode
     full.set_msa(X, q)
     full.set_profiling(True)
     # exchange scheme of a multi-GPU run: the library's own RCCL communicator on its stream (default), or the
