@@ -349,8 +349,17 @@ def main():
             else:
                 timings = {}
                 for mode in (1, 2, 3):
-                    ctx.plm_set_native_comm(mode)
-                    ctx.plm_gradient()                                   # warm: RCCL sets its channels up on first use
+                    ok = 1
+                    try:
+                        ctx.plm_set_native_comm(mode)
+                        ctx.plm_gradient()                               # warm: RCCL sets its channels up on first use
+                    except Exception as exc:                             # pragma: no cover (needs a multi-GPU node)
+                        print("rank %d: exchange mode %d unavailable (%r)" % (rank, mode, exc), file=sys.stderr)
+                        ok = 0
+                    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # a mode is timed only if it came up on every rank
+                    if not bool(flag.item()):
+                        continue
                     barrier()
                     t1 = time.perf_counter()
                     for _ in range(3):
