@@ -370,7 +370,7 @@ def main():
                     timings[mode] = float(tm.item()) * 1e3
                 # the sharded schemes also divide the optimiser's vector work by the world size: an evaluation-only timing
                 # is biased towards mode 1 by about that much, so mode 1 has to win by more than the vector work it keeps
-                chosen = min(timings, key=lambda m: timings[m] + (0.0 if m != 1 else 1.3 * (ctx.num_params() / 55e6) * (1.0 - 1.0 / world)))
+                chosen = 2 if not timings else min(timings, key=lambda m: timings[m] + (0.0 if m != 1 else 1.3 * (ctx.num_params() / 55e6) * (1.0 - 1.0 / world)))
             ctx.plm_set_native_comm(chosen)
             allreduce = chosen == 1
             comm_selection = {"evaluation_plus_exchange_ms": timings, "chosen_mode": chosen, "rccl_ranks": world,
