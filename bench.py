@@ -30,6 +30,19 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 LDS_PEAK_GBS = 256 * 256 * 2.4    # 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 TB/s (MI355X_MICROARCH.md, LDS)
 
 
+def kernel_sources_fingerprint():
+    """sha256 over the sources of the plmDCA kernels (the generator and what it generates included): profiles/traffic.json
+    is stamped with it, so a PMC measurement of other kernels than the ones in this tree is recognised as stale (the GPU box
+    has no .git to ask)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("pydca_amd/csrc/plm_engine.hip", "pydca_amd/csrc/logits_gather_asm.inc", "pydca_amd/csrc/scatter_gather_asm.inc",
+                "tools/gen_plm_asm.py"):
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _time_reference_eval(oplm, Xs, q, lh, lJ, threads):
     """Seconds of ONE objective + gradient evaluation of the reference's own C++ (oracle/_ref; kind "reference") or,
     when that build is absent, of the C restatement (kind "port") on the sequences Xs with `threads` OpenMP threads."""
@@ -92,7 +105,12 @@ def cpu_baseline(X, q, lh, lJ, evals_per_iter, sample_rows):
     m2 = max(2, min(N, sample_rows // 16))
     m1 = max(1, m2 // 2)
     full1, a1, b1, ts1, _ = _fit_full_eval(oplm, X, q, lh, lJ, 1, (m1, m2))
+    # two samples of a noisy host do not pin a line: besides the fit, the proportional scaling of each sample alone
+    # brackets the figure (the fit's intercept moved the extrapolation 42.6 -> 55.2 s between two runs of round 3)
+    prop = sorted((ts[0] * N / float(n1), ts[1] * N / float(n2), full))
     out = {"value": 1.0 / (full * evals_per_iter), "unit": "L-BFGS iterations/s", "cores": threads, "kind": kind,
+           "value_range": [1.0 / (prop[-1] * evals_per_iter), 1.0 / (prop[0] * evals_per_iter)],
+           "seconds_per_evaluation_range": [prop[0], prop[-1]],
            "sample": "one objective+gradient evaluation of the reference C++/OpenMP on the first %d and %d of %d sequences (L=%d, q=%d): "
                      "%.2f s and %.2f s on %d threads; fitted t = %.2f s + %.3f ms x N -> %.1f s at N, divided by the %.2f "
                      "evaluations/iteration of the GPU run" % (n1, n2, N, L, q, ts[0], ts[1], threads, a, b * 1e3, full, evals_per_iter),
@@ -178,6 +196,48 @@ def rna_workload_block(device, steps=10, warmup=3):
     return out
 
 
+def precision_modes(_lib, X, q, lh, lJ, device, workload, f32_value, f32_ms, steps=10, warmup=2):
+    """The float64 mode (PlmDCA(..., precision=64): float64 kernels, vectors and double-double reductions) timed like the
+    headline -- `warmup` untimed and `steps` timed L-BFGS iterations on the resident alignment -- next to the float32
+    headline, each with the parity class measured for it at this configuration (profiles/p3_config_<id>_cap100.json)."""
+    ctx = _lib.Context(device, _lib.DCA_F64)
+    ctx.set_msa(X, q)
+    ctx.compute_weights(0.8, _lib.DCA_F64)
+    ctx.plm_configure(lh, lJ, _lib.CARRY_CHUNKED)
+    ctx.plm_init_x()
+    ctx.plm_lbfgs_begin(steps + warmup + 1000)
+    st = ctx.plm_lbfgs_iterate(warmup)
+    it0 = st.iterations
+    t0 = time.perf_counter()
+    st = ctx.plm_lbfgs_iterate(steps)
+    dt = time.perf_counter() - t0
+    done = st.iterations - it0
+    ctx.close()
+    modes = {"f32": {"iterations_per_s": f32_value, "ms_per_step": f32_ms, "parity_class": "P4",
+                     "what": "float32 storage and arithmetic as in the reference (lbfgs.h:50-62), double reductions; the bench headline"},
+             "f64": {"iterations_per_s": done / dt, "ms_per_step": dt / max(done, 1) * 1e3, "steps": done, "warmup": warmup, "parity_class": "P3",
+                     "what": "float64 kernels and vectors, double-double reductions: PlmDCA(..., precision=64), `plmdca ... --precision 64`"}}
+    rpath = os.path.join(ROOT, "profiles", "p3_config_%s_cap100.json" % workload)
+    if os.path.exists(rpath):
+        try:
+            r = json.load(open(rpath))
+            modes["parity_report"] = os.path.relpath(rpath, ROOT)
+            modes["f64"]["vs_float64_oracle_at_cap_100"] = {k: r.get(k) for k in (
+                "gpu", "oracle", "first_divergence", "max_rel_fn", "max_rel_fn_apc_vs_fn", "max_rel_fn_apc_topL_self", "topL_same_fn", "topL_same_fn_apc")}
+            modes["f64"]["meets_north_star_tolerance"] = bool(
+                r.get("first_divergence") is None and r.get("max_rel_fn", 1) <= 1e-4 and r.get("max_rel_fn_apc_vs_fn", 1) <= 1e-4
+                and r.get("topL_same_fn") and r.get("topL_same_fn_apc"))
+            f = r.get("float32", {})
+            modes["f32"]["vs_float64_oracle_at_cap_100"] = {k: f.get(k) for k in (
+                "status", "max_rel_fn", "max_rel_fn_apc_vs_fn", "max_rel_fn_apc_topL_self", "topL_same_fn_apc", "topL_overlap_fn_apc")}
+            modes["f32"]["meets_north_star_tolerance"] = bool(f.get("max_rel_fn", 1) <= 1e-4 and f.get("topL_same_fn_apc"))
+        except Exception as exc:   # pragma: no cover
+            modes["parity_report_error"] = repr(exc)
+    else:
+        modes["parity_report"] = None
+    return modes
+
+
 def end_to_end(X, L, q, lh, lJ, device):
     """SURVEY 8 d2's end-to-end figures, outside the headline's timed region: what `plmdca compute_fn <bio> <file> --apc`
     (plmdca_main.py:136-256; max_iterations = the reference's default 100) and `mfdca compute_fn <bio> <file> --apc` do, from
@@ -234,14 +294,32 @@ def main():
     ap.add_argument("--no-mfdca", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-rna", action="store_true")
+    ap.add_argument("--no-modes", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
     args = ap.parse_args()
+
+    selftest = os.environ.get("DCA_BENCH_SELFTEST") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run,
+        # the launcher the driver uses), instead of silently measuring one GPU
+        import socket
+        import subprocess
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus and not selftest:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (torch.cuda.device_count())" % (args.gpus, have))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
 
     import torch
     from pydca_amd import _lib, parallel
@@ -251,9 +329,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     # self-test of the multi-process path on a box with ONE GPU: DCA_BENCH_SELFTEST=1 puts every rank on
     # device 0 and uses gloo (RCCL refuses two ranks on one device); numbers from it are meaningless
-    selftest = os.environ.get("DCA_BENCH_SELFTEST") == "1"
     if selftest:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -373,7 +452,7 @@ def main():
                 chosen = 2 if not timings else min(timings, key=lambda m: timings[m] + (0.0 if m != 1 else 1.3 * (ctx.num_params() / 55e6) * (1.0 - 1.0 / world)))
             ctx.plm_set_native_comm(chosen)
             allreduce = chosen == 1
-            comm_selection = {"evaluation_plus_exchange_ms": timings, "chosen_mode": chosen, "rccl_ranks": world,
+            comm_selection = {"evaluation_plus_exchange_ms": timings, "chosen_mode": chosen, "rccl_ranks": ctx.comm_info()[0],
                               "modes": {"1": "all-reduce(g)", "2": "RCCL reduce-scatter(g) + all-gather(x), sharded vectors",
                                         "3": "direct exchange (grouped send / recv + rank-ordered local sum), sharded vectors"}}
         elif allreduce:
@@ -435,19 +514,28 @@ def main():
     ms, launches = ktimes[dom]
     avg_s = ms / max(launches, 1) / 1e3
     # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/profile_round.sh):
-    # measured in a separate profiling run, NOT in this run -- reported with the commit it was measured at
-    traffic, traffic_commit = None, None
+    # measured in a separate profiling run, NOT in this run -- reported with a fingerprint of the kernel sources it was
+    # measured on, and flagged stale when the sources in this tree differ
+    traffic, traffic_commit, traffic_stale = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(args.workload, {}).get(dom)
             traffic_commit = tj.get("measured_at_commit")
+            traffic_stale = tj.get("kernel_sources_sha256") != kernel_sources_fingerprint()
         except Exception:
             traffic = None
-    roofline = {"kernel": dom, "bound": "hbm", "achieved": alg_bytes[dom] / avg_s / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": alg_bytes[dom] / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_measured_at_commit": traffic_commit,
+    adds = n_local * L * Lq                       # indexed adds per launch: one per (sequence, site, column)
+    valu_peak = 78.6 if args.precision == 32 else 39.3     # 157.3 TFLOP/s fp32 vector = 78.6e12 FMA slots/s; fp64 half of that
+    hbm_view = {"bound": "hbm", "achieved": alg_bytes[dom] / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes[dom] / avg_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes[dom]}
+    # The dominant kernel is a register gather: its binding roof is the issue rate of the indexed packed adds (DESIGN.md
+    # section 4), so THAT is the top-level object; the HBM view the contract names is the sub-object `hbm` (same launch,
+    # same duration), `traffic` the measured fabric bytes per launch.
+    roofline = {"kernel": dom, "bound": "valu", "achieved": adds / avg_s / 1e12, "peak": valu_peak, "unit": "Tadd/s",
+                "frac": adds / avg_s / 1e12 / valu_peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, separate rocprofv3 run)",
+                "traffic_measured_at_commit": traffic_commit, "traffic_is_stale": traffic_stale,
                 "avg_kernel_ms": ms / max(launches, 1), "launches": launches,
                 # one "launch" here = the stage of one evaluation, bracketed by HIP events on the library's stream; the scatter
                 # stage is plm_scatter_kernel (main) + plm_scatter_kernel (left-over column strips, when the strip count is
@@ -455,14 +543,18 @@ def main():
                 "stage_kernels": {"plm_logits": ["plm_logits_kernel"],
                                   "plm_scatter": ["plm_scatter_kernel (main)", "plm_scatter_kernel (left-over strips)",
                                                   "plm_sum_slabs_cols_kernel"]}[dom],
-                "note": "gather kernels: bound on chip (VALU/SALU issue of the indexed adds, LDS reads), not by HBM (DESIGN.md section 4); see valu / onchip",
+                "note": "gather kernel: bound on chip by the issue of the indexed packed adds (1 SALU + 1 VALU per 512-byte row piece), not by HBM; "
+                        "peak = fp%d vector peak counted in adds" % (32 if args.precision == 32 else 64),
+                "hbm": hbm_view,
                 "onchip": {"bound": "lds", "achieved": lds_bytes[dom] / avg_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                           "frac": lds_bytes[dom] / avg_s / 1e9 / LDS_PEAK_GBS},
-                # the adds themselves: N*L*Lq fp32 (fp64) adds per launch against the vector peak counted in
-                # adds (157.3 TFLOP/s fp32 = 78.6e12 FMA slots/s; fp64 half of that)
-                "valu": {"bound": "valu", "achieved": n_local * L * Lq / avg_s / 1e12,
-                         "peak": 78.6 if args.precision == 32 else 39.3, "unit": "Tadd/s",
-                         "frac": n_local * L * Lq / avg_s / 1e12 / (78.6 if args.precision == 32 else 39.3)}}
+                           "frac": lds_bytes[dom] / avg_s / 1e9 / LDS_PEAK_GBS}}
+    # both gather kernels, each against the same roof
+    roofline["per_kernel"] = {}
+    for k in alg_bytes:
+        k_s = ktimes[k][0] / max(ktimes[k][1], 1) / 1e3
+        if k_s > 0:
+            roofline["per_kernel"][k] = {"avg_ms": k_s * 1e3, "valu_frac": adds / k_s / 1e12 / valu_peak,
+                                         "hbm_frac": alg_bytes[k] / k_s / 1e9 / HBM_PEAK_GBS}
     kernels_ms = {k: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in ktimes.items()}
 
     out = {
@@ -474,7 +566,7 @@ def main():
                                "reference carry-over semantics (chunked scan)" % (L, N, q, lh, lJ),
                    "config_id": args.workload, "num_params": P, "parallelism": scheme},
         "evaluations_per_iteration": evals / max(steps_done, 1), "evaluations_per_s": evals / dt,
-        "lbfgs_status": st.status, "fx": st.fx,
+        "lbfgs_state": ("running" if not st.finished else "finished with libLBFGS status %d" % st.status), "fx": st.fx,
         "setup_s": {"generate_msa": t_gen, "weights_kernel": t_weights_ms / 1e3, "total_setup": t_setup},
         "kernels": kernels_ms, "roofline": roofline,
         "host_cores": os.cpu_count(),
@@ -487,7 +579,7 @@ def main():
         # FN_APC scores ranked on host (weights + counts + C + inverse + scoring + sort)
         # one untimed pass first (like the warm-up iterations of the plmDCA leg: first-use code
         # loading and allocator growth are not part of the metric), then three timed passes, each on a
-        # fresh context; the fastest is reported and all three are listed (a shared box shows
+        # fresh context; the MEDIAN is reported and all three are listed (a shared box shows
         # occasional 2-3x outliers in host-side allocation time)
         samples = []
         mctx = None
@@ -503,9 +595,10 @@ def main():
             order = mctx.scores_order()          # ranked on the device (stable radix sort)
             if rep:
                 samples.append(time.perf_counter() - t0)
-        t_mf = min(samples)
+        t_mf = float(np.median(samples))
         npairs = L * (L - 1) // 2
-        out["mfdca"] = {"pairs_per_s": npairs / t_mf, "seconds": t_mf, "samples_s": samples, "pairs": npairs, "top_pair_index": int(order[0]),
+        out["mfdca"] = {"pairs_per_s": npairs / t_mf, "seconds": t_mf, "statistic": "median of the timed passes", "samples_s": samples,
+                        "fastest_pairs_per_s": npairs / min(samples), "pairs": npairs, "top_pair_index": int(order[0]),
                         "stages_ms": {k: mctx.kernel_time(k)[0] for k in ("weights", "mf_sort", "mf_counts", "mf_inverse", "scores")},
                         "inverse_flops": float((L * (q - 1)) ** 3),
                         "inverse_tflops": float((L * (q - 1)) ** 3) / max(mctx.kernel_time("mf_inverse")[0], 1e-9) / 1e9}
@@ -516,6 +609,17 @@ def main():
                               "frac": inv_tf / 78.6, "flop_convention": "n^3", "n": L * (q - 1),
                               "avg_kernel_ms": mctx.kernel_time("mf_inverse")[0] / max(mctx.kernel_time("mf_inverse")[1], 1)}
         mctx.close()
+
+    if world == 1 and args.precision == 32 and not args.no_modes:
+        # The two precisions of the product side by side, each with its MEASURED parity class.  north_star's tolerance
+        # ("FN / DI within 1e-4 of the float64 CPU path, identical top-L") is protocol P3 of SURVEY 8c4; the float32 mode is the
+        # reference's own arithmetic (lbfgs.h:50-62) and lands in the P4 regime after 100 iterations of an optimisation
+        # that does not converge.  The figures come from the committed report of tests/test_gpu_configs.py::
+        # test_P3_full_size_at_reference_cap against the float64 oracle's golden run at this configuration.
+        try:
+            out["modes"] = precision_modes(_lib, X, q, lh, lJ, local_rank, args.workload, out["value"], out["ms_per_step"])
+        except Exception as exc:   # pragma: no cover
+            out["modes"] = {"error": repr(exc)}
 
     if world == 1 and not args.no_e2e:
         try:
@@ -537,6 +641,11 @@ def main():
         except Exception as exc:   # pragma: no cover
             out["cpu_baseline"] = {"error": repr(exc)}
 
+    # what was asked for is what ran: N ranks, and (native exchange) ONE communicator of N ranks
+    if out["n_gpus"] != args.gpus:
+        raise SystemExit("bench.py: measured %d rank(s) for --gpus %d" % (out["n_gpus"], args.gpus))
+    if comm_selection is not None and comm_selection["rccl_ranks"] != world:
+        raise SystemExit("bench.py: the RCCL communicator has %d ranks, expected %d" % (comm_selection["rccl_ranks"], world))
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -145,6 +145,10 @@ int dca_plm_get_g(dca_ctx* ctx, void* g_out, int dtype);
 int dca_comm_unique_id(const char* rccl_path, void* id128);
 int dca_comm_init(dca_ctx* ctx, const char* rccl_path, const void* id128, int world, int rank);
 int dca_comm_destroy(dca_ctx* ctx);
+/* world size and rank as the communicator itself reports them (ncclCommCount / ncclCommUserRank): a launcher asserts with
+ * it that its N processes form ONE communicator of N ranks.  dca_comm_init / dca_comm_destroy answer DCA_ERR_STATE, and
+ * change nothing, while an optimisation whose vectors are cut for the current communicator is in progress. */
+int dca_comm_info(dca_ctx* ctx, int* world, int* rank);
 
 /* Exchange step of the sharded plmDCA evaluation through the context's communicator (after dca_plm_configure):
  *   mode 1: all-reduce(sum) of the gradient and of fx after every evaluation, optimiser vectors replicated;

@@ -51,7 +51,8 @@ def _load():
         f = getattr(lib, "oracle_lbfgs" + sfx)
         f.restype = C.c_int
         f.argtypes = [_u8p, rp, C.c_int, C.c_int, C.c_int, ct, ct, C.c_int, C.c_int, C.c_int,
-                      rp, C.POINTER(ct), C.POINTER(C.c_int * 3), C.c_void_p, C.c_int]
+                      rp, C.POINTER(ct), C.POINTER(C.c_int * 3), C.c_void_p, C.c_int,
+                      C.c_void_p, C.c_int, C.c_void_p]
     return lib
 
 
@@ -125,8 +126,8 @@ def gradient(X, w, q, lambda_h, lambda_J, x, carry=True, threads=0):
     return float(fx), g
 
 
-def lbfgs(X, w, q, lambda_h, lambda_J, max_iterations, x0, carry=True, threads=0, trace_cap=0):
-    """-> dict(x, fx, status, iterations, evaluations, trace)."""
+def lbfgs(X, w, q, lambda_h, lambda_J, max_iterations, x0, carry=True, threads=0, trace_cap=0, snapshots=()):
+    """-> dict(x, fx, status, iterations, evaluations, trace[, snapshots = {iteration: x after it}])."""
     X = np.ascontiguousarray(X, dtype=np.uint8)
     sfx, ct = _sfx(x0.dtype)
     N, L = X.shape
@@ -134,12 +135,19 @@ def lbfgs(X, w, q, lambda_h, lambda_J, max_iterations, x0, carry=True, threads=0
     fx = ct(0)
     stats = (C.c_int * 3)()
     trace = np.zeros((max(trace_cap, 1), 4), dtype=x0.dtype)
+    snap_it = np.ascontiguousarray(sorted(int(k) for k in snapshots), dtype=np.int32)
+    snap_x = np.zeros((len(snap_it), x.shape[0]), dtype=x0.dtype) if len(snap_it) else None
     getattr(lib(), "oracle_lbfgs" + sfx)(
         X, np.ascontiguousarray(w, dtype=x0.dtype), N, L, q, ct(lambda_h), ct(lambda_J),
         int(max_iterations), int(bool(carry)), threads or os.cpu_count(), x, C.byref(fx),
-        C.byref(stats), trace.ctypes.data_as(C.c_void_p) if trace_cap else None, trace_cap)
-    return dict(x=x, fx=float(fx.value), status=stats[0], iterations=stats[1],
-                evaluations=stats[2], trace=trace[:min(trace_cap, stats[1])])
+        C.byref(stats), trace.ctypes.data_as(C.c_void_p) if trace_cap else None, trace_cap,
+        snap_it.ctypes.data_as(C.c_void_p) if len(snap_it) else None, len(snap_it),
+        snap_x.ctypes.data_as(C.c_void_p) if len(snap_it) else None)
+    out = dict(x=x, fx=float(fx.value), status=stats[0], iterations=stats[1],
+               evaluations=stats[2], trace=trace[:min(trace_cap, stats[1])])
+    if len(snap_it):
+        out["snapshots"] = {int(k): snap_x[i] for i, k in enumerate(snap_it) if k <= stats[1]}
+    return out
 
 
 # ----------------------------------------------------------------------------

@@ -152,7 +152,10 @@ int oracle_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int 
  * is this repository's deterministic parity target.  With plain sums the objective of two float64
  * implementations differs by ~1e-13 (N*L terms in two orders); the line search interpolates on DIFFERENCES of objective
  * values, and over 100 iterations of an optimisation that does not converge that rounding noise grows to 6e-4 in the
- * scores at config E (profiles/r03_e_sensitivity_cap100_plain_sums.json).  A compensated sum does not depend on the order. */
+ * scores at config E (profiles/r03_e_sensitivity_cap100_plain_sums.json).  A compensated sum does not depend on the order.
+ * Round 4: the same holds for the optimiser's dot products (g.d, y.s, y.y, x.x, g.g and the two-loop recursion's s.d, y.d;
+ * P = 5.5e7 products at config D, ~7e-13 of order-dependent rounding in a plain sequential sum), so vdot is compensated
+ * too in this instantiation; the device sums the same rounded products in double-double. */
 #define ORACLE_COMPENSATED_FX 1
 #define REAL double
 #define FN(name) CAT(name, _f64)

@@ -209,14 +209,15 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
  * Restates what the reference backend runs: lbfgs/lib/lbfgs.cpp:248-644 (driver),
  * :815-1004 (line search), :1128-1295 (trial interval update), with the
  * parameters set in plmdcaBackend.cpp:68-75 and the defaults of lbfgs.cpp:116-121.
- * Vector reductions are sequential sums in REAL (arithmetic_ansi.h:114-121).
+ * Vector reductions are sequential sums in REAL (arithmetic_ansi.h:114-121); the float64 instantiation compensates
+ * them (Neumaier, like the objective: see plm_oracle.c), so that they do not depend on the order of summation.
  * ====================================================================== */
 
 static REAL FN(vdot)(const REAL* a, const REAL* b, size_t n)
 {
-    REAL s = 0;
-    for (size_t i = 0; i < n; ++i) s += a[i] * b[i];
-    return s;
+    REAL s = 0, c = 0;      /* c: compensation term (stays 0 in the reference-order float instantiation) */
+    for (size_t i = 0; i < n; ++i) FX_ADD(s, c, a[i] * b[i]);     /* the product is rounded first (-ffp-contract=off) */
+    return s + c;
 }
 
 /* minimiser of the cubic through (u,fu,du),(v,fv,dv): lbfgs.cpp:1024-1038 */
@@ -418,10 +419,12 @@ static REAL FN(plm_eval)(void* c, const REAL* x, REAL* g, size_t n)
 
 /* driver, lbfgs.cpp:248-644 with m=5, epsilon=1e-3 (plmdcaBackend.cpp:68-75).
  * x is in/out.  stats[0]=status, [1]=iterations completed, [2]=evaluations.
- * trace (optional, 4 REALs per iteration: fx,xnorm,gnorm,step) up to trace_cap iterations. */
+ * trace (optional, 4 REALs per iteration: fx,xnorm,gnorm,step) up to trace_cap iterations.
+ * snap_iters / snap_x (optional): x after iteration snap_iters[s] is copied to snap_x + s*P (checkpoints of one long run). */
 int FN(oracle_lbfgs)(const uint8_t* X, const REAL* w, int N, int L, int q,
                      REAL lambda_h, REAL lambda_J, int max_iterations, int carry, int threads,
-                     REAL* x, REAL* fx_out, int* stats, REAL* trace, int trace_cap)
+                     REAL* x, REAL* fx_out, int* stats, REAL* trace, int trace_cap,
+                     const int* snap_iters, int nsnap, REAL* snap_x)
 {
     enum { M = PLM_LBFGS_M };
     const size_t n = plm_num_params(L, q);
@@ -462,6 +465,12 @@ int FN(oracle_lbfgs)(const uint8_t* X, const REAL* w, int N, int L, int q,
         if (trace && k <= trace_cap) {
             REAL* t = trace + (size_t)(k - 1) * 4;
             t[0] = fx; t[1] = xnorm; t[2] = gnorm; t[3] = step;
+        }
+        for (int sidx = 0; sidx < nsnap; ++sidx)
+            if (snap_iters[sidx] == k) memcpy(snap_x + (size_t)sidx * n, x, n * sizeof(REAL));
+        if (getenv("ORACLE_PROGRESS_FILE")) {      /* long runs (config D: half a minute per evaluation): one line per iteration */
+            FILE* pf = fopen(getenv("ORACLE_PROGRESS_FILE"), "a");
+            if (pf) { fprintf(pf, "%d %.17g %.17g %.17g %.17g %d\n", k, (double)fx, (double)xnorm, (double)gnorm, (double)step, nevals); fclose(pf); }
         }
         if (xnorm < 1.0) xnorm = 1.0;
         if (gnorm / xnorm <= eps) { ret = PLM_LBFGS_SUCCESS; break; }

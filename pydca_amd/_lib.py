@@ -79,6 +79,7 @@ def lib():
         "dca_comm_unique_id": (i, [C.c_char_p, vp]),
         "dca_comm_init": (i, [vp, C.c_char_p, vp, i, i]),
         "dca_comm_destroy": (i, [vp]),
+        "dca_comm_info": (i, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "dca_plm_set_native_comm": (i, [vp, i]),
         "dca_mf_set_native_comm": (i, [vp, i]),
         "dca_set_weights": (i, [vp, vp]),
@@ -133,7 +134,7 @@ def lib():
 
 
 EXPORTS = ["dca_compute_weights_sharded", "dca_weights_partial_counts", "dca_set_weight_counts", "dca_comm_unique_id",
-           "dca_comm_init", "dca_comm_destroy", "dca_plm_set_native_comm", "dca_mf_set_native_comm",
+           "dca_comm_init", "dca_comm_destroy", "dca_comm_info", "dca_plm_set_native_comm", "dca_mf_set_native_comm",
            "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_fasta_shape", "dca_read_fasta", "dca_read_fasta_alloc", "dca_host_free", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_num_params", "dca_plm_init_x",
@@ -276,6 +277,12 @@ class Context:
 
     def comm_destroy(self):
         check(self._l.dca_comm_destroy(self._h))
+
+    def comm_info(self):
+        """(world, rank) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        w, r = C.c_int(0), C.c_int(0)
+        check(self._l.dca_comm_info(self._h, C.byref(w), C.byref(r)))
+        return w.value, r.value
 
     def plm_set_native_comm(self, mode):
         """0 off, 1 all-reduce of g and fx per evaluation, 2 sharded optimiser vectors (RCCL reduce-scatter / all-gather),

@@ -496,8 +496,10 @@ int dca_comm_init(dca_ctx* ctx, const char* rccl_path, const void* id128, int wo
     CHECK_CTX(ctx);
     if (!id128) return DCA_ERR_ARG;
     // slices and reductions configured for the previous communicator's world / rank do not carry over
+    // (an engine in the middle of an optimisation refuses: its vector slices are cut for the old world, so the
+    // communicator must not change under it -- DCA_ERR_STATE, nothing touched)
     if (ctx->comm) {
-        if (ctx->plm) ctx->plm->set_native_comm(0);
+        if (ctx->plm && ctx->plm->configured_for_comm()) DCA_TRY(ctx->plm->set_native_comm(0));
         if (ctx->mf) dca_mf_engine_set_native(ctx->mf, false);
     }
     return dca_comm_init_impl(ctx, rccl_path, id128, world, rank);
@@ -505,10 +507,15 @@ int dca_comm_init(dca_ctx* ctx, const char* rccl_path, const void* id128, int wo
 int dca_comm_destroy(dca_ctx* ctx)
 {
     CHECK_CTX(ctx);
-    if (ctx->plm) ctx->plm->set_native_comm(0);
+    if (ctx->comm && ctx->plm && ctx->plm->configured_for_comm()) DCA_TRY(ctx->plm->set_native_comm(0));
     if (ctx->mf) dca_mf_engine_set_native(ctx->mf, false);
     dca_comm_destroy_impl(ctx);
     return DCA_OK;
+}
+int dca_comm_info(dca_ctx* ctx, int* world, int* rank)
+{
+    CHECK_CTX(ctx);
+    return dca_comm_info_impl(ctx, world, rank);
 }
 int dca_plm_set_native_comm(dca_ctx* ctx, int mode)
 {

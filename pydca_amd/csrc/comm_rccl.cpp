@@ -31,6 +31,8 @@ struct RcclApi {
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*CommCount)(RcclComm, int*) = nullptr;         // optional: what the communicator itself reports (dca_comm_info)
+    int (*CommUserRank)(RcclComm, int*) = nullptr;
 };
 RcclApi g_api;
 
@@ -78,6 +80,8 @@ int load_api(const char* path)
               bind(h, api.AllGather, "ncclAllGather") && bind(h, api.GroupStart, "ncclGroupStart") && bind(h, api.GroupEnd, "ncclGroupEnd") &&
               bind(h, api.Send, "ncclSend") && bind(h, api.Recv, "ncclRecv");
     if (!ok) { dlclose(h); return DCA_ERR_IO; }
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(h, "ncclCommCount"));
+    api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
     api.handle = h;
     g_api = api;
     return DCA_OK;
@@ -115,6 +119,20 @@ int dca_comm_init_impl(dca_ctx* ctx, const char* rccl_path, const void* id128, i
     ctx->comm = comm;
     ctx->comm_rank = rank;
     ctx->comm_world = world;
+    return DCA_OK;
+}
+
+// world size and rank as the communicator reports them (ncclCommCount / ncclCommUserRank), so that a caller can assert
+// that the N processes it started really form ONE communicator of N ranks; the values handed to dca_comm_init where the
+// library does not export the queries
+int dca_comm_info_impl(dca_ctx* ctx, int* world, int* rank)
+{
+    if (!ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
+    int w = ctx->comm_world, r = ctx->comm_rank;
+    if (g_api.CommCount) RCCL_TRY(g_api.CommCount(static_cast<RcclComm>(ctx->comm), &w));
+    if (g_api.CommUserRank) RCCL_TRY(g_api.CommUserRank(static_cast<RcclComm>(ctx->comm), &r));
+    if (world) *world = w;
+    if (rank) *rank = r;
     return DCA_OK;
 }
 

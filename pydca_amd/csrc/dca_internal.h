@@ -128,6 +128,7 @@ int dca_weights_finish(dca_ctx* ctx);     // w = 1 / count, Meff from ctx->dCoun
 int dca_comm_unique_id_impl(const char* rccl_path, void* id128);
 int dca_comm_init_impl(dca_ctx* ctx, const char* rccl_path, const void* id128, int world, int rank);
 void dca_comm_destroy_impl(dca_ctx* ctx);
+int dca_comm_info_impl(dca_ctx* ctx, int* world, int* rank);
 int dca_comm_native(dca_ctx* ctx, int op, void* buf, size_t count, int dtype, bool direct = false);   // direct: grouped send / recv + local sum
 int dca_comm_native_reduce(dca_ctx* ctx, void* vec, size_t count, int dtype, double* scalar_dev);
 int dca_comm_native_sum_u32(dca_ctx* ctx, uint32_t* buf, size_t count);
@@ -157,6 +158,7 @@ struct PlmEngineBase {
     void* hook_user = nullptr;
     virtual void weights_changed() = 0;            // dca_compute_weights* / dca_set_weights ran: configure again, exchange scheme kept
     virtual int set_native_comm(int mode) = 0;     // 0 off, 1 all-reduce of g and fx, 2 sharded optimiser vectors, 3 the same by direct exchange
+    virtual bool configured_for_comm() const = 0;  // configured: its slices follow a communicator (an unconfigured engine re-cuts them in configure)
     int native_mode = 0;                           // ... through ctx->comm (RCCL) on the context's stream
 };
 PlmEngineBase* dca_make_plm_engine(dca_ctx* ctx);

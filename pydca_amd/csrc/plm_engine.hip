@@ -274,6 +274,20 @@ __device__ __forceinline__ void dd_wave_reduce(double& hi, double& lo)       // 
     }
 }
 
+__device__ __forceinline__ void dd_block_reduce(double& hi, double& lo, double* redHi, double* redLo)      // result in thread 0
+{
+    redHi[threadIdx.x] = hi;
+    redLo[threadIdx.x] = lo;
+    __syncthreads();
+    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) dd_add2(redHi[threadIdx.x], redLo[threadIdx.x], redHi[threadIdx.x + st], redLo[threadIdx.x + st]);
+        __syncthreads();
+    }
+    hi = redHi[0];
+    lo = redLo[0];
+    __syncthreads();
+}
+
 template <typename T, int Q>
 __global__ __launch_bounds__(256)
 void plm_softmax_kernel(const T* __restrict__ SR, T* __restrict__ Rout, const T* __restrict__ x, const uint8_t* __restrict__ X,
@@ -733,34 +747,73 @@ __device__ __forceinline__ void block_reduce_store(double v, double* red, double
     __syncthreads();
 }
 
-// partials[k*gridDim.x + block] for k = 0..2 : a.b, c.c, a.a   (g.d, x.x, g.g)
-template <typename T>
-__global__ void vec_dot3_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, size_t n,
-                                double* __restrict__ partials)
+// Dot-product accumulators of the optimiser.  float32 vectors: products and sums in double (already far more exact than the
+// reference's float sums).  float64 vectors (the parity mode): the ROUNDED products are summed in double-double, like the
+// objective -- a plain double sum of P = 5.5e7 products carries ~1e-13 of order-dependent rounding, g.d / y.s / y.y and the
+// Gram entries steer the line search and scale the direction, and the optimisation amplifies such noise from iteration to
+// iteration.  The float64 oracle compensates the same sums (Neumaier), so both see the sum of the
+// same rounded products to the last bit or two, whatever the order.  Partials travel as (hi, lo) pairs in both cases.
+template <bool DD> struct DotAcc;
+template <> struct DotAcc<false> {
+    double hi = 0.0;
+    static constexpr double lo = 0.0;
+    __device__ __forceinline__ void add(double a, double b) { hi += a * b; }
+    __device__ __forceinline__ void wave_reduce() { for (int off = 32; off > 0; off >>= 1) hi += __shfl_down(hi, off); }
+};
+template <> struct DotAcc<true> {
+    double hi = 0.0, lo = 0.0;
+    __device__ __forceinline__ void add(double a, double b) { dd_add(hi, lo, __dmul_rn(a, b)); }
+    __device__ __forceinline__ void wave_reduce() { dd_wave_reduce(hi, lo); }
+};
+// the workgroup's waves leave their (hi, lo) in red[wave][2 * v], [2 * v + 1]; thread v < nv adds them in wave order
+template <int NV>
+__device__ __forceinline__ void dot_block_store(double (*red)[2 * NV], int nv, double* __restrict__ partials)
 {
-    __shared__ double red[kVecThreads];
-    double s0 = 0, s1 = 0, s2 = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+        double hi = 0.0, lo = 0.0;
+        for (int w = 0; w < (int)blockDim.x / 64; ++w) dd_add2(hi, lo, red[w][2 * threadIdx.x], red[w][2 * threadIdx.x + 1]);
+        const size_t slot = (size_t)threadIdx.x * gridDim.x + blockIdx.x;
+        partials[2 * slot] = hi;
+        partials[2 * slot + 1] = lo;
+    }
+}
+
+// (hi, lo) partials [2 * (k*gridDim.x + block)] for k = 0..2 : a.b, c.c, a.a   (g.d, x.x, g.g)
+template <typename T>
+__global__ __launch_bounds__(kVecThreads)
+void vec_dot3_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, size_t n,
+                     double* __restrict__ partials)
+{
+    __shared__ double red[kVecThreads / 64][6];
+    DotAcc<sizeof(T) == 8> s0, s1, s2;
     DCA_VEC_LOOP(n,
         const Pack<T> pa = ldp(a, iv); const Pack<T> pb = ldp(b, iv); const Pack<T> pc = ldp(c, iv);
         _Pragma("unroll") for (int k = 0; k < VEC; ++k) {
             const double av = pa.v[k]; const double bv = pb.v[k]; const double cv = pc.v[k];
-            s0 += av * bv; s1 += cv * cv; s2 += av * av;
+            s0.add(av, bv); s1.add(cv, cv); s2.add(av, av);
         },
-        { const double av = a[i]; const double bv = b[i]; const double cv = c[i]; s0 += av * bv; s1 += cv * cv; s2 += av * av; })
-    block_reduce_store(s0, red, partials + blockIdx.x);
-    block_reduce_store(s1, red, partials + gridDim.x + blockIdx.x);
-    block_reduce_store(s2, red, partials + 2 * gridDim.x + blockIdx.x);
+        { const double av = a[i]; const double bv = b[i]; const double cv = c[i]; s0.add(av, bv); s1.add(cv, cv); s2.add(av, av); })
+    s0.wave_reduce(); s1.wave_reduce(); s2.wave_reduce();
+    if ((threadIdx.x & 63) == 0) {
+        double* r = red[threadIdx.x >> 6];
+        r[0] = s0.hi; r[1] = s0.lo; r[2] = s1.hi; r[3] = s1.lo; r[4] = s2.hi; r[5] = s2.lo;
+    }
+    dot_block_store<3>(red, 3, partials);
 }
 template <typename T>
-__global__ void vec_dot_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n, double* __restrict__ partials)
+__global__ __launch_bounds__(kVecThreads)
+void vec_dot_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n, double* __restrict__ partials)
 {
-    __shared__ double red[kVecThreads];
-    double s0 = 0;
+    __shared__ double red[kVecThreads / 64][2];
+    DotAcc<sizeof(T) == 8> s0;
     DCA_VEC_LOOP(n,
         const Pack<T> pa = ldp(a, iv); const Pack<T> pb = ldp(b, iv);
-        _Pragma("unroll") for (int k = 0; k < VEC; ++k) s0 += (double)pa.v[k] * (double)pb.v[k];,
-        s0 += (double)a[i] * (double)b[i];)
-    block_reduce_store(s0, red, partials + blockIdx.x);
+        _Pragma("unroll") for (int k = 0; k < VEC; ++k) s0.add((double)pa.v[k], (double)pb.v[k]);,
+        s0.add((double)a[i], (double)b[i]);)
+    s0.wave_reduce();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s0.hi; red[threadIdx.x >> 6][1] = s0.lo; }
+    dot_block_store<1>(red, 1, partials);
 }
 // L-BFGS direction in one pass instead of 2m dependent dot/axpy rounds: every vector of the
 // two-loop recursion (lbfgs.cpp:568-601) lies in span{g, s_k, y_k}, so the recursion can be run
@@ -831,16 +884,14 @@ __global__ __launch_bounds__(kVecThreads)
 void vec_diff_gram_kernel(VecPtrs5 P, T* __restrict__ se, T* __restrict__ ye, const T* __restrict__ x, const T* __restrict__ xp,
                           const T* __restrict__ g, const T* __restrict__ gp, int e, size_t n, double* __restrict__ partials)
 {
-    __shared__ double red[kVecThreads / 64][27];
-    double acc[27];
-#pragma unroll
-    for (int v = 0; v < 27; ++v) acc[v] = 0.0;
+    __shared__ double red[kVecThreads / 64][54];
+    DotAcc<sizeof(T) == 8> acc[27];
     DCA_VEC_LOOP(n,
         const Pack<T> px = ldp(x, iv); const Pack<T> pxp = ldp(xp, iv); const Pack<T> pg = ldp(g, iv); const Pack<T> pgp = ldp(gp, iv);
         Pack<T> pse; Pack<T> pye;
         _Pragma("unroll") for (int u = 0; u < VEC; ++u) {
             pse.v[u] = px.v[u] - pxp.v[u]; pye.v[u] = pg.v[u] - pgp.v[u];
-            acc[0] += (double)pye.v[u] * (double)pse.v[u]; acc[1] += (double)pye.v[u] * (double)pye.v[u];
+            acc[0].add((double)pye.v[u], (double)pse.v[u]); acc[1].add((double)pye.v[u], (double)pye.v[u]);
         }
         stp(se, iv, pse); stp(ye, iv, pye);
         _Pragma("unroll") for (int k = 0; k < 5; ++k) {
@@ -849,29 +900,23 @@ void vec_diff_gram_kernel(VecPtrs5 P, T* __restrict__ se, T* __restrict__ ye, co
             _Pragma("unroll") for (int u = 0; u < VEC; ++u) {
                 const double gv = pg.v[u]; const double sev = pse.v[u]; const double yev = pye.v[u];
                 const double sk = psk.v[u]; const double yk = pyk.v[u];
-                acc[2 + k] += sk * gv; acc[7 + k] += yk * gv; acc[12 + k] += sev * yk; acc[17 + k] += yev * sk; acc[22 + k] += yev * yk;
+                acc[2 + k].add(sk, gv); acc[7 + k].add(yk, gv); acc[12 + k].add(sev, yk); acc[17 + k].add(yev, sk); acc[22 + k].add(yev, yk);
             }
         },
         { const T sev_ = x[i] - xp[i]; const T yev_ = g[i] - gp[i]; se[i] = sev_; ye[i] = yev_;
           const double gv = g[i]; const double sev = sev_; const double yev = yev_;
-          acc[0] += yev * sev; acc[1] += yev * yev;
+          acc[0].add(yev, sev); acc[1].add(yev, yev);
           _Pragma("unroll") for (int k = 0; k < 5; ++k) {
               const double sk = k == e ? sev : (double)static_cast<const T*>(P.s[k])[i]; const double yk = k == e ? yev : (double)static_cast<const T*>(P.y[k])[i];
-              acc[2 + k] += sk * gv; acc[7 + k] += yk * gv; acc[12 + k] += sev * yk; acc[17 + k] += yev * sk; acc[22 + k] += yev * yk;
+              acc[2 + k].add(sk, gv); acc[7 + k].add(yk, gv); acc[12 + k].add(sev, yk); acc[17 + k].add(yev, sk); acc[22 + k].add(yev, yk);
           } })
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int v = 0; v < 27; ++v) {
-        double a = acc[v];
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
-        if (lane == 0) red[wv][v] = a;
+        acc[v].wave_reduce();
+        if (lane == 0) { red[wv][2 * v] = acc[v].hi; red[wv][2 * v + 1] = acc[v].lo; }
     }
-    __syncthreads();
-    if (threadIdx.x < 27) {
-        double a = 0.0;
-        for (int w = 0; w < kVecThreads / 64; ++w) a += red[w][threadIdx.x];
-        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = a;
-    }
+    dot_block_store<27>(red, 27, partials);
 }
 
 // d = c.g * g + sum_k c.s[k] * s_k + c.y[k] * y_k
@@ -896,14 +941,16 @@ __global__ void vec_compose_kernel(T* __restrict__ d, const T* __restrict__ g, V
           d[i] = (T)v; })
 }
 
-// out[k] = sum_b partials[k*nb + b], k < nk; one block per k, fixed tree
-__global__ void vec_final_kernel(const double* __restrict__ partials, int nb, int nk, double* __restrict__ out)
+// out[k] = sum_b of the (hi, lo) pairs partials[2 * (k*nb + b)], k < nk, rounded once; one block per k, fixed tree
+__global__ __launch_bounds__(256)
+void vec_final_kernel(const double* __restrict__ partials, int nb, int nk, double* __restrict__ out)
 {
-    __shared__ double red[256];
+    __shared__ double redHi[256], redLo[256];
     const int k = blockIdx.x;
-    double s = 0;
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partials[(size_t)k * nb + b];
-    block_reduce_store(s, red, out + k);
+    double hi = 0.0, lo = 0.0;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) dd_add2(hi, lo, partials[2 * ((size_t)k * nb + b)], partials[2 * ((size_t)k * nb + b) + 1]);
+    dd_block_reduce(hi, lo, redHi, redLo);
+    if (threadIdx.x == 0) out[k] = hi + lo;
 }
 // out[0] = (add ? out[0] : 0) + sum partials[0..n)
 __global__ void sum_partials_kernel(const double* __restrict__ partials, int n, double* __restrict__ out, int add)
@@ -921,19 +968,6 @@ __global__ void sum_partials_kernel(const double* __restrict__ partials, int n, 
 }
 
 // ---- the same for (hi, lo) pairs (the objective's partial sums)
-__device__ __forceinline__ void dd_block_reduce(double& hi, double& lo, double* redHi, double* redLo)      // result in thread 0
-{
-    redHi[threadIdx.x] = hi;
-    redLo[threadIdx.x] = lo;
-    __syncthreads();
-    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) dd_add2(redHi[threadIdx.x], redLo[threadIdx.x], redHi[threadIdx.x + st], redLo[threadIdx.x + st]);
-        __syncthreads();
-    }
-    hi = redHi[0];
-    lo = redLo[0];
-    __syncthreads();
-}
 // block b sums its contiguous chunk of the n pairs into pair b of out
 __global__ __launch_bounds__(256)
 void dd_sum_chunks_kernel(const double* __restrict__ parts, int n, double* __restrict__ out)
@@ -1240,7 +1274,7 @@ struct PlmEngine : PlmEngineBase {
         nRegPart = (int)npairs + ceil_div(Lq, 256);
         DCA_TRY(dalloc(&dFxPart, 2 * (size_t)nFxPart));                       // (hi, lo) pairs
         DCA_TRY(dalloc(&dRegPart, 2 * (size_t)(nRegPart + kSumStageBlocks)));      // pairs; + the first-stage sums of the regulariser partials
-        DCA_TRY(dalloc(&dVecPart, 27 * kVecBlocks));
+        DCA_TRY(dalloc(&dVecPart, 2 * 27 * kVecBlocks));      // (hi, lo) pairs
 
         HIP_TRY(hipMemsetAsync(dx, 0, (P + kVecPad) * sizeof(T), ctx->stream));
         HIP_TRY(hipMemsetAsync(dg, 0, (P + kVecPad) * sizeof(T), ctx->stream));
@@ -1502,6 +1536,7 @@ struct PlmEngine : PlmEngineBase {
         vn = vlo >= P ? 0 : std::min(slice, P - vlo);
         return DCA_OK;
     }
+    bool configured_for_comm() const override { return configured; }
     int set_native_comm(int mode) override
     {
         if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }

@@ -65,6 +65,12 @@ def compute_pair_site_freqs(alignment_data=None, num_site_states=None, seqs_weig
         ctx.close()
 
 
+def compute_pair_site_freqs_serial(alignment_data=None, num_site_states=None, seqs_weight=None):
+    """msa_numerics.py:128-179, the reference's un-parallelised twin of compute_pair_site_freqs (same result, same
+    pair order); here both names reach the same device kernel."""
+    return compute_pair_site_freqs(alignment_data=alignment_data, num_site_states=num_site_states, seqs_weight=seqs_weight)
+
+
 def get_reg_pair_site_freqs(pair_site_freqs=None, seqs_len=None, num_site_states=None, pseudocount=None):
     """msa_numerics.py:231-267 (in place, like the reference)."""
     theta_by_qsqrd = pseudocount / float(num_site_states * num_site_states)
@@ -96,6 +102,16 @@ def compute_couplings(corr_mat=None):
     finally:
         ctx.close()
     return -1.0 * inv
+
+
+def slice_couplings(couplings=None, site_pair=None, num_site_states=None):
+    """msa_numerics.py:346-374 -> float64[q, q]: the (q-1) x (q-1) block of site pair (i, j) of the L(q-1) x L(q-1)
+    couplings matrix, with a zero row and column for the gap state (a host-side slice; nothing to compute)."""
+    q = int(num_site_states)
+    i, j = int(site_pair[0]), int(site_pair[1])
+    block = np.zeros((q, q), dtype=np.float64)
+    block[:q - 1, :q - 1] = np.asarray(couplings)[i * (q - 1):(i + 1) * (q - 1), j * (q - 1):(j + 1) * (q - 1)]
+    return block
 
 
 def compute_two_site_model_fields(couplings=None, reg_fi=None, seqs_len=None, num_site_states=None):

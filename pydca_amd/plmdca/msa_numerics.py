@@ -29,6 +29,17 @@ def _check(couplings, seqs_len, num_site_states):
     return c
 
 
+def slice_couplings(couplings=None, site_pair=None, num_site_states=None, seqs_len=None):
+    """plmdca/msa_numerics.py:128-152 -> float64[q, q]: the (q-1)^2 gap-stripped couplings of pair (i, j), i < j, cut from
+    the 1-D array in pair order, with a zero row and column for the gap state."""
+    L, q = int(seqs_len), int(num_site_states)
+    i, j = int(site_pair[0]), int(site_pair[1])
+    pair = L * (L - 1) // 2 - (L - i) * (L - i - 1) // 2 + j - i - 1
+    block = np.zeros((q, q), dtype=np.float64)
+    block[:q - 1, :q - 1] = np.asarray(couplings).reshape(-1)[pair * (q - 1) ** 2:(pair + 1) * (q - 1) ** 2].reshape(q - 1, q - 1)
+    return block
+
+
 def compute_two_site_model_fields(couplings=None, reg_fi=None, seqs_len=None, num_site_states=None):
     """plmdca/msa_numerics.py:156-246 -> float64[pairs, 2, q]."""
     c = _check(couplings, seqs_len, num_site_states)

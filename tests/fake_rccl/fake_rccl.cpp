@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY -- a stand-in for librccl.so that implements the eleven entry points csrc/comm_rccl.cpp binds
+// TEST INFRASTRUCTURE ONLY -- a stand-in for librccl.so that implements the entry points csrc/comm_rccl.cpp binds
 // (same names, same signatures) between THREADS of one process, so that the product's native exchange path (in-place
 // reduce-scatter / all-gather / all-reduce on the context's stream, sharded weights, mfDCA counts) can be driven with
 // world sizes 2 and 3 on the single GPU a test box has; real RCCL refuses two ranks on one device.
@@ -101,6 +101,8 @@ int ncclCommInitRank(void** comm, int nranks, ncclUniqueId id, int rank)
 }
 
 int ncclCommDestroy(void* comm) { delete static_cast<Comm*>(comm); return 0; }
+int ncclCommCount(void* comm, int* count) { *count = static_cast<Comm*>(comm)->group->nranks; return 0; }
+int ncclCommUserRank(void* comm, int* rank) { *rank = static_cast<Comm*>(comm)->rank; return 0; }
 const char* ncclGetErrorString(int r) { return r == 0 ? "no error" : r == 4 ? "invalid argument" : "fake rccl: hip error"; }
 
 // Point-to-point: only inside ncclGroupStart / ncclGroupEnd, the way the product issues its direct exchange (every rank

@@ -67,6 +67,21 @@ def test_msa_numerics_module_stage_functions():
     np.testing.assert_allclose(mn.compute_couplings(corr_mat=corr), G["couplings"], rtol=1e-8, atol=1e-10)
     with pytest.raises(np.linalg.LinAlgError):
         mn.compute_couplings(corr_mat=np.zeros((8, 8)))
+    # the two helpers of the module that the classes do not call: the serial twin of the pair counts (msa_numerics.py:128-179)
+    # and the zero-padded block cut (:346-374; plmdca twin plmdca/msa_numerics.py:128-152)
+    fij2 = mn.compute_pair_site_freqs_serial(alignment_data=X, num_site_states=q, seqs_weight=w)
+    np.testing.assert_allclose(mn.get_reg_pair_site_freqs(pair_site_freqs=fij2, seqs_len=L, num_site_states=q, pseudocount=0.5),
+                               G["reg_fij"], rtol=1e-12)
+    J = G["couplings"]
+    blk = mn.slice_couplings(couplings=J, site_pair=(1, 3), num_site_states=q)
+    assert blk.shape == (q, q) and not blk[q - 1].any() and not blk[:, q - 1].any()
+    np.testing.assert_array_equal(blk[:q - 1, :q - 1], J[(q - 1):2 * (q - 1), 3 * (q - 1):4 * (q - 1)])
+    from pydca_amd.plmdca import msa_numerics as pn
+    flat = np.arange(L * (L - 1) // 2 * (q - 1) ** 2, dtype=np.float64)
+    b2 = pn.slice_couplings(couplings=flat, site_pair=(1, 3), num_site_states=q, seqs_len=L)
+    pair = (L - 1) + (3 - 1 - 1)                                   # (0,1)..(0,L-1), then (1,2), (1,3)
+    np.testing.assert_array_equal(b2[:q - 1, :q - 1].reshape(-1), flat[pair * (q - 1) ** 2:(pair + 1) * (q - 1) ** 2])
+    assert not b2[q - 1].any() and not b2[:, q - 1].any()
 
 
 def test_plmdca_class_against_reference_run(oracle_mf):
@@ -575,7 +590,7 @@ def test_native_exchange_path_with_several_ranks(world):
         assert r["mf_stale_counts_dropped"] and r["mf_fi_err"] < 1e-13, r      # reduction switched on after a query; re-weighted afterwards
 
 
-@pytest.mark.parametrize("mode", ["vectors", "allreduce"])
+@pytest.mark.parametrize("mode", ["vectors", "allreduce", "selflaunch"])
 def test_bench_two_process_selftest(mode):
     """bench.py under torch.distributed.run with two ranks on ONE GPU (DCA_BENCH_SELFTEST=1: gloo
     instead of RCCL, which refuses two ranks per device).  Exercises the whole multi-process path --
@@ -589,16 +604,23 @@ def test_bench_two_process_selftest(mode):
     port = "29621" if mode == "vectors" else "29622"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "C"]
+    if mode == "selflaunch":
+        # plain `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) must start its two ranks itself -- round 3's
+        # bench printed a 1-GPU line for it
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "C"]
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
     two = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert two.returncode == 0, two.stderr[-2000:]
     d2 = json.loads(two.stdout.strip().splitlines()[-1])
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--workload", "C",
-                          "--no-cpu-baseline", "--no-mfdca"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--no-cpu-baseline", "--no-mfdca", "--no-e2e"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
-    assert d2["n_gpus"] == 2 and d2["steps"] == d1["steps"] == 4 and d2["lbfgs_status"] == d1["lbfgs_status"]
+    assert d2["n_gpus"] == 2 and d2["steps"] == d1["steps"] == 4 and d2["lbfgs_state"] == d1["lbfgs_state"] == "running"
     assert abs(d2["fx"] - d1["fx"]) <= 1e-6 * abs(d1["fx"])
-    assert d2["scaling"] == "strong" and "roofline" in d1
+    assert d2["scaling"] == "strong" and d1["roofline"]["bound"] == "valu" and d1["roofline"]["hbm"]["bound"] == "hbm"
+    assert "modes" in d1 and d1["modes"]["f64"]["iterations_per_s"] > 0
 
 
 def test_msa_numerics_direct_information_functions():

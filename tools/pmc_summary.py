@@ -48,6 +48,10 @@ def main():
         t[wl] = {"plm_scatter": scatter or None, "plm_logits": d.get("plm_logits_kernel")}
         import os
         t["measured_at_commit"] = os.environ.get("DCA_COMMIT", "unknown")      # bench.py reports it next to roofline.traffic
+        # fingerprint of the kernel sources the counters were collected on: bench.py flags the figures stale when the tree differs
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import kernel_sources_fingerprint
+        t["kernel_sources_sha256"] = kernel_sources_fingerprint()
         json.dump(t, open(path, "w"), indent=1)
     for r in rows[:8]:
         print("%-28s launches %4d  hbm bytes/launch %.4g" % (r[0], r[1], r[6]))
