@@ -157,6 +157,21 @@ int oracle_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int 
  * P = 5.5e7 products at config D, ~7e-13 of order-dependent rounding in a plain sequential sum), so vdot is compensated
  * too in this instantiation; the device sums the same rounded products in double-double. */
 #define ORACLE_COMPENSATED_FX 1
+/* Round 4: the float64 instantiation fixes the ORDER of its floating-point additions where the reference's float32 code
+ * leaves a choice that no float64 implementation is bound to (ORACLE_CANONICAL_F64; the float32 instantiation above keeps
+ * the reference's order bit for bit):
+ *   logits     z = ((sum_j J) + h) + carry: coupling rows first, ascending j from zero (the reference starts from the
+ *              carry: plmdca_numerics.cpp:499-515) -- a chunk-parallel scan cannot know the carry before the sum;
+ *   residual   one rounded value r = w p(a) - w delta(a, x) is added to every sum (the reference adds -w and +w p(a) one
+ *              after the other, :541-566);
+ *   fields     the gradient sums of the fields are compensated like the objective (order-independent).
+ * The per-slot chains of the coupling gradient stay plain sequential sums over n in ascending order, and the two site
+ * views are merged as (2 lambda x + view_i) + view_j, as before.  Why: at config E two float64 runs that differ in nothing
+ * but the order of these sums (1e-13 relative) end 7.5e-5 apart in FN after the reference's 100 iterations
+ * (profiles/r04_sensitivity_E_cap100.json) -- the optimisation does not converge and amplifies rounding by ~1.2 x per
+ * iteration -- so a device-vs-oracle comparison at 1e-4 needs BOTH to add in the same order; with it the device's
+ * float64 gradient equals this oracle's bit for bit up to the last-place differences of the two exp() implementations. */
+#define ORACLE_CANONICAL_F64 1
 #define REAL double
 #define FN(name) CAT(name, _f64)
 #define REAL_EXP exp

@@ -129,6 +129,10 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
             REAL* cgi = cg + (size_t)i * L * q2;
             REAL* hgi = hg + (size_t)i * q;
             REAL fi = 0, fic = 0;
+#ifdef ORACLE_CANONICAL_F64
+            REAL hgc[64];                         /* compensation terms of the field-gradient sums */
+            for (int a = 0; a < q; ++a) hgc[a] = 0;
+#endif
             for (int j = 0; j < i; ++j) memcpy(Wi + (size_t)j * q2, x + nh + plm_pair_index(L, j, i) * q2, q2 * sizeof(REAL));
             for (int j = i + 1; j < L; ++j) {
                 const REAL* Jij = x + nh + plm_pair_index(L, i, j) * q2;
@@ -140,6 +144,21 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
             for (int n = 0; n < N; ++n) {
                 const uint8_t* s = X + (size_t)n * L;
                 if (!carry) for (int a = 0; a < q; ++a) p[a] = 0;
+#ifdef ORACLE_CANONICAL_F64
+                /* float64 instantiation: the same terms in the order ((sum_j J) + h) + carry -- the coupling rows first, in
+                 * ascending j from zero, then the field, then the carried-over probabilities (see plm_oracle.c) */
+                REAL sj[64];
+                for (int a = 0; a < q; ++a) sj[a] = 0;
+                for (int j = 0; j < i; ++j) {
+                    const REAL* r = Wi + (size_t)j * q2 + (size_t)s[j] * q;
+                    for (int a = 0; a < q; ++a) sj[a] += r[a];
+                }
+                for (int j = i + 1; j < L; ++j) {
+                    const REAL* r = Wi + (size_t)j * q2 + (size_t)s[j] * q;
+                    for (int a = 0; a < q; ++a) sj[a] += r[a];
+                }
+                for (int a = 0; a < q; ++a) p[a] = (sj[a] + x[(size_t)i * q + a]) + p[a];
+#else
                 for (int a = 0; a < q; ++a) p[a] += x[(size_t)i * q + a];
                 for (int j = 0; j < i; ++j) {
                     const REAL* r = Wi + (size_t)j * q2 + (size_t)s[j] * q;
@@ -149,6 +168,7 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
                     const REAL* r = Wi + (size_t)j * q2 + (size_t)s[j] * q;
                     for (int a = 0; a < q; ++a) p[a] += r[a];
                 }
+#endif
                 REAL mx = p[0];
                 for (int a = 0; a < q; ++a) if (p[a] > mx) mx = p[a];
                 for (int a = 0; a < q; ++a) p[a] = REAL_EXP(p[a] - mx);
@@ -160,9 +180,21 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
                 const REAL wn = w[n];
                 const int ri = s[i];
                 FX_ADD(fi, fic, -(wn * REAL_LOG(p[ri])));
+                REAL wp[64];
+#ifdef ORACLE_CANONICAL_F64
+                /* float64 instantiation: every sum receives the ONE rounded residual w p(a) - w delta(a, x_ni) instead of the
+                 * two addends -w and +w p(a) of :541-566 one after the other; the field-gradient sums are compensated */
+                for (int a = 0; a < q; ++a) wp[a] = wn * p[a];
+                wp[ri] -= wn;
+                for (int a = 0; a < q; ++a) FX_ADD(hgi[a], hgc[a], wp[a]);
+                for (int j = 0; j < L; ++j) {
+                    if (j == i) continue;
+                    REAL* row = Ti + (size_t)j * q2 + (size_t)s[j] * q;
+                    for (int a = 0; a < q; ++a) row[a] += wp[a];
+                }
+#else
                 hgi[ri] -= wn;
                 for (int a = 0; a < q; ++a) hgi[a] += wn * p[a];
-                REAL wp[64];
                 for (int a = 0; a < q; ++a) wp[a] = wn * p[a];
                 for (int j = 0; j < L; ++j) {
                     if (j == i) continue;
@@ -170,6 +202,7 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
                     row[ri] -= wn;
                     for (int a = 0; a < q; ++a) row[a] += wp[a];
                 }
+#endif
             }
             /* back into the pair orientation (state of the smaller site first), as :494,:541-567 */
             for (int j = 0; j < i; ++j) memcpy(cgi + (size_t)j * q2, Ti + (size_t)j * q2, q2 * sizeof(REAL));
@@ -180,6 +213,9 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
             }
             fsite[2 * i] = fi;
             fsite[2 * i + 1] = fic;
+#ifdef ORACLE_CANONICAL_F64
+            for (int a = 0; a < q; ++a) hgi[a] += hgc[a];
+#endif
         }
         free(Wi); free(Ti);
     }

@@ -17,6 +17,8 @@
 // The 64x64 diagonal leaves (Cholesky + triangular inverse) run in one workgroup in LDS.
 #include <climits>
 #include <mutex>
+#include <atomic>
+
 #include "dca_internal.h"
 
 namespace {
@@ -993,7 +995,7 @@ struct Arena {
 // 256).  WALK_ROWS only.
 int launch_gemm_banded(dca_ctx* ctx, hipStream_t stream, GemmArgs g, int maxWGs)
 {
-    static bool attr128 = false;
+    static std::atomic<bool> attr128{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
     if (!attr128) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 16 * 8));
         attr128 = true;
@@ -1022,7 +1024,7 @@ bool launch_gemm_small_pair(dca_ctx* ctx, const GemmArgs& a, const GemmArgs& b)
     const dim3 ga = grid64(a), gb = grid64(b);
     if (!on || (long long)ga.x * ga.y > small32_max() || (long long)gb.x * gb.y > small32_max()) return false;
     const size_t lds = (size_t)2 * (32 + 32) * (64 + 2) * sizeof(double);
-    static bool attr = false;
+    static std::atomic<bool> attr{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         attr = true;
@@ -1042,7 +1044,7 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
     if ((long long)grid.x * grid.y <= small32Max) {          // far fewer tiles than CUs: 32 x 32 tiles on four times as many CUs
         dim3 g32(grid.x * 2, grid.y * 2);
         const size_t lds = (size_t)2 * (32 + 32) * (64 + 2) * sizeof(double);
-        static bool attr32 = false;
+        static std::atomic<bool> attr32{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
         if (!attr32) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr32 = true;
@@ -1051,7 +1053,7 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
         return DCA_OK;
     }
     if ((long long)grid.x * grid.y <= deepMaxTiles) {       // under two workgroups per CU: latency bound (measured: 0 -> 37.7, 128 -> 37.0, 400 -> 36.4, 1600 -> 36.9 ms)
-        static bool attr = false;
+        static std::atomic<bool> attr{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
         if (!attr) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)gemm_lds_bytes<64>()));
@@ -1081,14 +1083,14 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
             const bool walkOk = g.walk != WALK_COLUMNS_REVERSED;
             if (!use128 && walkOk && rect && (masks == 2 || (rect == 2 && masks == 1)) && (long long)grid.x * grid.y >= 2048) {
                 // 128 x 64 tiles: grid.y counts 128-row tiles
-                static bool attrR = false;
+                static std::atomic<bool> attrR{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
                 if (!attrR) {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 16 * 8));
                     attrR = true;
                 }
                 hipLaunchKernelGGL((gemm_nt_f64_dma_kernel<4, 2>), dim3(grid.x, gy), dim3(256), (size_t)2 * (128 + 64) * 16 * sizeof(double), ctx->stream, g);
             } else if (use128) {
-                static bool attr128 = false;
+                static std::atomic<bool> attr128{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
                 if (!attr128) {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 16 * 8));
                     attr128 = true;
@@ -1189,12 +1191,13 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     // background product is waited for at the join); any background at depths 1 or 2 loses -- their subtrees are chains of
     // few-tile products that share CUs with it (0,40,10: 36.0, 0,0,10: 25.5 without stream priorities) -- so only the top
     // level overlaps: n = 8000: 14.7 -> 14.5, n = 6000: 7.6 -> 7.5, n = 4000: unchanged
-    static int sideBudget[kSideDepths] = {240, 0, 0};
-    static bool budgetRead = false;
-    if (!budgetRead) {
-        if (const char* e = getenv("DCA_CHOLINV_SIDE_WGS")) sscanf(e, "%d,%d,%d", &sideBudget[0], &sideBudget[1], &sideBudget[2]);
-        budgetRead = true;
-    }
+    struct SideBudget { int v[kSideDepths]; };
+    static const SideBudget sideBudgetInit = [] {            // parsed once, thread-safe (contexts may live on several host threads)
+        SideBudget b{{240, 0, 0}};
+        if (const char* e = getenv("DCA_CHOLINV_SIDE_WGS")) sscanf(e, "%d,%d,%d", &b.v[0], &b.v[1], &b.v[2]);
+        return b;
+    }();
+    const int* sideBudget = sideBudgetInit.v;
     bool onSide = false;
     static const int sideMinN1 = getenv("DCA_CHOLINV_SIDE_MIN") ? atoi(getenv("DCA_CHOLINV_SIDE_MIN")) : 1024;
     // the fork comes BEFORE the SYRK: that product's 820 lower 128 x 128 tiles fill 512 slots 1.6 times (47 TF), and the
@@ -1209,12 +1212,22 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
         onSide = true;
         return DCA_OK;
     };
-    if (useSide && forkBeforeSyrk) DCA_TRY(fork_side());
-    if (!paired) DCA_TRY(launch_gemm(ctx, syrkArgs));
-    if (useSide && !forkBeforeSyrk) DCA_TRY(fork_side());
-    DCA_TRY(cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo, side, depth + 1));
-    if (onSide) HIP_TRY(hipStreamWaitEvent(ctx->stream, side->join[depth], 0));
-    else if (!paired) DCA_TRY(launch_gemm(ctx, ttArgs));
+    // Once the background product is in flight, NO path may leave this frame without joining it: it writes Tt in the
+    // arena, and the caller hands the side set back and may reuse or free the workspace as soon as this returns.  On
+    // an error below, the side stream is drained on the host before the error is passed on.
+    auto bail = [&](int rc) -> int {
+        if (onSide) hipStreamSynchronize(side->s[depth]);
+        ws.top = mark;
+        return rc;
+    };
+    int rc = DCA_OK;
+    if (useSide && forkBeforeSyrk && (rc = fork_side()) != DCA_OK) return bail(rc);
+    if (!paired && (rc = launch_gemm(ctx, syrkArgs)) != DCA_OK) return bail(rc);
+    if (useSide && !forkBeforeSyrk && (rc = fork_side()) != DCA_OK) return bail(rc);
+    if ((rc = cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo, side, depth + 1)) != DCA_OK) return bail(rc);
+    if (onSide) {
+        if (hipStreamWaitEvent(ctx->stream, side->join[depth], 0) != hipSuccess) { dca_set_error("cholinv: join of the side stream failed"); return bail(DCA_ERR_HIP); }
+    } else if (!paired) DCA_TRY(launch_gemm(ctx, ttArgs));
     // X21[i][j] = -sum_k X22[i][k] * T^T[j][k];  X22 lower (k <= i); mirrored into the (1,2) block
     DCA_TRY(launch_gemm(ctx, GemmArgs{M22, ld, MASK_LOWER, Tt, n2, MASK_NONE, M21, ld, M12, ld, n2, n1, n2, -1.0, 0.0, 0, WALK_ROWS_REVERSED}));
     ws.top = mark;

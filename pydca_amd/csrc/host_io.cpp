@@ -10,6 +10,7 @@
 // open-addressing table of 64-bit row hashes with memcmp on a hash match (file order, so the reference's "first
 // occurrence wins" is kept), rows compacted in place.  Config D (25 MB, 50 000 x 500): 0.67 s with getline + a set of
 // strings -> a few ms.
+#include <cerrno>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -50,28 +51,52 @@ struct CodeTable {
 };
 const CodeTable kCodes;
 
-// read-only view of a whole file
+// read-only view of a whole file: regular files are mapped; anything else that can be opened and read (a FIFO, /dev/stdin,
+// a process substitution -- the reference's std::ifstream / Biopython readers take those too) or a file that cannot be
+// mapped is read into a heap buffer, and the same indexer runs over it
 struct MappedFile {
     const char* data = nullptr;
     size_t size = 0;
     int fd = -1;
+    bool mapped = false;
+    std::vector<char> heap;
+    bool slurp()
+    {
+        heap.clear();
+        char buf[1 << 16];
+        for (;;) {
+            const ssize_t got = ::read(fd, buf, sizeof(buf));
+            if (got < 0) { if (errno == EINTR) continue; return false; }
+            if (got == 0) break;
+            heap.insert(heap.end(), buf, buf + got);
+        }
+        data = heap.data();
+        size = heap.size();
+        return true;
+    }
     bool open(const char* path)
     {
         fd = ::open(path, O_RDONLY);
         if (fd < 0) return false;
         struct stat st;
-        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); fd = -1; return false; }
-        size = (size_t)st.st_size;
-        if (size == 0) return true;
-        void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
-        if (p == MAP_FAILED) { ::close(fd); fd = -1; return false; }
-        madvise(p, size, MADV_SEQUENTIAL);
-        data = static_cast<const char*>(p);
+        if (fstat(fd, &st) != 0 || S_ISDIR(st.st_mode)) { ::close(fd); fd = -1; return false; }
+        if (S_ISREG(st.st_mode)) {
+            size = (size_t)st.st_size;
+            if (size == 0) return true;
+            void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (p != MAP_FAILED) {
+                madvise(p, size, MADV_SEQUENTIAL);
+                data = static_cast<const char*>(p);
+                mapped = true;
+                return true;
+            }
+        }
+        if (!slurp()) { ::close(fd); fd = -1; return false; }
         return true;
     }
     ~MappedFile()
     {
-        if (data) munmap(const_cast<char*>(data), size);
+        if (mapped) munmap(const_cast<char*>(data), size);
         if (fd >= 0) ::close(fd);
     }
 };

@@ -580,6 +580,40 @@ __global__ void plm_sum_slabs_cols_kernel(T* __restrict__ G, size_t slabElems, i
     for (int sidx = 1; sidx < nzero; ++sidx) G[(size_t)sidx * slabElems + off] = (T)0;
 }
 
+// ------------------------------------------------------------------ column sums of R (float64 mode)
+// g[h_i(a)] needs sum_n R[n][(i,a)].  The float32 path reads it off G (sum over the states of site 0's rows); in float64
+// mode -- the parity mode -- it is summed in double-double, i.e. independently of the order, like the objective: the
+// oracle compensates the same sums (ORACLE_CANONICAL_F64), so both round the same exact value.  One more pass over R.
+constexpr int kColSumRowBlocks = 64;
+template <typename T>
+__global__ __launch_bounds__(256)
+void plm_colsum_parts_kernel(const T* __restrict__ R, int N, int Cs, int Lq, double* __restrict__ parts)
+{
+    __shared__ double redHi[4][64], redLo[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int rpb = (N + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rpb, r1 = min(N, r0 + rpb);
+    double hi = 0.0, lo = 0.0;
+    if (c < Lq)
+        for (int n = r0 + wv; n < r1; n += 4) dd_add(hi, lo, (double)R[(size_t)n * Cs + c]);
+    redHi[wv][lane] = hi; redLo[wv][lane] = lo;
+    __syncthreads();
+    if (wv == 0 && c < Lq) {
+        for (int w = 1; w < 4; ++w) dd_add2(hi, lo, redHi[w][lane], redLo[w][lane]);
+        parts[2 * ((size_t)blockIdx.y * Lq + c)] = hi;
+        parts[2 * ((size_t)blockIdx.y * Lq + c) + 1] = lo;
+    }
+}
+__global__ void plm_colsum_final_kernel(const double* __restrict__ parts, int nblocks, int Lq, double* __restrict__ colSum)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Lq) return;
+    double hi = 0.0, lo = 0.0;
+    for (int b = 0; b < nblocks; ++b) dd_add2(hi, lo, parts[2 * ((size_t)b * Lq + c)], parts[2 * ((size_t)b * Lq + c) + 1]);
+    colSum[c] = hi + lo;
+}
+
 // ------------------------------------------------------------------ fold
 // g[J_ij(a,b)] = 2 lambda_J J + G[(j,b)][(i,a)] + G[(i,a)][(j,b)]   (plmdca_numerics.cpp:541-602:
 // the site-i and the site-j conditional both contribute), regulariser value per pair
@@ -623,9 +657,11 @@ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* 
     for (int t = lane; t < q2; t += 64) {
         const int a = t / q, b = t % q;
         const T xv = x[base + t];
+        // (2 lambda x + site i's conditional) + site j's conditional: the order of the reference's one-thread merge
+        // (plmdca_numerics.cpp:570-602 in ascending site order) and of the oracle
         T gv = addReg ? (T)2 * lambdaJ * xv : (T)0;
-        gv += slab_sum(G, (size_t)(i * q + a) * Cs + j * q + b, slabElems, nsplit);
-        gv += tile[b * q + a];
+        gv += tile[b * q + a];                                                            // G[(j,b)][(i,a)]: column of site i
+        gv += slab_sum(G, (size_t)(i * q + a) * Cs + j * q + b, slabElems, nsplit);      // G[(i,a)][(j,b)]: column of site j
         g[base + t] = gv;
         if (addReg) dd_add(reg, regLo, (double)lambdaJ * (double)xv * (double)xv);
     }
@@ -635,10 +671,12 @@ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* 
 
 // g[h_i(a)] = 2 lambda_h h + sum_n R[n][(i,a)]; the column sum of R is the sum over b of
 // any site's rows of G (site 0 here).  (:463-471, :538-539, :573-578)
+// colSum (float64 mode): the column sums of R summed order-independently by plm_colsum_* below; else they are taken
+// from G as described above.
 template <typename T>
 __global__ void plm_fold_fields_kernel(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
                                        double* __restrict__ regPart, int Lq, int q, int Cs, T lambdaH, int addReg,
-                                       size_t slabElems, int nsplit)
+                                       size_t slabElems, int nsplit, const double* __restrict__ colSum)
 {
     __shared__ double red[256];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -647,7 +685,8 @@ __global__ void plm_fold_fields_kernel(const T* __restrict__ x, const T* __restr
         const T xv = x[c];
         T gv = addReg ? (T)2 * lambdaH * xv : (T)0;
         T s = 0;
-        for (int b = 0; b < q; ++b) s += slab_sum(G, (size_t)b * Cs + c, slabElems, nsplit);
+        if (colSum) s = (T)colSum[c];
+        else for (int b = 0; b < q; ++b) s += slab_sum(G, (size_t)b * Cs + c, slabElems, nsplit);
         g[c] = gv + s;
         if (addReg) reg = (double)lambdaH * (double)xv * (double)xv;
     }
@@ -1004,6 +1043,26 @@ __global__ void sum_chunks_kernel(const double* __restrict__ partials, int n, do
     block_reduce_store(s, red, out + blockIdx.x);
 }
 
+#ifdef DCA_ROUND_ABLATE
+// ANALYSIS BUILD ONLY (make ablate -> lib/libdca_hip_ablate.so; the shipped library has no such switch): the float64 engine
+// rounds the output of selected stages to float32, DCA_ROUND_F32_STAGES = bit mask (1 W, 2 S, 4 R, 8 G, 16 g, 32 x, 64 d).
+// Rounding a stage's OUTPUT is a lower bound on what computing that stage in float32 would do to the result; used to
+// decide which mixed-precision pipelines can keep protocol P3 (tests/analysis/mixed_precision_table.py).
+__global__ void round_to_f32_kernel(double* __restrict__ p, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = (double)(float)p[i];
+}
+inline int round_stage_mask() { const char* e = getenv("DCA_ROUND_F32_STAGES"); return e ? atoi(e) : 0; }
+#define DCA_ROUND_STAGE(bit, ptr, count)                                                                             \
+    do {                                                                                                             \
+        if constexpr (sizeof(T) == 8)                                                                                \
+            if (round_stage_mask() & (bit))                                                                          \
+                hipLaunchKernelGGL(round_to_f32_kernel, dim3(2048), dim3(256), 0, ctx->stream, reinterpret_cast<double*>(ptr), (size_t)(count)); \
+    } while (0)
+#else
+#define DCA_ROUND_STAGE(bit, ptr, count) do { } while (0)
+#endif
+
 template <typename T>
 __global__ void cast_weights_kernel(const double* __restrict__ wd, T* __restrict__ w, int N)
 {
@@ -1131,6 +1190,7 @@ struct PlmEngine : PlmEngineBase {
     int NT = 0;
     PairIJ* dPairs = nullptr;
     double *dFxPart = nullptr, *dRegPart = nullptr, *dVecPart = nullptr;
+    double *dColPart = nullptr, *dColSum = nullptr;      // float64 mode: column sums of R in double-double
     int nFxPart = 0, nRegPart = 0;
     bool lbfgs_alloc = false;
     // vector sharding (dca_plm_set_vector_sharding): this rank's slice [vlo, vlo + vn) of every P-vector;
@@ -1164,6 +1224,7 @@ struct PlmEngine : PlmEngineBase {
         for (int i = 0; i < 5; ++i) { dca_dev_free(dS[i]); dca_dev_free(dY[i]); }
         dca_dev_free(dLb); dLb = nullptr; dca_dev_free(dWt); dca_dev_free(dSR); dca_dev_free(dR); dca_dev_free(dG); dca_dev_free(dw); dca_dev_free(dXL); dca_dev_free(dXT2);
         dca_dev_free(dPairs); dca_dev_free(dFxPart); dca_dev_free(dRegPart); dca_dev_free(dVecPart);
+        dca_dev_free(dColPart); dca_dev_free(dColSum);
     }
     ~PlmEngine() override { freeall(); }
 
@@ -1188,7 +1249,11 @@ struct PlmEngine : PlmEngineBase {
         // warm-up rows of a small array) until there is about one chunk-wave per SIMD: config C 0.30 -> 0.16 ms with 32
         if (chunk_ <= 0)
             while (chunk > 32 && (long long)ceil_div(N - halo_, chunk) * ceil_div(L, 64) < 1024) chunk /= 2;
-        warm = warm_ > 0 ? warm_ : 40;
+        // warm-up steps of the chunk-parallel scan: 2^-40 of start-up error is far below float rounding; the float64 mode is
+        // the parity mode and takes 80, with which the chunked scan is BIT-identical to the serial chain (the start-up
+        // error has dropped below the last place of every carried probability; 100 iterations at configs D and E end in the
+        // same bits, profiles/r04_sensitivity_*.json)
+        warm = warm_ > 0 ? warm_ : (sizeof(T) == 8 ? 80 : 40);
         if (carry_mode == DCA_CARRY_SERIAL) { chunk = N - halo; warm = halo; }
         if (carry_mode == DCA_CARRY_EXACT) warm = 0;
         numScanChunks = ceil_div(N - halo, chunk);
@@ -1199,6 +1264,7 @@ struct PlmEngine : PlmEngineBase {
         for (int i = 0; i < 5; ++i) dS[i] = dY[i] = nullptr;
         dWt = dSR = dR = dG = dw = nullptr; dXL = nullptr; dXT2 = nullptr; dPairs = nullptr;
         dFxPart = dRegPart = dVecPart = nullptr;
+        dColPart = dColSum = nullptr;
         lbfgs_alloc = false;
         o = decltype(o)();
 
@@ -1239,7 +1305,11 @@ struct PlmEngine : PlmEngineBase {
             const char* splitEnv = getenv("DCA_SCATTER_SPLIT");    // tuning knob: the split of the main launch
             double bestCost = 1e300;
             scatSplit = 1; scatChunksPerSplit = numScatChunks; scatRemCT = scatRemSplit = scatRemChunksPerSplit = 0;
-            for (int sp = 1; sp <= (splitEnv ? numScatChunks : s0); ++sp) {
+            // float64 = parity mode: ONE chain per (site, state, column) over the sequences in ascending order -- the oracle's
+            // (and the reference's one-thread) order of summation, so that the gradient does not depend on the launch
+            // geometry; no tile-range split and no separate launch for the left-over strips unless a test forces them
+            const bool canonical = sizeof(T) == 8 && !splitEnv && !remEnv;
+            for (int sp = 1; sp <= (canonical ? 0 : (splitEnv ? numScatChunks : s0)); ++sp) {
                 if (splitEnv && sp != std::max(1, std::min(numScatChunks, atoi(splitEnv)))) continue;
                 const int cps = ceil_div(numScatChunks, sp);
                 if (ceil_div(numScatChunks, cps) != sp && !splitEnv) continue;               // same as a smaller split
@@ -1275,6 +1345,10 @@ struct PlmEngine : PlmEngineBase {
         DCA_TRY(dalloc(&dFxPart, 2 * (size_t)nFxPart));                       // (hi, lo) pairs
         DCA_TRY(dalloc(&dRegPart, 2 * (size_t)(nRegPart + kSumStageBlocks)));      // pairs; + the first-stage sums of the regulariser partials
         DCA_TRY(dalloc(&dVecPart, 2 * 27 * kVecBlocks));      // (hi, lo) pairs
+        if (sizeof(T) == 8) {
+            DCA_TRY(dalloc(&dColPart, 2 * (size_t)kColSumRowBlocks * Lq));
+            DCA_TRY(dalloc(&dColSum, (size_t)Lq));
+        }
 
         HIP_TRY(hipMemsetAsync(dx, 0, (P + kVecPad) * sizeof(T), ctx->stream));
         HIP_TRY(hipMemsetAsync(dg, 0, (P + kVecPad) * sizeof(T), ctx->stream));
@@ -1404,6 +1478,7 @@ struct PlmEngine : PlmEngineBase {
             hipLaunchKernelGGL(plm_expand_kernel<T>, dim3((unsigned)npairs), dim3(256), (size_t)q * q * sizeof(T), st,
                                dx, dWt, dPairs, L, q, Cs);
         }
+        DCA_ROUND_STAGE(1, dWt, (size_t)Wrows * Cs);
         {
             constexpr int CW = 512 / (int)sizeof(T);
             const int numCT = ceil_div(Cs, CW);
@@ -1415,6 +1490,7 @@ struct PlmEngine : PlmEngineBase {
             ScopedKernelClock kc(ctx, "plm_logits");
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(logits_waves(Q) * 64), lds, st, dWt, dXL, dSR, N, Npad, L, Cs, numCT, numNB);
         }
+        DCA_ROUND_STAGE(2, dSR, (size_t)N * Cs);
         {
             dim3 grid(ceil_div(L, 64), ceil_div(numScanChunks, 4));
             ScopedKernelClock kc(ctx, "plm_softmax");
@@ -1424,6 +1500,7 @@ struct PlmEngine : PlmEngineBase {
             hipLaunchKernelGGL((plm_softmax_kernel<T, Q>), grid, dim3(256), softLds, st, dSR, dR, dx, ctx->dX, dw, dFxPart,
                                N, L, Ls, Cs, halo, chunk, warm, carry_mode != DCA_CARRY_EXACT ? 1 : 0, numScanChunks);
         }
+        DCA_ROUND_STAGE(4, dR, (size_t)N * Cs);
         {
             constexpr int CW = kRowBytes / (int)sizeof(T);
             const int numCT = ceil_div(Cs, CW);
@@ -1451,6 +1528,7 @@ struct PlmEngine : PlmEngineBase {
             };
             DCA_TRY(launch(plm_scatter_kernel<T, Q, 2>));
         }
+        DCA_ROUND_STAGE(8, dG, (size_t)std::max(scatSplit, scatRemSplit) * Grows * Cs);
         {
             ScopedKernelClock kc(ctx, "plm_fold");
             int foldSlabs = scatSplit;
@@ -1461,9 +1539,14 @@ struct PlmEngine : PlmEngineBase {
             const size_t lds = (size_t)kFoldWaves * ((q * q + 3) / 4 * 4) * sizeof(T);
             hipLaunchKernelGGL(plm_fold_pairs_kernel<T>, dim3((unsigned)ceil_div((int)npairs, kFoldWaves)), dim3(64 * kFoldWaves), lds, st, dx, dG, dg, dPairs,
                                dRegPart, L, q, Cs, (T)lambda_J, add_reg, (size_t)Grows * Cs, foldSlabs, (int)npairs);
+            if (dColSum) {
+                hipLaunchKernelGGL(plm_colsum_parts_kernel<T>, dim3(ceil_div(Lq, 64), kColSumRowBlocks), dim3(256), 0, st, dR, N, Cs, Lq, dColPart);
+                hipLaunchKernelGGL(plm_colsum_final_kernel, dim3(ceil_div(Lq, 256)), dim3(256), 0, st, dColPart, kColSumRowBlocks, Lq, dColSum);
+            }
             hipLaunchKernelGGL(plm_fold_fields_kernel<T>, dim3(ceil_div(Lq, 256)), dim3(256), 0, st, dx, dG, dg,
-                               dRegPart + 2 * npairs, Lq, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, foldSlabs);
+                               dRegPart + 2 * npairs, Lq, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, foldSlabs, dColSum);
         }
+        DCA_ROUND_STAGE(16, dg, P);
         // fx = regulariser + data term  -> ctx->dScal[0]
         // (one partial per site pair: summed in two stages, a single workgroup needs 28 us for the 125 000 of config D)
         hipLaunchKernelGGL(dd_sum_chunks_kernel, dim3(kSumStageBlocks), dim3(256), 0, st, dRegPart, nRegPart, dRegPart + 2 * (size_t)nRegPart);
@@ -1660,6 +1743,7 @@ struct PlmEngine : PlmEngineBase {
                 (brackt && (stmax - stmin <= xtol * stmax)))
                 *stp = bx.st;
             v_step(dx, dxp, *stp, dd);
+            DCA_ROUND_STAGE(32, dx, P);
             if ((*rc_hip = gather_vector(dx))) return 0;      // sharded vectors: every rank needs the whole x
             if ((*rc_hip = evaluate_async())) return 0;
             double dg_;
@@ -1748,6 +1832,7 @@ struct PlmEngine : PlmEngineBase {
                 ScopedKernelClock kc(ctx, "lbfgs_vec");
                 hipLaunchKernelGGL(lbfgs_two_loop_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->dScal, dLb, e, o.end, bound, gg);
                 hipLaunchKernelGGL(vec_compose_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dd + vlo, dg + vlo, ptrs, &dLb->cf, vn);
+                DCA_ROUND_STAGE(64, dd, P);
                 o.dginit_on_device = true;
             }
             o.step = 1.0;

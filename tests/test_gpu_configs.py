@@ -213,7 +213,7 @@ def test_config_C_lbfgs_P3_chunked_float64(L_, oracle_plm, oracle_mf, msa_C, ora
         s_gpu = ctx.plm_scores(apc)
         s_ref = oracle_mf.plm_fn(ref["x"], L, q, apc_correct=apc)
         # FN relative to itself; FN_APC (a difference that crosses zero) relative to the pair's uncorrected score
-        report["max_rel_%s" % ("fn_apc_vs_fn" if apc else "fn")] = assert_scores_within(s_gpu, s_ref, fn_ref, 1e-4)
+        report["max_rel_%s" % ("fn_apc_vs_fn" if apc else "fn")] = assert_scores_within(s_gpu, s_ref, fn_ref, 1e-4, top=L)
         assert list(_top(s_gpu, L)) == list(_top(s_ref, L))
     # DI of the same parameters (the other score BASELINE.json's tolerance names)
     reg_fi = oracle_mf.get_reg_single_site_freqs(oracle_mf.compute_single_site_freqs(X.astype(np.int32) + 1, q, ref["w64"]), L, q, 0.5)

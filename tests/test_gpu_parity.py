@@ -117,22 +117,34 @@ def test_gradient_float32_vs_reference_and_oracle(L_, oracle_plm, tag, mode):
 
 @pytest.mark.parametrize("tag", ["toy_rna", "toy_protein", "rf71"])
 def test_gradient_float64_vs_oracle(L_, oracle_plm, tag):
-    """float64 kernels vs the float64 oracle: summation order is the only difference."""
+    """float64 kernels vs the float64 oracle AT THE LAST BITS.  Round 4: the float64 mode forms every sum in the oracle's
+    order (coupling rows in ascending j, then field, then carry; one chain per (site, state, column) over the sequences in
+    ascending order; (2 lambda x + view_i) + view_j) or order-independently (objective and field gradients in
+    double-double against the oracle's compensated sums), and its chunked scan warms up for 80 steps, which makes it
+    bit-identical to the serial chain.  What is left are the last-place differences of the two exp() implementations
+    (device library / glibc): most gradient elements are EQUAL, the vector agrees to a few 1e-16 (1e-12 before)."""
     G = golden("plm_" + tag)
     L, q = int(G["L"]), int(G["q"])
     lh, lJ = float(G["lambda_h"]), float(G["lambda_J"])
     w64 = oracle_plm.weights(G["X"], 0.8, np.float64)
-    x = perturbed(oracle_plm.init_x(G["X"], w64, q), L, q)
-    for mode, carry in ((L_.CARRY_SERIAL, True), (L_.CARRY_CHUNKED, True), (L_.CARRY_EXACT, False)):
-        ctx = make_ctx(L_, G["X"], q, L_.DCA_F64, 0.8, L_.DCA_F64)
-        ctx.plm_configure(lh, lJ, mode)
-        ctx.plm_set_x(x)
-        fx = ctx.plm_gradient()
-        g = ctx.plm_get_g(np.float64)
-        fx_o, g_o = oracle_plm.gradient(G["X"], w64, q, lh, lJ, x, carry=carry)
-        assert abs(fx - fx_o) <= 1e-11 * abs(fx_o), (mode, fx, fx_o)
-        assert rel_err(g, g_o) < 1e-11, mode
-        ctx.close()
+    x0 = oracle_plm.init_x(G["X"], w64, q)
+    got = {}
+    for name, x in (("x0", x0), ("x1", perturbed(x0, L, q))):
+        for mode, carry in ((L_.CARRY_SERIAL, True), (L_.CARRY_CHUNKED, True), (L_.CARRY_EXACT, False)):
+            ctx = make_ctx(L_, G["X"], q, L_.DCA_F64, 0.8, L_.DCA_F64)
+            ctx.plm_configure(lh, lJ, mode)
+            ctx.plm_set_x(x)
+            fx = ctx.plm_gradient()
+            g = ctx.plm_get_g(np.float64)
+            fx_o, g_o = oracle_plm.gradient(G["X"], w64, q, lh, lJ, x, carry=carry)
+            assert abs(fx - fx_o) <= 4e-16 * abs(fx_o), (name, mode, fx, fx_o)           # equal or one unit in the last place
+            assert rel_err(g, g_o) < 5e-15, (name, mode, rel_err(g, g_o))
+            assert np.mean(g != g_o) < 0.3, (name, mode, float(np.mean(g != g_o)))
+            got[(name, mode)] = (fx, g)
+            ctx.close()
+        # the chunked scan (80 warm-up steps in float64) and the serial chain: the same bits
+        assert got[(name, L_.CARRY_CHUNKED)][0] == got[(name, L_.CARRY_SERIAL)][0]
+        assert np.array_equal(got[(name, L_.CARRY_CHUNKED)][1], got[(name, L_.CARRY_SERIAL)][1])
 
 
 def test_chunked_scan_equals_serial_chain(L_, oracle_plm):
@@ -232,7 +244,7 @@ def test_lbfgs_float64_matches_oracle_at_equal_iteration_cap(L_, oracle_plm, ora
     for apc in (False, True):
         s_gpu = ctx.plm_scores(apc)
         s_ref = oracle_mf.plm_fn(ref["x"], L, q, apc_correct=apc)
-        assert_scores_within(s_gpu, s_ref, fn_ref, 1e-4)          # FN relative to itself, FN_APC relative to the pair's FN
+        assert_scores_within(s_gpu, s_ref, fn_ref, 1e-4, top=L)          # FN relative to itself, FN_APC relative to the pair's FN
         assert _topL_same(s_gpu, s_ref, L)
     ctx.close()
 
@@ -266,7 +278,7 @@ def test_exact_gradient_mode_converges_to_the_oracles_minimiser(L_, oracle_plm, 
     for apc in (False, True):
         s_gpu = ctx.plm_scores(apc)
         s_ref = oracle_mf.plm_fn(ref["x"], L, q, apc_correct=apc)
-        assert_scores_within(s_gpu, s_ref, fn_ref, 1e-4)
+        assert_scores_within(s_gpu, s_ref, fn_ref, 1e-4, top=L)
         assert _topL_same(s_gpu, s_ref, L)
     # the oracle's minimiser is a stationary point for the device too: the gradient there passes the same test
     ctx.plm_set_x(ref["x"])

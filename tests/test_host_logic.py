@@ -172,6 +172,42 @@ def test_native_fasta_reader_edge_cases(tmp_path):
     assert fasta_reader.get_alignment_int_array(str(u), "rna").tolist() == _text_mode_reader(str(u), "rna").tolist()
 
 
+def test_readers_take_a_fifo(tmp_path):
+    """Inputs that are not regular files (a FIFO here; /dev/stdin and process substitutions alike) cannot be mapped: the
+    native readers read them into memory and run the same indexer -- the reference's std::ifstream and Biopython readers
+    accept such inputs too."""
+    import ctypes as C
+    import threading
+    from pydca_amd import _lib
+    G = golden("plm_toy_rna")
+    src = open(data_file("toy_rna.fa"), "rb").read()
+
+    def through_fifo(call):
+        fifo = str(tmp_path / "msa.fifo")
+        if os.path.exists(fifo):
+            os.unlink(fifo)
+        os.mkfifo(fifo)
+        t = threading.Thread(target=lambda: open(fifo, "wb").write(src))
+        t.start()
+        try:
+            return call(fifo)
+        finally:
+            t.join()
+    X, raw = through_fifo(lambda f: _lib.read_fasta(f, _lib.RNA))
+    X_file, raw_file = _lib.read_fasta(data_file("toy_rna.fa"), _lib.RNA)
+    assert raw == raw_file and np.array_equal(X, X_file)
+
+    def cxx(fifo):
+        out = np.empty((int(G["raw_count"]) + 1, int(G["L"])), dtype=np.uint8)
+        rawc = C.c_int(0)
+        n = _lib.lib().dca_read_msa(os.fsencode(fifo), 2, int(G["L"]), out.ctypes.data_as(C.c_void_p), out.shape[0], C.byref(rawc))
+        return out[:n], rawc.value
+    X2, raw2 = through_fifo(cxx)
+    assert raw2 == int(G["raw_count"]) and np.array_equal(X2, G["X"])
+    with pytest.raises(Exception):
+        _lib.read_fasta(str(tmp_path), _lib.RNA)          # a directory is still an error
+
+
 def test_readers_large_alignment_with_scattered_duplicates(tmp_path):
     """Both native readers on 20 000 x 300 with 15 % duplicates scattered through the file: first occurrences kept in
     file order (numpy reference), row hashes + memcmp, several host threads."""
