@@ -273,12 +273,39 @@ def logits_jt(q):
 # 1.88 for 12 waves x 56 sequences with two ping-pong sets (round 1's shape; 16 x 32: 2.25).
 # q=5: 16 waves x 48 sequences, two sets.
 LOGITS_CFG = {21: (8, 96), 5: (16, 48)}
+# Row registers double-buffered (round 4): the q rows of site j+1 are requested WHILE site j's adds issue (one ds_read every
+# few adds, into a second set of q register pairs), so a wave no longer stops for an LDS round trip (~490 clk) in front of
+# every site -- with two waves per SIMD that bubble is what kept the adds at ~57 % of the VALU.  The second set costs 2q
+# registers, i.e. q = 21 runs 80 instead of 96 sequences per wave; only the first site of a tile still waits.
+LOGITS_DBUF = {21: False, 5: False}
+if os.environ.get("DCA_GEN_LG21"):             # experiments: "waves,nseq,dbuf"
+    _w, _n, _d = (int(v) for v in os.environ["DCA_GEN_LG21"].split(","))
+    LOGITS_CFG[21] = (_w, _n)
+    LOGITS_DBUF[21] = bool(_d)
 LS0 = 36                       # first state-word SGPR
-LOGITS_CHUNK = 16              # dwords per scalar load of the single-set schedule (32 sequences)
+LOGITS_CHUNK = 16              # largest scalar load of the single-set schedule (16 dwords = 32 sequences)
 
 
 def logits_single_set(q):
     return LOGITS_CFG[q][0] == 8
+
+
+def logits_chunks(q):
+    """single-set schedule: the site's nseq/2 state dwords as (first dword, dwords) pieces of 16 / 8 / 4, smallest first (the
+    LAST piece should be a long one: the next site's first pieces are requested when its first word is used)"""
+    nw = LOGITS_CFG[q][1] // 2
+    sizes, left = [], nw
+    for piece in (16, 8, 4):
+        while left >= piece:
+            sizes.append(piece)
+            left -= piece
+    assert left == 0 and len(sizes) >= 2
+    sizes.sort()
+    out, at = [], 0
+    for sz in sizes:
+        out.append((at, sz))
+        at += sz
+    return out
 
 
 def logits_plan(q):
@@ -289,15 +316,18 @@ def logits_plan(q):
     nw = (nseq // 2 + 3) // 4 * 4
     tb = LS0 + (1 if logits_single_set(q) else 2) * nw
     assert tb + 7 <= 96 and nseq % 8 == 0
-    assert not logits_single_set(q) or (nw % LOGITS_CHUNK == 0 and nw // LOGITS_CHUNK >= 2)
-    return waves, nseq, acc0 - 2 * q, acc0, nw, tb
+    w0 = acc0 - 2 * q * (2 if LOGITS_DBUF[q] else 1)
+    assert w0 >= 8, "no VGPRs left for the compiler"
+    return waves, nseq, w0, acc0, nw, tb
 
 
 def logits_chunk_load(q, c):
-    """single-set schedule: scalar load of chunk c (LOGITS_CHUNK dwords) of the site the state pointer is at"""
+    """single-set schedule: scalar load of piece c of the site the state pointer is at"""
     waves, nseq, w0, acc0, nw, tb = logits_plan(q)
-    base = LS0 + c * LOGITS_CHUNK
-    return "s_load_dwordx%d s[%d:%d], s[%d:%d], 0x%x" % (LOGITS_CHUNK, base, base + LOGITS_CHUNK - 1, tb + 2, tb + 3, c * LOGITS_CHUNK * 4)
+    at, sz = logits_chunks(q)[c]
+    base = LS0 + at
+    assert base % 4 == 0
+    return "s_load_dwordx%d s[%d:%d], s[%d:%d], 0x%x" % (sz, base, base + sz - 1, tb + 2, tb + 3, at * 4)
 
 
 def logits_state_loads(q, sset):
@@ -340,19 +370,30 @@ def logits_body(q, f64):
     waves, nseq, w0, acc0, nw, tb = logits_plan(q)
     jt = logits_jt(q)
     single = logits_single_set(q)
-    nchunks = nw // LOGITS_CHUNK
+    dbuf = LOGITS_DBUF[q]
+    chunks = logits_chunks(q) if single else []
+    nchunks = len(chunks)
+    last_first_seq = 2 * chunks[-1][0] if single else -1          # first sequence whose state word lies in the last piece
     add = "v_add_f64" if f64 else "v_pk_add_f32"
     gb, ld = tb + 4, tb + 6
     stage_at = logits_stage_sites(q)
     advance = ["s_add_u32 s%d, s%d, %%[stride]" % (tb + 2, tb + 2), "s_addc_u32 s%d, s%d, 0" % (tb + 3, tb + 3)]
+    rowsets = [w0, w0 + 2 * q] if dbuf else [w0, w0]
+
+    def row_reads(jj, rb):
+        return ["ds_read_b64 v[%d:%d], %%[vbase] offset:%d" % (rb + 2 * b, rb + 2 * b + 1, (jj * q + b) * ROWBYTES) for b in range(q)]
+
     o = ["s_mov_b32 s%d, m0" % (tb + 1),
          "s_mov_b64 s[%d:%d], %%[sptr]" % (tb + 2, tb + 3),
          "s_mov_b64 s[%d:%d], %%[gbase]" % (gb, gb + 1),
          "s_mov_b32 s%d, %%[ldst]" % ld,
          "s_mov_b32 s%d, 0" % tb]
     o += [logits_chunk_load(q, c) for c in range(nchunks - 1)] if single else logits_state_loads(q, 0)
+    if dbuf:
+        o += row_reads(0, rowsets[0])
     for jj in range(jt):
         cur = LS0 if single else LS0 + (jj % 2) * nw
+        rb = rowsets[jj % 2]
         if jj + 1 < jt and not single:
             o += advance
         for i, at in enumerate(stage_at):
@@ -366,26 +407,32 @@ def logits_body(q, f64):
                       "s_addc_u32 s%d, s%d, 0" % (gb + 1, gb + 1),
                       "s_add_u32 s%d, s%d, %d" % (ld, ld, waves * 1024),
                       ".Ldca_lg_skip%d_%%=:" % i]
-        for b in range(q):
-            o.append("ds_read_b64 v[%d:%d], %%[vbase] offset:%d" % (w0 + 2 * b, w0 + 2 * b + 1, (jj * q + b) * ROWBYTES))
-        o.append("s_waitcnt lgkmcnt(0)")
+        if not dbuf:
+            o += row_reads(jj, rb)
+        o.append("s_waitcnt lgkmcnt(0)")          # this site's rows (and the state words requested during the previous site) have landed
         if single:
             o.append(logits_chunk_load(q, nchunks - 1))
         elif jj + 1 < jt:
             o += logits_state_loads(q, (jj + 1) % 2)
         o.append("s_set_gpr_idx_on s%d, 0x2" % tb)
+        # double-buffered rows: the next site's row reads are dealt over this site's adds (DS instructions are not indexed)
+        pending = row_reads(jj + 1, rowsets[(jj + 1) % 2]) if dbuf and jj + 1 < jt else []
+        every = max(1, (nseq - 16) // max(1, len(pending)))
         for sq in range(nseq):
-            if single and sq == (nchunks - 1) * LOGITS_CHUNK * 2:
+            if single and sq == last_first_seq:
                 o.append("s_waitcnt lgkmcnt(0)")
                 if jj + 1 < jt:
                     o += advance + [logits_chunk_load(q, c) for c in range(nchunks - 1)]
+            if pending and sq % every == 0:
+                o.append(pending.pop(0))
             w = cur + sq // 2
             if sq % 2 == 0:
                 o.append("s_pack_ll_b32_b16 m0, s%d, 0" % w)
             else:
                 o.append("s_lshr_b32 m0, s%d, 16" % w)
             a = acc0 + 2 * sq
-            o.append("%s v[%d:%d], v[%d:%d], v[%d:%d]" % (add, a, a + 1, a, a + 1, w0, w0 + 1))
+            o.append("%s v[%d:%d], v[%d:%d], v[%d:%d]" % (add, a, a + 1, a, a + 1, rb, rb + 1))
+        o += pending
         o.append("s_set_gpr_idx_off")
     o.append("s_mov_b32 m0, s%d" % (tb + 1))
     return o
@@ -404,7 +451,7 @@ def logits_macro(q, f64):
     lines.append("        : %s \\" % ", ".join(ops))
     lines.append('        : [vbase] "v"(VBASE), [sptr] "s"(SPTR), [stride] "s"(STRIDE), [npc] "s"(NPC), [gbase] "s"(GBASE), '
                  '[ginc] "s"(GINC), [voff] "v"(VOFF), [ldst] "s"(LDST) \\')
-    clob = ['"memory"', '"scc"'] + ['"v%d"' % (w0 + i) for i in range(2 * q)] + ['"s%d"' % i for i in range(LS0, tb + 7)]
+    clob = ['"memory"', '"scc"'] + ['"v%d"' % (w0 + i) for i in range(acc0 - w0)] + ['"s%d"' % i for i in range(LS0, tb + 7)]
     lines.append("        : %s)" % ", ".join(clob))
     return "\n".join(lines)
 
