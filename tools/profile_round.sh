@@ -13,7 +13,7 @@ python bench.py > "$out/bench_D.json" 2> "$out/bench_D.err"
 python bench.py --workload C > "$out/bench_C.json" 2> "$out/bench_C.err"
 python bench.py --workload E > "$out/bench_E.json" 2> "$out/bench_E.err"
 cd /tmp && export TMPDIR=/tmp
-B="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-rna"
+B="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-rna --no-modes"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- $B > "$out/stats_run.log" 2>&1
 cp "$(ls -t /tmp/p_stats/*/*kernel_stats.csv | head -1)" "$out/D_kernel_stats.csv"
 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_inv -- python "$root/tools/time_mf.py" --reps 2 > /dev/null 2>&1
