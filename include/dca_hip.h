@@ -160,6 +160,20 @@ int dca_comm_info(dca_ctx* ctx, int* world, int* rank);
  *   mode 0: off.  Replaces any hook set with dca_plm_set_reduce_hook / dca_plm_set_vector_sharding. */
 int dca_plm_set_native_comm(dca_ctx* ctx, int mode);
 
+/* Column-strip decomposition of the plmDCA evaluation over the context's communicator (exchange mode 4; instead of
+ * dca_plm_configure + dca_plm_set_native_comm).  The context holds the WHOLE alignment and its weights, like a
+ * single-GPU one; rank r of `world` holds the columns of sites [L r / world, L (r+1) / world) of the coupling table and of
+ * every per-sequence array, walks all sequences for them -- logits, carry scan and scatter stay local, no halo -- and owns
+ * the packed parameters of the pairs (i, j), i < j, whose first site it holds (rank 0 the fields too), with their share
+ * of the L-BFGS vectors.  Per evaluation two grouped point-to-point exchanges cross the wires: the couplings a rank's
+ * columns need from LOWER ranks (and its sites' fields from rank 0) before the table is expanded, and the rows of the
+ * gradient table that belong to the sites of lower ranks (and the field gradients for rank 0) before the fold --
+ * (L q)^2 / 2 x (1 - 1/world) elements each way summed over the node, against 2 x (world - 1) x P for the sequence-sharded
+ * schemes (config D, 8 ranks: 2 x 193 MB against 2 x 1.5 GB), as all-to-all traffic over every xGMI link at once.
+ * This is the reference's own parallel axis (its OpenMP loop runs over sites, plmdca_numerics.cpp:490).
+ * dca_plm_get_x / _get_g / _scores are collective in this mode (every rank calls them). */
+int dca_plm_configure_strips(dca_ctx* ctx, double lambda_h, double lambda_J, int carry_mode, int chunk, int warmup);
+
 /* mfDCA pair counts summed over the shards through the communicator (instead of dca_mf_set_reduce_hook). */
 int dca_mf_set_native_comm(dca_ctx* ctx, int on);
 

@@ -87,6 +87,7 @@ def lib():
         "dca_get_weight_counts": (i, [vp, vp]),
         "dca_get_meff": (i, [vp, C.POINTER(d)]),
         "dca_plm_configure": (i, [vp, d, d, i, i, i, i, i]),
+        "dca_plm_configure_strips": (i, [vp, d, d, i, i, i]),
         "dca_plm_num_params": (sz, [i, i]),
         "dca_plm_init_x": (i, [vp]),
         "dca_plm_set_x": (i, [vp, vp, i]),
@@ -137,7 +138,7 @@ EXPORTS = ["dca_compute_weights_sharded", "dca_weights_partial_counts", "dca_set
            "dca_comm_init", "dca_comm_destroy", "dca_comm_info", "dca_plm_set_native_comm", "dca_mf_set_native_comm",
            "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_fasta_shape", "dca_read_fasta", "dca_read_fasta_alloc", "dca_host_free", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
-           "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_num_params", "dca_plm_init_x",
+           "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_configure_strips", "dca_plm_num_params", "dca_plm_init_x",
            "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_di_from_arrays", "dca_di_from_fields", "dca_plm_set_vector_sharding",
            "dca_plm_lbfgs_begin", "dca_plm_lbfgs_iterate", "dca_plm_scores", "dca_plm_di_scores",
            "dca_mf_di_scores", "dca_plm_pair_couplings", "dca_mf_fields", "dca_mf_pair_couplings",
@@ -314,6 +315,11 @@ class Context:
     def plm_configure(self, lambda_h, lambda_J, carry_mode=CARRY_CHUNKED, chunk=0, warmup=0, halo=0, add_regulariser=1):
         check(self._l.dca_plm_configure(self._h, float(lambda_h), float(lambda_J), int(carry_mode), int(chunk),
                                         int(warmup), int(halo), int(add_regulariser)))
+
+    def plm_configure_strips(self, lambda_h, lambda_J, carry_mode=CARRY_CHUNKED, chunk=0, warmup=0):
+        """Column-strip decomposition over the context's communicator (comm_init first; the context holds the whole
+        alignment): this rank takes the columns of its share of the sites.  plm_get_x / plm_get_g / plm_scores are collective."""
+        check(self._l.dca_plm_configure_strips(self._h, float(lambda_h), float(lambda_J), int(carry_mode), int(chunk), int(warmup)))
 
     def plm_init_x(self):
         check(self._l.dca_plm_init_x(self._h))

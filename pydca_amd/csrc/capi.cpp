@@ -421,6 +421,13 @@ int dca_plm_configure(dca_ctx* ctx, double lambda_h, double lambda_J, int carry_
     if (carry_mode < 0 || carry_mode > 2) return DCA_ERR_ARG;
     return ctx->plm->configure(lambda_h, lambda_J, carry_mode, chunk, warmup, halo, add_regulariser);
 }
+int dca_plm_configure_strips(dca_ctx* ctx, double lambda_h, double lambda_J, int carry_mode, int chunk, int warmup)
+{
+    CHECK_CTX(ctx);
+    DCA_TRY(need_plm(ctx));
+    if (carry_mode < 0 || carry_mode > 2) return DCA_ERR_ARG;
+    return ctx->plm->configure_strips(lambda_h, lambda_J, carry_mode, chunk, warmup);
+}
 int dca_plm_init_x(dca_ctx* ctx) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->init_x(); }
 int dca_plm_set_x(dca_ctx* ctx, const void* x, int dtype) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->set_x(x, dtype); }
 int dca_plm_get_x(dca_ctx* ctx, void* x, int dtype) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->get_x(x, dtype); }

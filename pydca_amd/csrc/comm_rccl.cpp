@@ -236,6 +236,30 @@ int dca_comm_native(dca_ctx* ctx, int op, void* buf, size_t count, int dtype, bo
     return DCA_OK;
 }
 
+// ---- grouped point-to-point transfers on ctx->stream (the column-strip decomposition's two exchanges, plm_engine.hip):
+// dca_comm_p2p_begin, any number of dca_comm_p2p_send / _recv (matched in issue order per peer, as NCCL does), dca_comm_p2p_end
+int dca_comm_p2p_begin(dca_ctx* ctx)
+{
+    if (!ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
+    RCCL_TRY(g_api.GroupStart());
+    return DCA_OK;
+}
+int dca_comm_p2p_send(dca_ctx* ctx, const void* buf, size_t count, int dtype, int peer)
+{
+    RCCL_TRY(g_api.Send(buf, count, rccl_type(dtype), peer, static_cast<RcclComm>(ctx->comm), ctx->stream));
+    return DCA_OK;
+}
+int dca_comm_p2p_recv(dca_ctx* ctx, void* buf, size_t count, int dtype, int peer)
+{
+    RCCL_TRY(g_api.Recv(buf, count, rccl_type(dtype), peer, static_cast<RcclComm>(ctx->comm), ctx->stream));
+    return DCA_OK;
+}
+int dca_comm_p2p_end(dca_ctx* ctx)
+{
+    RCCL_TRY(g_api.GroupEnd());
+    return DCA_OK;
+}
+
 // all-reduce of a vector and of one double (gradient + objective, pair counts + Meff) as one group
 int dca_comm_native_reduce(dca_ctx* ctx, void* vec, size_t count, int dtype, double* scalar_dev)
 {

@@ -129,6 +129,10 @@ int dca_comm_unique_id_impl(const char* rccl_path, void* id128);
 int dca_comm_init_impl(dca_ctx* ctx, const char* rccl_path, const void* id128, int world, int rank);
 void dca_comm_destroy_impl(dca_ctx* ctx);
 int dca_comm_info_impl(dca_ctx* ctx, int* world, int* rank);
+int dca_comm_p2p_begin(dca_ctx* ctx);
+int dca_comm_p2p_send(dca_ctx* ctx, const void* buf, size_t count, int dtype, int peer);
+int dca_comm_p2p_recv(dca_ctx* ctx, void* buf, size_t count, int dtype, int peer);
+int dca_comm_p2p_end(dca_ctx* ctx);
 int dca_comm_native(dca_ctx* ctx, int op, void* buf, size_t count, int dtype, bool direct = false);   // direct: grouped send / recv + local sum
 int dca_comm_native_reduce(dca_ctx* ctx, void* vec, size_t count, int dtype, double* scalar_dev);
 int dca_comm_native_sum_u32(dca_ctx* ctx, uint32_t* buf, size_t count);
@@ -143,6 +147,7 @@ struct PlmEngineBase {
     virtual ~PlmEngineBase() {}
     virtual int configure(double lambda_h, double lambda_J, int carry_mode, int chunk, int warmup,
                           int halo, int add_reg) = 0;
+    virtual int configure_strips(double lambda_h, double lambda_J, int carry_mode, int chunk, int warmup) = 0;   // column-strip decomposition over ctx->comm
     virtual int init_x() = 0;
     virtual int set_x(const void* x, int dtype) = 0;
     virtual int get_x(void* x, int dtype) = 0;

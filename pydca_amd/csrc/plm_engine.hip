@@ -47,14 +47,18 @@ struct PairIJ { uint16_t i, j; };
 // W[(j,b)][(i,a)] = W[(i,a)][(j,b)] = J_ij(a,b); diagonal blocks and padding stay 0.
 // One workgroup per site pair; the q x q block goes through LDS so that both
 // writes are runs of q contiguous elements.
+// Column window [s0, s1) of sites (the whole alignment unless the column-strip decomposition is on): W, S, R and G hold the
+// columns of those sites only, re-based to column 0; their rows always cover all sites.
 template <typename T>
 __global__ void plm_expand_kernel(const T* __restrict__ x, T* __restrict__ W, const PairIJ* __restrict__ pairs,
-                                  int L, int q, int Cs)
+                                  int L, int q, int Cs, int s0, int s1)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
     T* tile = reinterpret_cast<T*>(dca_smem);
     const int p = blockIdx.x;
     const int i = pairs[p].i, j = pairs[p].j;
+    const bool iIn = i >= s0 && i < s1, jIn = j >= s0 && j < s1;
+    if (!iIn && !jIn) return;                    // uniform over the workgroup
     const int q2 = q * q;
     const T* src = x + (size_t)L * q + (size_t)p * q2;
     for (int t = threadIdx.x; t < q2; t += blockDim.x) tile[t] = src[t];   // tile[a*q+b]
@@ -62,9 +66,9 @@ __global__ void plm_expand_kernel(const T* __restrict__ x, T* __restrict__ W, co
     for (int t = threadIdx.x; t < q2; t += blockDim.x) {
         const int r = t / q, c = t % q;
         // row (i,a=r), columns (j,b=c): contiguous in b
-        W[(size_t)(i * q + r) * Cs + j * q + c] = tile[r * q + c];
+        if (jIn) W[(size_t)(i * q + r) * Cs + (j - s0) * q + c] = tile[r * q + c];
         // row (j,b=r), columns (i,a=c): contiguous in a
-        W[(size_t)(j * q + r) * Cs + i * q + c] = tile[c * q + r];
+        if (iIn) W[(size_t)(j * q + r) * Cs + (i - s0) * q + c] = tile[c * q + r];
     }
 }
 
@@ -614,6 +618,23 @@ __global__ void plm_colsum_final_kernel(const double* __restrict__ parts, int nb
     colSum[c] = hi + lo;
 }
 
+// ------------------------------------------------------------------ column-strip decomposition: parameter pieces
+// pairs (j, i), j in [j0, j1) (sender's sites), i in [i0, i1) (receiver's sites, i0 >= j1), between the packed vector and
+// a dense [j][i][q*q] message
+template <typename T, bool PACK>
+__global__ void strip_pairs_copy_kernel(T* __restrict__ x, T* __restrict__ buf, int L, int q, int j0, int j1, int i0, int i1)
+{
+    const int ni = i1 - i0;
+    const int j = j0 + blockIdx.x / ni, i = i0 + blockIdx.x % ni;
+    const int q2 = q * q;
+    T* px = x + (size_t)L * q + pair_index(L, j, i) * q2;
+    T* pb = buf + (size_t)blockIdx.x * q2;
+    for (int t = threadIdx.x; t < q2; t += blockDim.x) {
+        if (PACK) pb[t] = px[t];
+        else px[t] = pb[t];
+    }
+}
+
 // ------------------------------------------------------------------ fold
 // g[J_ij(a,b)] = 2 lambda_J J + G[(j,b)][(i,a)] + G[(i,a)][(j,b)]   (plmdca_numerics.cpp:541-602:
 // the site-i and the site-j conditional both contribute), regulariser value per pair
@@ -632,22 +653,44 @@ __device__ __forceinline__ T slab_sum(const T* __restrict__ G, size_t off, size_
 // small configurations were bound by workgroup dispatch and three dependent global round trips per workgroup
 // (config C: 19 900 workgroups, 0.143 ms for 0.35 GB).
 constexpr int kFoldWaves = 4;
+constexpr int kMaxStripRanks = 64;
+// Column-strip decomposition: rank r holds the columns of sites [site0[r], site0[r+1]) and folds the pairs (i, j), i < j,
+// whose FIRST site it holds.  Site i's conditional of such a pair lies in its own G; site j's lies in the G of the rank that
+// holds j's columns, which has sent its rows of this rank's sites: recv[r'] = (this rank's L q rows) x recvCs[r'] columns.
+struct StripMap {
+    int rank = 0, world = 1, s0 = 0, s1 = 0;
+    int site0[kMaxStripRanks + 1];
+    const void* recv[kMaxStripRanks];
+    int recvCs[kMaxStripRanks];
+};
 template <typename T>
 __global__ __launch_bounds__(64 * kFoldWaves)
 void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
                            const PairIJ* __restrict__ pairs, double* __restrict__ regPart,
-                           int L, int q, int Cs, T lambdaJ, int addReg, size_t slabElems, int nsplit, int npairs)
+                           int L, int q, int Cs, T lambdaJ, int addReg, size_t slabElems, int nsplit, int pairBegin, int pairEnd,
+                           const StripMap sm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
     const int q2 = q * q;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     T* tile = reinterpret_cast<T*>(dca_smem) + (size_t)wave * ((q2 + 3) / 4 * 4);     // G[(j,b)][(i,a)] stored as tile[b*q+a]
-    const int p = blockIdx.x * kFoldWaves + wave;
-    if (p >= npairs) return;                                   // wave-uniform; no workgroup barriers below
+    const int p = pairBegin + blockIdx.x * kFoldWaves + wave;
+    if (p >= pairEnd) return;                                  // wave-uniform; no workgroup barriers below
     const int i = pairs[p].i, j = pairs[p].j;
+    const int ic = (i - sm.s0) * q;                            // site i's first column in this rank's window
     for (int t = lane; t < q2; t += 64) {
         const int b = t / q, a = t % q;
-        tile[t] = slab_sum(G, (size_t)(j * q + b) * Cs + i * q + a, slabElems, nsplit);
+        tile[t] = slab_sum(G, (size_t)(j * q + b) * Cs + ic + a, slabElems, nsplit);
+    }
+    // site j's conditional: this rank's G when it holds j's columns too, else the rows its holder has sent
+    const T* Gj = G;
+    size_t jRow = (size_t)i * q, jCs = (size_t)Cs;
+    int jc = (j - sm.s0) * q, jSplit = nsplit;
+    if (j >= sm.s1) {
+        int r = sm.rank + 1;
+        while (j >= sm.site0[r + 1]) ++r;
+        Gj = static_cast<const T*>(sm.recv[r]);
+        jRow = (size_t)(i - sm.s0) * q; jCs = (size_t)sm.recvCs[r]; jc = (j - sm.site0[r]) * q; jSplit = 1;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -661,7 +704,7 @@ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* 
         // (plmdca_numerics.cpp:570-602 in ascending site order) and of the oracle
         T gv = addReg ? (T)2 * lambdaJ * xv : (T)0;
         gv += tile[b * q + a];                                                            // G[(j,b)][(i,a)]: column of site i
-        gv += slab_sum(G, (size_t)(i * q + a) * Cs + j * q + b, slabElems, nsplit);      // G[(i,a)][(j,b)]: column of site j
+        gv += slab_sum(Gj, (jRow + a) * jCs + jc + b, slabElems, jSplit);                 // G[(i,a)][(j,b)]: column of site j
         g[base + t] = gv;
         if (addReg) dd_add(reg, regLo, (double)lambdaJ * (double)xv * (double)xv);
     }
@@ -1191,6 +1234,20 @@ struct PlmEngine : PlmEngineBase {
     PairIJ* dPairs = nullptr;
     double *dFxPart = nullptr, *dRegPart = nullptr, *dVecPart = nullptr;
     double *dColPart = nullptr, *dColSum = nullptr;      // float64 mode: column sums of R in double-double
+    // Column-strip decomposition (native_mode 4, configure_strips): this rank holds the COLUMNS of sites [cS0, cS1) of W, S, R
+    // and G (re-based to column 0; Cs is the window's stride), walks all sequences, and owns the packed parameters
+    // [oLo, oHi): the pairs (i, j) whose first site it holds (rank 0 the fields too).  Without it the window is everything.
+    bool stripRequested = false, strips = false;
+    int sWorld = 1, sRank = 0, cS0 = 0, cS1 = 0, Lloc = 0;
+    std::vector<int> siteB;                                 // site boundaries of the ranks (world + 1)
+    size_t oLo = 0, oHi = 0;
+    int pairBegin = 0, pairEnd = 0;
+    T *dGrecv = nullptr, *dXsend = nullptr, *dXrecv = nullptr;
+    std::vector<size_t> grecvOff, xsendOff, xrecvOff;      // per peer, elements
+    int strip_cs(int r) const { return (int)round_up((size_t)(siteB[r + 1] - siteB[r]) * q, 128); }
+    size_t pair_start(int s) const { return (size_t)L * (L - 1) / 2 - (size_t)(L - s) * (L - s - 1) / 2; }     // pairs whose first site is < s
+    size_t owned_lo(int r) const { return r == 0 ? 0 : (size_t)L * q + pair_start(siteB[r]) * q * q; }
+    size_t owned_hi(int r) const { return (size_t)L * q + pair_start(siteB[r + 1]) * q * q; }
     int nFxPart = 0, nRegPart = 0;
     bool lbfgs_alloc = false;
     // vector sharding (dca_plm_set_vector_sharding): this rank's slice [vlo, vlo + vn) of every P-vector;
@@ -1225,6 +1282,7 @@ struct PlmEngine : PlmEngineBase {
         dca_dev_free(dLb); dLb = nullptr; dca_dev_free(dWt); dca_dev_free(dSR); dca_dev_free(dR); dca_dev_free(dG); dca_dev_free(dw); dca_dev_free(dXL); dca_dev_free(dXT2);
         dca_dev_free(dPairs); dca_dev_free(dFxPart); dca_dev_free(dRegPart); dca_dev_free(dVecPart);
         dca_dev_free(dColPart); dca_dev_free(dColSum);
+        dca_dev_free(dGrecv); dca_dev_free(dXsend); dca_dev_free(dXrecv);
     }
     ~PlmEngine() override { freeall(); }
 
@@ -1265,12 +1323,25 @@ struct PlmEngine : PlmEngineBase {
         dWt = dSR = dR = dG = dw = nullptr; dXL = nullptr; dXT2 = nullptr; dPairs = nullptr;
         dFxPart = dRegPart = dVecPart = nullptr;
         dColPart = dColSum = nullptr;
+        dGrecv = dXsend = dXrecv = nullptr;
         lbfgs_alloc = false;
         o = decltype(o)();
 
         P = dca_plm_num_params(L, q);
         const int Lq = L * q;
-        Cs = (int)round_up(Lq, 128);
+        strips = stripRequested && ctx->comm && ctx->comm_world > 1;
+        stripRequested = false;
+        sWorld = strips ? ctx->comm_world : 1;
+        sRank = strips ? ctx->comm_rank : 0;
+        if (sWorld > kMaxStripRanks || (strips && sWorld > L)) { dca_set_error("column strips: too many ranks for %d sites", L); return DCA_ERR_ARG; }
+        if (strips && (halo || hook || comm)) { dca_set_error("column strips take the whole alignment and no hooks"); return DCA_ERR_ARG; }
+        siteB.assign(sWorld + 1, 0);
+        for (int r = 0; r <= sWorld; ++r) siteB[r] = (int)((long long)L * r / sWorld);
+        cS0 = siteB[sRank]; cS1 = siteB[sRank + 1]; Lloc = cS1 - cS0;
+        oLo = owned_lo(sRank); oHi = owned_hi(sRank);
+        pairBegin = (int)pair_start(cS0); pairEnd = (int)pair_start(cS1);
+        const int LqLoc = Lloc * q;
+        Cs = (int)round_up(LqLoc, 128);
         const int JT = jt();
         Wrows = ceil_div(L, JT) * JT * q + 128;     // + over-read margin of the last LDS-DMA tile
         scatJW = 2;     // sites per wave of the scatter kernel
@@ -1340,14 +1411,28 @@ struct PlmEngine : PlmEngineBase {
         DCA_TRY(dalloc(&dXT2, (size_t)L * NT));
         const size_t npairs = (size_t)L * (L - 1) / 2;
         DCA_TRY(dalloc(&dPairs, npairs));
-        nFxPart = ceil_div(L, 64) * ceil_div(numScanChunks, 4) * 4;
+        nFxPart = ceil_div(Lloc, 64) * ceil_div(numScanChunks, 4) * 4;
         nRegPart = (int)npairs + ceil_div(Lq, 256);
         DCA_TRY(dalloc(&dFxPart, 2 * (size_t)nFxPart));                       // (hi, lo) pairs
         DCA_TRY(dalloc(&dRegPart, 2 * (size_t)(nRegPart + kSumStageBlocks)));      // pairs; + the first-stage sums of the regulariser partials
         DCA_TRY(dalloc(&dVecPart, 2 * 27 * kVecBlocks));      // (hi, lo) pairs
+        // with column strips only the owned pairs' (and the window's field blocks') partials are written: the others must read as zero
+        HIP_TRY(hipMemsetAsync(dRegPart, 0, 2 * (size_t)(nRegPart + kSumStageBlocks) * sizeof(double), ctx->stream));
+        HIP_TRY(hipMemsetAsync(dFxPart, 0, 2 * (size_t)nFxPart * sizeof(double), ctx->stream));
         if (sizeof(T) == 8) {
             DCA_TRY(dalloc(&dColPart, 2 * (size_t)kColSumRowBlocks * Lq));
             DCA_TRY(dalloc(&dColSum, (size_t)Lq));
+        }
+        grecvOff.assign(sWorld + 1, 0); xsendOff.assign(sWorld + 1, 0); xrecvOff.assign(sWorld + 1, 0);
+        if (strips) {
+            const size_t q2 = (size_t)q * q;
+            size_t gtot = 0, stot = 0, rtot = 0;
+            for (int r = 0; r < sWorld; ++r) {
+                grecvOff[r] = gtot; xsendOff[r] = stot; xrecvOff[r] = rtot;
+                if (r > sRank) { gtot += (size_t)LqLoc * strip_cs(r); stot += (size_t)Lloc * (siteB[r + 1] - siteB[r]) * q2; }
+                if (r < sRank) rtot += (size_t)(siteB[r + 1] - siteB[r]) * Lloc * q2;
+            }
+            DCA_TRY(dalloc(&dGrecv, gtot)); DCA_TRY(dalloc(&dXsend, stot)); DCA_TRY(dalloc(&dXrecv, rtot));
         }
 
         HIP_TRY(hipMemsetAsync(dx, 0, (P + kVecPad) * sizeof(T), ctx->stream));
@@ -1355,7 +1440,13 @@ struct PlmEngine : PlmEngineBase {
         // the exchange scheme (reduce hook, vector-sharding hook, native mode) survives a re-configuration -- a context whose
         // weights changed must be configured again and would otherwise silently fall back to unreduced local sums
         vlo = 0; vn = P; Ppad = P;
-        if (native_mode >= 2) {
+        if (strips) {
+            native_mode = 4;
+            vlo = oLo; vn = oHi - oLo;
+        } else if (native_mode == 4) {
+            native_mode = 0;
+        }
+        if (native_mode == 2 || native_mode == 3) {
             if (!ctx->comm) native_mode = 0;
             else DCA_TRY(set_slices(ctx->comm_rank, ctx->comm_world));
         } else if (comm) {
@@ -1399,6 +1490,17 @@ struct PlmEngine : PlmEngineBase {
         }
         configured = true;
         return DCA_OK;
+    }
+
+    int configure_strips(double lh, double lJ, int cmode, int chunk_, int warm_) override
+    {
+        if (!ctx->comm) { dca_set_error("column strips need a communicator: dca_comm_init first"); return DCA_ERR_STATE; }
+        if (o.begun && !o.finished) { dca_set_error("the decomposition cannot change during an optimisation"); return DCA_ERR_STATE; }
+        hook = nullptr; hook_user = nullptr; comm = nullptr; comm_user = nullptr; comm_rank = comm_world = 0;
+        stripRequested = true;
+        const int rc = configure(lh, lJ, cmode, chunk_, warm_, 0, 1);
+        stripRequested = false;
+        return rc;
     }
 
     // PlmDCA::initFieldsAndCouplings (plmdca_numerics.cpp:207-249) in T, host side
@@ -1455,6 +1557,7 @@ struct PlmEngine : PlmEngineBase {
     int get_x(void* x, int dtype) override
     {
         if (!configured) return DCA_ERR_STATE;
+        if (native_mode == 4) DCA_TRY(strip_allgather(dx));       // collective, like get_g: every rank calls it
         if (dtype == DCA_F32) return download(dx, static_cast<float*>(x));
         if (dtype == DCA_F64) return download(dx, static_cast<double*>(x));
         return DCA_ERR_ARG;
@@ -1476,7 +1579,7 @@ struct PlmEngine : PlmEngineBase {
         {
             ScopedKernelClock kc(ctx, "plm_expand");
             hipLaunchKernelGGL(plm_expand_kernel<T>, dim3((unsigned)npairs), dim3(256), (size_t)q * q * sizeof(T), st,
-                               dx, dWt, dPairs, L, q, Cs);
+                               dx, dWt, dPairs, L, q, Cs, cS0, cS1);
         }
         DCA_ROUND_STAGE(1, dWt, (size_t)Wrows * Cs);
         {
@@ -1492,13 +1595,14 @@ struct PlmEngine : PlmEngineBase {
         }
         DCA_ROUND_STAGE(2, dSR, (size_t)N * Cs);
         {
-            dim3 grid(ceil_div(L, 64), ceil_div(numScanChunks, 4));
+            dim3 grid(ceil_div(Lloc, 64), ceil_div(numScanChunks, 4));
             ScopedKernelClock kc(ctx, "plm_softmax");
             constexpr int softNP = (64 * Q * (int)sizeof(T) + 1023) / 1024;
             const size_t softLds = (size_t)4 * 2 * softNP * 1024;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plm_softmax_kernel<T, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)softLds));
-            hipLaunchKernelGGL((plm_softmax_kernel<T, Q>), grid, dim3(256), softLds, st, dSR, dR, dx, ctx->dX, dw, dFxPart,
-                               N, L, Ls, Cs, halo, chunk, warm, carry_mode != DCA_CARRY_EXACT ? 1 : 0, numScanChunks);
+            // the window's sites: their fields, their alignment column, their columns of S / R
+            hipLaunchKernelGGL((plm_softmax_kernel<T, Q>), grid, dim3(256), softLds, st, dSR, dR, dx + (size_t)cS0 * q, ctx->dX + cS0, dw, dFxPart,
+                               N, Lloc, Ls, Cs, halo, chunk, warm, carry_mode != DCA_CARRY_EXACT ? 1 : 0, numScanChunks);
         }
         DCA_ROUND_STAGE(4, dR, (size_t)N * Cs);
         {
@@ -1531,20 +1635,28 @@ struct PlmEngine : PlmEngineBase {
         DCA_ROUND_STAGE(8, dG, (size_t)std::max(scatSplit, scatRemSplit) * Grows * Cs);
         {
             ScopedKernelClock kc(ctx, "plm_fold");
+            const int LqLoc = Lloc * q;
             int foldSlabs = scatSplit;
-            if (scatSplit > 2) {     // more than two slabs: one streaming pass is cheaper than strided reads in the fold
+            if (scatSplit > 2 || (strips && scatSplit > 1)) {     // more than two slabs: one streaming pass is cheaper than strided reads in the fold (and rows that travel are sent summed)
                 hipLaunchKernelGGL(plm_sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, st, dG, (size_t)Grows * Cs, scatSplit);
                 foldSlabs = 1;
             }
-            const size_t lds = (size_t)kFoldWaves * ((q * q + 3) / 4 * 4) * sizeof(T);
-            hipLaunchKernelGGL(plm_fold_pairs_kernel<T>, dim3((unsigned)ceil_div((int)npairs, kFoldWaves)), dim3(64 * kFoldWaves), lds, st, dx, dG, dg, dPairs,
-                               dRegPart, L, q, Cs, (T)lambda_J, add_reg, (size_t)Grows * Cs, foldSlabs, (int)npairs);
             if (dColSum) {
-                hipLaunchKernelGGL(plm_colsum_parts_kernel<T>, dim3(ceil_div(Lq, 64), kColSumRowBlocks), dim3(256), 0, st, dR, N, Cs, Lq, dColPart);
-                hipLaunchKernelGGL(plm_colsum_final_kernel, dim3(ceil_div(Lq, 256)), dim3(256), 0, st, dColPart, kColSumRowBlocks, Lq, dColSum);
+                hipLaunchKernelGGL(plm_colsum_parts_kernel<T>, dim3(ceil_div(LqLoc, 64), kColSumRowBlocks), dim3(256), 0, st, dR, N, Cs, LqLoc, dColPart);
+                hipLaunchKernelGGL(plm_colsum_final_kernel, dim3(ceil_div(LqLoc, 256)), dim3(256), 0, st, dColPart, kColSumRowBlocks, LqLoc, dColSum);
             }
-            hipLaunchKernelGGL(plm_fold_fields_kernel<T>, dim3(ceil_div(Lq, 256)), dim3(256), 0, st, dx, dG, dg,
-                               dRegPart + 2 * npairs, Lq, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, foldSlabs, dColSum);
+            hipLaunchKernelGGL(plm_fold_fields_kernel<T>, dim3(ceil_div(LqLoc, 256)), dim3(256), 0, st, dx + (size_t)cS0 * q, dG, dg + (size_t)cS0 * q,
+                               dRegPart + 2 * npairs, LqLoc, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, foldSlabs, dColSum);
+            StripMap sm;
+            sm.rank = sRank; sm.world = sWorld; sm.s0 = cS0; sm.s1 = cS1;
+            for (int r = 0; r <= sWorld; ++r) sm.site0[r] = siteB[r];
+            for (int r = 0; r < sWorld; ++r) { sm.recv[r] = strips && r > sRank ? dGrecv + grecvOff[r] : nullptr; sm.recvCs[r] = strips ? strip_cs(r) : 0; }
+            if (strips) DCA_TRY(exchange_g());
+            const size_t lds = (size_t)kFoldWaves * ((q * q + 3) / 4 * 4) * sizeof(T);
+            const int nOwned = pairEnd - pairBegin;
+            if (nOwned > 0)
+                hipLaunchKernelGGL(plm_fold_pairs_kernel<T>, dim3((unsigned)ceil_div(nOwned, kFoldWaves)), dim3(64 * kFoldWaves), lds, st, dx, dG, dg, dPairs,
+                                   dRegPart, L, q, Cs, (T)lambda_J, add_reg, (size_t)Grows * Cs, foldSlabs, pairBegin, pairEnd, sm);
         }
         DCA_ROUND_STAGE(16, dg, P);
         // fx = regulariser + data term  -> ctx->dScal[0]
@@ -1562,7 +1674,7 @@ struct PlmEngine : PlmEngineBase {
         int rc = (q == 21) ? launch_eval<21>() : launch_eval<5>();
         if (rc != DCA_OK) return rc;
         o.evals += 1;
-        if (comm || native_mode >= 2) {
+        if (comm || native_mode == 2 || native_mode == 3) {
             // sharded vectors: sum the shards' gradients, keep this rank's slice; fx is summed with the
             // scalars of the caller (eval_scalars / gradient)
             DCA_TRY(do_comm(DCA_COMM_REDUCE_SCATTER, dg, Ppad, (int)sizeof(T) * 8, "reduce-scatter"));
@@ -1583,7 +1695,7 @@ struct PlmEngine : PlmEngineBase {
     // or through the caller's hook (the stream is drained first: the hook works outside it)
     int do_comm(int op, void* buf, size_t count, int dtype, const char* what)
     {
-        if (native_mode >= 2) return dca_comm_native(ctx, op, buf, count, dtype, native_mode == 3);
+        if (native_mode >= 2) return dca_comm_native(ctx, op, buf, count, dtype, native_mode == 3);      // mode 4: only the scalar all-reduce comes here
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (comm(comm_user, op, buf, count, dtype) != 0) { dca_set_error("comm hook failed (%s)", what); return DCA_ERR_ARG; }
         return DCA_OK;
@@ -1597,7 +1709,77 @@ struct PlmEngine : PlmEngineBase {
     int gather_vector(T* v)
     {
         if (!comm && native_mode < 2) return DCA_OK;
+        if (native_mode == 4) return strip_allgather(v);
         return do_comm(DCA_COMM_ALL_GATHER, v, Ppad, (int)sizeof(T) * 8, "all-gather");
+    }
+    // after a step: every rank needs x where its evaluation reads it
+    int publish_x()
+    {
+        if (native_mode == 4) return exchange_x();
+        return gather_vector(dx);
+    }
+
+    // ---------------- column-strip decomposition: the two exchanges of an evaluation and the all-gather of the API calls
+    // (grouped point-to-point transfers on the context's stream; no reference counterpart)
+    // A, before expand: the parameters a rank's columns need but another rank owns -- the pairs (j, i) with j on a LOWER
+    // rank travel up, packed densely; the fields of its sites come from rank 0.
+    int exchange_x()
+    {
+        const int dt = (int)sizeof(T) * 8;
+        const size_t q2 = (size_t)q * q;
+        for (int r = sRank + 1; r < sWorld; ++r) {
+            const int ni = siteB[r + 1] - siteB[r];
+            hipLaunchKernelGGL((strip_pairs_copy_kernel<T, true>), dim3((unsigned)(Lloc * ni)), dim3(64), 0, ctx->stream, dx, dXsend + xsendOff[r], L, q, cS0, cS1, siteB[r], siteB[r + 1]);
+        }
+        DCA_TRY(dca_comm_p2p_begin(ctx));
+        int rc = DCA_OK;
+        if (sRank == 0) { for (int r = 1; r < sWorld && rc == DCA_OK; ++r) rc = dca_comm_p2p_send(ctx, dx + (size_t)siteB[r] * q, (size_t)(siteB[r + 1] - siteB[r]) * q, dt, r); }
+        else rc = dca_comm_p2p_recv(ctx, dx + (size_t)cS0 * q, (size_t)Lloc * q, dt, 0);
+        for (int r = sRank + 1; r < sWorld && rc == DCA_OK; ++r) rc = dca_comm_p2p_send(ctx, dXsend + xsendOff[r], (size_t)Lloc * (siteB[r + 1] - siteB[r]) * q2, dt, r);
+        for (int r = 0; r < sRank && rc == DCA_OK; ++r) rc = dca_comm_p2p_recv(ctx, dXrecv + xrecvOff[r], (size_t)(siteB[r + 1] - siteB[r]) * Lloc * q2, dt, r);
+        const int rc2 = dca_comm_p2p_end(ctx);
+        if (rc != DCA_OK) return rc;
+        DCA_TRY(rc2);
+        for (int r = 0; r < sRank; ++r) {
+            const int nj = siteB[r + 1] - siteB[r];
+            hipLaunchKernelGGL((strip_pairs_copy_kernel<T, false>), dim3((unsigned)(nj * Lloc)), dim3(64), 0, ctx->stream, dx, dXrecv + xrecvOff[r], L, q, siteB[r], siteB[r + 1], cS0, cS1);
+        }
+        HIP_TRY(hipGetLastError());
+        return DCA_OK;
+    }
+    // B, between scatter and fold: the rows of G that belong to the sites of a LOWER rank travel down (whole rows of this
+    // rank's window: one contiguous block per peer), the field gradients of this rank's sites go to rank 0.
+    int exchange_g()
+    {
+        const int dt = (int)sizeof(T) * 8;
+        DCA_TRY(dca_comm_p2p_begin(ctx));
+        int rc = DCA_OK;
+        for (int r = 0; r < sRank && rc == DCA_OK; ++r)
+            rc = dca_comm_p2p_send(ctx, dG + (size_t)siteB[r] * q * Cs, (size_t)(siteB[r + 1] - siteB[r]) * q * Cs, dt, r);
+        for (int r = sRank + 1; r < sWorld && rc == DCA_OK; ++r)
+            rc = dca_comm_p2p_recv(ctx, dGrecv + grecvOff[r], (size_t)Lloc * q * strip_cs(r), dt, r);
+        if (rc == DCA_OK) {
+            if (sRank > 0) rc = dca_comm_p2p_send(ctx, dg + (size_t)cS0 * q, (size_t)Lloc * q, dt, 0);
+            else for (int r = 1; r < sWorld && rc == DCA_OK; ++r) rc = dca_comm_p2p_recv(ctx, dg + (size_t)siteB[r] * q, (size_t)(siteB[r + 1] - siteB[r]) * q, dt, r);
+        }
+        const int rc2 = dca_comm_p2p_end(ctx);
+        if (rc != DCA_OK) return rc;
+        return rc2;
+    }
+    // every rank's owned range of a P-vector to every other rank, in place (get_x / get_g / scores: not on the hot path)
+    int strip_allgather(T* v)
+    {
+        const int dt = (int)sizeof(T) * 8;
+        DCA_TRY(dca_comm_p2p_begin(ctx));
+        int rc = DCA_OK;
+        for (int k = 1; k < sWorld && rc == DCA_OK; ++k) {
+            const int to = (sRank + k) % sWorld, from = (sRank - k + sWorld) % sWorld;
+            rc = dca_comm_p2p_send(ctx, v + oLo, oHi - oLo, dt, to);
+            if (rc == DCA_OK) rc = dca_comm_p2p_recv(ctx, v + owned_lo(from), owned_hi(from) - owned_lo(from), dt, from);
+        }
+        const int rc2 = dca_comm_p2p_end(ctx);
+        if (rc != DCA_OK) return rc;
+        return rc2;
     }
     int set_vector_sharding(int rank, int world, dca_comm_hook h, void* user) override
     {
@@ -1625,7 +1807,13 @@ struct PlmEngine : PlmEngineBase {
         if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
         if (o.begun && !o.finished) { dca_set_error("the exchange scheme cannot change during an optimisation"); return DCA_ERR_STATE; }
         if (mode != 0 && !ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
+        if (mode == 4) { dca_set_error("the column-strip decomposition is set up by dca_plm_configure_strips"); return DCA_ERR_ARG; }
         if (mode < 0 || mode > 3) return DCA_ERR_ARG;
+        if (strips) {       // the arrays are cut for a column window: another scheme (or none) needs a new configuration
+            if (mode != 0) { dca_set_error("configured for column strips: dca_plm_configure again first"); return DCA_ERR_STATE; }
+            configured = false; strips = false; native_mode = 0; o = decltype(o)();
+            return DCA_OK;
+        }
         if (mode >= 2) DCA_TRY(set_slices(ctx->comm_rank, ctx->comm_world));      // validate before anything is dropped
         else { vlo = 0; vn = P; Ppad = P; }
         comm = nullptr; comm_user = nullptr; comm_rank = comm_world = 0;
@@ -1744,7 +1932,7 @@ struct PlmEngine : PlmEngineBase {
                 *stp = bx.st;
             v_step(dx, dxp, *stp, dd);
             DCA_ROUND_STAGE(32, dx, P);
-            if ((*rc_hip = gather_vector(dx))) return 0;      // sharded vectors: every rank needs the whole x
+            if ((*rc_hip = publish_x())) return 0;            // sharded vectors: every rank needs the x its evaluation reads
             if ((*rc_hip = evaluate_async())) return 0;
             double dg_;
             if ((*rc_hip = eval_scalars(f, &dg_, xx, gg))) return 0;
@@ -1849,6 +2037,7 @@ struct PlmEngine : PlmEngineBase {
     int scores(int apc, double* out) override
     {
         if (!configured) return DCA_ERR_STATE;
+        if (native_mode == 4) DCA_TRY(strip_allgather(dx));
         const size_t npairs = (size_t)L * (L - 1) / 2;
         double* dOut = nullptr;
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));

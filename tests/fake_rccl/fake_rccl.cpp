@@ -8,6 +8,7 @@
 
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -113,7 +114,7 @@ struct P2P { bool send; void* buf; size_t bytes; int peer; Comm* comm; hipStream
 thread_local int t_depth = 0;
 thread_local std::vector<P2P> t_ops;
 std::mutex g_mail_mu;
-std::map<std::pair<Group*, std::pair<int, int>>, std::vector<char>> g_mail;
+std::map<std::pair<Group*, std::pair<int, int>>, std::deque<std::vector<char>>> g_mail;      // FIFO per (from, to): several messages to one peer in a group match in issue order
 }  // namespace
 
 int ncclGroupStart() { ++t_depth; return 0; }
@@ -129,7 +130,7 @@ int ncclGroupEnd()
         std::vector<char> box(o.bytes);
         if (hipMemcpy(box.data(), o.buf, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
         std::lock_guard<std::mutex> lk(g_mail_mu);
-        g_mail[{g, {o.comm->rank, o.peer}}].swap(box);
+        g_mail[{g, {o.comm->rank, o.peer}}].push_back(std::move(box));
     }
     barrier(g);
     int rc = 0;
@@ -139,9 +140,9 @@ int ncclGroupEnd()
         {
             std::lock_guard<std::mutex> lk(g_mail_mu);
             auto it = g_mail.find({g, {o.peer, o.comm->rank}});
-            if (it == g_mail.end() || it->second.size() != o.bytes) { rc = 4; continue; }
-            box.swap(it->second);
-            g_mail.erase(it);
+            if (it == g_mail.end() || it->second.empty() || it->second.front().size() != o.bytes) { rc = 4; continue; }
+            box.swap(it->second.front());
+            it->second.pop_front();
         }
         if (hipMemcpy(o.buf, box.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) rc = 1;
     }

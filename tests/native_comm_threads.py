@@ -41,7 +41,7 @@ def main():
     M = golden("mf_toy_protein")
     XM = (M["X"] - 1).astype(np.uint8)
 
-    uid_w, uid_p1, uid_p2, uid_p3, uid_m = (_lib.comm_unique_id(FAKE) for _ in range(5))
+    uid_w, uid_p1, uid_p2, uid_p3, uid_m, uid_p4 = (_lib.comm_unique_id(FAKE) for _ in range(6))
     out = [None] * world
 
     def run(rank):
@@ -68,6 +68,25 @@ def main():
                     fx_err=abs(fx - fx_ref) / abs(fx_ref), g_err=float(np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref)),
                     status=[st.status, st.iterations, st.evaluations], fx_end_err=abs(st.fx - st_ref.fx) / abs(st_ref.fx),
                     x_err=float(np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref)), x_sum=float(x.sum()))
+                s.close()
+            # mode 4, the column-strip decomposition: every rank holds the WHOLE alignment and the columns of its sites
+            if world > 1:
+                s = _lib.Context(0, _lib.DCA_F64)
+                s.set_msa(X, q)
+                s.set_weights(w)
+                s.comm_init(uid_p4, world, rank, FAKE)
+                s.plm_configure_strips(1.0, 20.0)
+                s.plm_set_x(x0)
+                fx = s.plm_gradient()
+                g = s.plm_get_g(np.float64)
+                s.plm_lbfgs_begin(iters)
+                st = s.plm_lbfgs_iterate(iters)
+                x = s.plm_get_x(np.float64)
+                sc = s.plm_scores(True)
+                res["mode4"] = dict(
+                    fx_err=abs(fx - fx_ref) / abs(fx_ref), g_err=float(np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref)),
+                    status=[st.status, st.iterations, st.evaluations], fx_end_err=abs(st.fx - st_ref.fx) / abs(st_ref.fx),
+                    x_err=float(np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref)), x_sum=float(x.sum()), score_sum=float(sc.sum()))
                 s.close()
             # mfDCA pair counts summed through the communicator
             m = parallel.make_sharded_mf_context(_lib, XM, int(M["q"]), M["w"], rank, world, 0)

@@ -586,6 +586,14 @@ def test_native_exchange_path_with_several_ranks(world):
             assert m["status"] == res["reference_status"], m
             assert m["fx_end_err"] <= 1e-9 and m["x_err"] < 1e-7, m
             assert m["x_sum"] == res["ranks"][0][mode]["x_sum"]           # every rank ends with the same x
+        # mode 4, the column-strip decomposition (every rank the whole alignment and the columns of its sites; two grouped
+        # point-to-point exchanges per evaluation): the same sums in the same order as the unsharded run, so it follows
+        # it even more closely than the sequence-sharded schemes
+        m = r["mode4"]
+        assert m["fx_err"] <= 1e-13 and m["g_err"] < 1e-13, m
+        assert m["status"] == res["reference_status"], m
+        assert m["fx_end_err"] <= 1e-9 and m["x_err"] < 1e-7, m
+        assert m["x_sum"] == res["ranks"][0]["mode4"]["x_sum"] and m["score_sum"] == res["ranks"][0]["mode4"]["score_sum"]
         assert r["mf_err"] < 1e-9
         assert r["mf_stale_counts_dropped"] and r["mf_fi_err"] < 1e-13, r      # reduction switched on after a query; re-weighted afterwards
 
