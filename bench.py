@@ -421,40 +421,81 @@ def main():
             # optimiser vectors (2), the same as a direct exchange of grouped send / recv (3) -- and keep the fastest.
             # DCA_BENCH_SCHEME=1|2|3 forces one; DCA_BENCH_ALLREDUCE / DCA_BENCH_VECTORS keep their meaning.
             forced = os.environ.get("DCA_BENCH_SCHEME")
+            x0 = parallel.initial_x(X, w32, q, np.float32)
+            strip_ctx = None
+
+            def strips_up():
+                """mode 4: a context with the WHOLE alignment whose rank takes the columns of its share of the sites"""
+                c = _lib.Context(local_rank, _lib.DCA_F64 if args.precision == 64 else _lib.DCA_F32)
+                c.set_msa(X, q)
+                c.set_weight_counts(counts)
+                if not native_comm_up(c):
+                    c.close()
+                    return None
+                c.plm_configure_strips(lh, lJ, _lib.CARRY_CHUNKED)
+                return c
+
+            def time_mode(c, mode):
+                """three L-BFGS iterations (after one untimed) under an exchange scheme, max over the ranks, ms per iteration"""
+                ok = 1
+                try:
+                    if mode != 4:
+                        c.plm_set_native_comm(mode)
+                    c.plm_set_x(x0)
+                    c.plm_lbfgs_begin(1000)
+                    c.plm_lbfgs_iterate(1)                                   # warm: RCCL sets its channels up on first use
+                except Exception as exc:                                     # pragma: no cover (needs a multi-GPU node)
+                    print("rank %d: exchange mode %d unavailable (%r)" % (rank, mode, exc), file=sys.stderr)
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)                  # a mode is timed only if it came up on every rank
+                if not bool(flag.item()):
+                    return None
+                barrier()
+                t1 = time.perf_counter()
+                c.plm_lbfgs_iterate(3)
+                barrier()
+                tm = torch.tensor([(time.perf_counter() - t1) / 3.0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                return float(tm.item()) * 1e3
+
             if forced:
                 chosen, timings = int(forced), {}
             elif os.environ.get("DCA_BENCH_ALLREDUCE") == "1":
                 chosen, timings = 1, {}
             else:
+                # Which scheme the wires like cannot be known before it runs on them (DESIGN.md section 6): three iterations of
+                # each are timed once on this node -- all-reduce of g (1), RCCL reduce-scatter + all-gather with sharded
+                # optimiser vectors (2), the same as a direct exchange of grouped send / recv (3), the column-strip
+                # decomposition (4: a fifth of the bytes, all-to-all) -- and the fastest runs the benchmark.
                 timings = {}
                 for mode in (1, 2, 3):
-                    ok = 1
-                    try:
-                        ctx.plm_set_native_comm(mode)
-                        ctx.plm_gradient()                               # warm: RCCL sets its channels up on first use
-                    except Exception as exc:                             # pragma: no cover (needs a multi-GPU node)
-                        print("rank %d: exchange mode %d unavailable (%r)" % (rank, mode, exc), file=sys.stderr)
-                        ok = 0
-                    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # a mode is timed only if it came up on every rank
-                    if not bool(flag.item()):
-                        continue
-                    barrier()
-                    t1 = time.perf_counter()
-                    for _ in range(3):
-                        ctx.plm_gradient()
-                    barrier()
-                    tm = torch.tensor([(time.perf_counter() - t1) / 3.0], dtype=torch.float64, device="cuda")
-                    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                    timings[mode] = float(tm.item()) * 1e3
-                # the sharded schemes also divide the optimiser's vector work by the world size: an evaluation-only timing
-                # is biased towards mode 1 by about that much, so mode 1 has to win by more than the vector work it keeps
-                chosen = 2 if not timings else min(timings, key=lambda m: timings[m] + (0.0 if m != 1 else 1.3 * (ctx.num_params() / 55e6) * (1.0 - 1.0 / world)))
-            ctx.plm_set_native_comm(chosen)
+                    t = time_mode(ctx, mode)
+                    if t is not None:
+                        timings[mode] = t
+                strip_ctx = strips_up()
+                if strip_ctx is not None:
+                    t = time_mode(strip_ctx, 4)
+                    if t is not None:
+                        timings[4] = t
+                chosen = 2 if not timings else min(timings, key=lambda m: timings[m])
+            if chosen == 4:
+                if strip_ctx is None:
+                    strip_ctx = strips_up()
+                if strip_ctx is None:
+                    raise SystemExit("bench.py: exchange mode 4 asked for but the communicator did not come up")
+                ctx.close()
+                ctx = strip_ctx
+            else:
+                if strip_ctx is not None:
+                    strip_ctx.close()
+                ctx.plm_set_native_comm(chosen)
+            ctx.plm_set_x(x0)
             allreduce = chosen == 1
-            comm_selection = {"evaluation_plus_exchange_ms": timings, "chosen_mode": chosen, "rccl_ranks": ctx.comm_info()[0],
-                              "modes": {"1": "all-reduce(g)", "2": "RCCL reduce-scatter(g) + all-gather(x), sharded vectors",
-                                        "3": "direct exchange (grouped send / recv + rank-ordered local sum), sharded vectors"}}
+            comm_selection = {"ms_per_iteration": timings, "chosen_mode": chosen, "rccl_ranks": ctx.comm_info()[0],
+                              "modes": {"1": "sequences sharded, all-reduce(g)", "2": "sequences sharded, RCCL reduce-scatter(g) + all-gather(x), sharded vectors",
+                                        "3": "sequences sharded, direct exchange (grouped send / recv + rank-ordered local sum), sharded vectors",
+                                        "4": "column strips: every rank all sequences x the columns of its sites; couplings up / gradient-table rows down by grouped send / recv"}}
         elif allreduce:
             hook = parallel.TorchAllReduceHook(local_rank)
             ctx.plm_set_reduce_hook(hook)
@@ -463,9 +504,11 @@ def main():
             ctx.plm_set_vector_sharding(rank, world, hook)
         scheme = ("sequences sharded x%d, all-reduce(g) over RCCL" % world if allreduce else
                   "sequences sharded x%d, reduce-scatter(g) + all-gather(x) over RCCL, L-BFGS vectors sharded x%d" % (world, world))
+        if comm_selection is not None and comm_selection["chosen_mode"] == 4:
+            scheme = "column strips x%d (sites sharded, all sequences on every rank), point-to-point exchange of couplings and gradient-table rows over RCCL" % world
         scheme += ", native collectives on the library's stream" if native else ", torch.distributed hooks"
         if comm_selection is not None:
-            scheme += "; exchange mode %d of 3 picked by a start-up timing, RCCL communicator of %d ranks" % (comm_selection["chosen_mode"], world)
+            scheme += "; exchange mode %d of 4 picked by a start-up timing, RCCL communicator of %d ranks" % (comm_selection["chosen_mode"], world)
     t_setup = time.perf_counter() - t0
 
     # ---- warm-up iterations, then exactly K timed iterations
@@ -498,6 +541,8 @@ def main():
     Lq = L * q
     P = ctx.num_params()
     n_local = ctx.N
+    if comm_selection is not None and comm_selection["chosen_mode"] == 4:
+        n_local = ctx.N / float(world)            # column strips: all sequences x 1/world of the columns = the same share of the adds
     esz = 4 if args.precision == 32 else 8
     # algorithmic HBM bytes per launch: compulsory reads + writes of each kernel
     alg_bytes = {
