@@ -1237,7 +1237,7 @@ struct PlmEngine : PlmEngineBase {
     // Column-strip decomposition (native_mode 4, configure_strips): this rank holds the COLUMNS of sites [cS0, cS1) of W, S, R
     // and G (re-based to column 0; Cs is the window's stride), walks all sequences, and owns the packed parameters
     // [oLo, oHi): the pairs (i, j) whose first site it holds (rank 0 the fields too).  Without it the window is everything.
-    bool stripRequested = false, strips = false;
+    bool stripRequested = false, strips = false, stripEmulate = false;
     int sWorld = 1, sRank = 0, cS0 = 0, cS1 = 0, Lloc = 0;
     std::vector<int> siteB;                                 // site boundaries of the ranks (world + 1)
     size_t oLo = 0, oHi = 0;
@@ -1299,14 +1299,37 @@ struct PlmEngine : PlmEngineBase {
         if (halo_ < 0 || halo_ >= N) { dca_set_error("halo out of range"); return DCA_ERR_ARG; }
         if (L > 65535) { dca_set_error("L too large"); return DCA_ERR_ARG; }
         lambda_h = lh; lambda_J = lJ; carry_mode = cmode; halo = halo_; add_reg = add_reg_;
+        // the column window first: the scan's chunking below depends on how many sites this rank walks
+        strips = stripRequested && ctx->comm && ctx->comm_world > 1;
+        stripRequested = false;
+        sWorld = strips ? ctx->comm_world : 1;
+        sRank = strips ? ctx->comm_rank : 0;
+#ifdef DCA_ROUND_ABLATE
+        // ANALYSIS BUILD ONLY: DCA_STRIP_EMULATE=rank,world cuts the column window of that rank WITHOUT a communicator and
+        // skips the two exchanges -- the evaluation's results are then wrong, its kernel times are those of one rank of the
+        // column-strip decomposition (tools/time_eval.py under the analysis library)
+        stripEmulate = false;
+        if (const char* e = getenv("DCA_STRIP_EMULATE")) {
+            int er = 0, ew = 1;
+            if (sscanf(e, "%d,%d", &er, &ew) == 2 && ew > 1 && er >= 0 && er < ew) { strips = true; stripEmulate = true; sRank = er; sWorld = ew; }
+        }
+#endif
+        if (sWorld > kMaxStripRanks || (strips && sWorld > L)) { dca_set_error("column strips: too many ranks for %d sites", L); return DCA_ERR_ARG; }
+        if (strips && (halo || hook || comm)) { dca_set_error("column strips take the whole alignment and no hooks"); return DCA_ERR_ARG; }
+        siteB.assign(sWorld + 1, 0);
+        for (int r = 0; r <= sWorld; ++r) siteB[r] = (int)((long long)L * r / sWorld);
+        cS0 = siteB[sRank]; cS1 = siteB[sRank + 1]; Lloc = cS1 - cS0;
+        oLo = owned_lo(sRank); oHi = owned_hi(sRank);
+        pairBegin = (int)pair_start(cS0); pairEnd = (int)pair_start(cS1);
+
         // scan chunk: 256 sequences (15 % warm-up rows instead of 31 %) when that still leaves at least one
         // chunk-wave per SIMD and the rows are long (q = 21; config D: 1.20 -> 0.99 ms; with q = 5 the chain
         // latency dominates and 128 stays faster), else 128
-        chunk = chunk_ > 0 ? chunk_ : ((q >= 16 && (long long)ceil_div(N - halo_, 256) * ceil_div(L, 64) >= 1024) ? 256 : 128);
+        chunk = chunk_ > 0 ? chunk_ : ((q >= 16 && (long long)ceil_div(N - halo_, 256) * ceil_div(Lloc, 64) >= 1024) ? 256 : 128);
         // small alignments: the scan is a chain of one step per sequence and wave, so shorter chunks (more waves, more
         // warm-up rows of a small array) until there is about one chunk-wave per SIMD: config C 0.30 -> 0.16 ms with 32
         if (chunk_ <= 0)
-            while (chunk > 32 && (long long)ceil_div(N - halo_, chunk) * ceil_div(L, 64) < 1024) chunk /= 2;
+            while (chunk > 32 && (long long)ceil_div(N - halo_, chunk) * ceil_div(Lloc, 64) < 1024) chunk /= 2;
         // warm-up steps of the chunk-parallel scan: 2^-40 of start-up error is far below float rounding; the float64 mode is
         // the parity mode and takes 80, with which the chunked scan is BIT-identical to the serial chain (the start-up
         // error has dropped below the last place of every carried probability; 100 iterations at configs D and E end in the
@@ -1329,17 +1352,6 @@ struct PlmEngine : PlmEngineBase {
 
         P = dca_plm_num_params(L, q);
         const int Lq = L * q;
-        strips = stripRequested && ctx->comm && ctx->comm_world > 1;
-        stripRequested = false;
-        sWorld = strips ? ctx->comm_world : 1;
-        sRank = strips ? ctx->comm_rank : 0;
-        if (sWorld > kMaxStripRanks || (strips && sWorld > L)) { dca_set_error("column strips: too many ranks for %d sites", L); return DCA_ERR_ARG; }
-        if (strips && (halo || hook || comm)) { dca_set_error("column strips take the whole alignment and no hooks"); return DCA_ERR_ARG; }
-        siteB.assign(sWorld + 1, 0);
-        for (int r = 0; r <= sWorld; ++r) siteB[r] = (int)((long long)L * r / sWorld);
-        cS0 = siteB[sRank]; cS1 = siteB[sRank + 1]; Lloc = cS1 - cS0;
-        oLo = owned_lo(sRank); oHi = owned_hi(sRank);
-        pairBegin = (int)pair_start(cS0); pairEnd = (int)pair_start(cS1);
         const int LqLoc = Lloc * q;
         Cs = (int)round_up(LqLoc, 128);
         const int JT = jt();
@@ -1557,7 +1569,7 @@ struct PlmEngine : PlmEngineBase {
     int get_x(void* x, int dtype) override
     {
         if (!configured) return DCA_ERR_STATE;
-        if (native_mode == 4) DCA_TRY(strip_allgather(dx));       // collective, like get_g: every rank calls it
+        if (native_mode == 4 && !stripEmulate) DCA_TRY(strip_allgather(dx));       // collective, like get_g: every rank calls it
         if (dtype == DCA_F32) return download(dx, static_cast<float*>(x));
         if (dtype == DCA_F64) return download(dx, static_cast<double*>(x));
         return DCA_ERR_ARG;
@@ -1651,7 +1663,7 @@ struct PlmEngine : PlmEngineBase {
             sm.rank = sRank; sm.world = sWorld; sm.s0 = cS0; sm.s1 = cS1;
             for (int r = 0; r <= sWorld; ++r) sm.site0[r] = siteB[r];
             for (int r = 0; r < sWorld; ++r) { sm.recv[r] = strips && r > sRank ? dGrecv + grecvOff[r] : nullptr; sm.recvCs[r] = strips ? strip_cs(r) : 0; }
-            if (strips) DCA_TRY(exchange_g());
+            if (strips && !stripEmulate) DCA_TRY(exchange_g());
             const size_t lds = (size_t)kFoldWaves * ((q * q + 3) / 4 * 4) * sizeof(T);
             const int nOwned = pairEnd - pairBegin;
             if (nOwned > 0)
@@ -1702,20 +1714,20 @@ struct PlmEngine : PlmEngineBase {
     }
     int reduce_scalars(int first, int count)
     {
-        if (!comm && native_mode < 2) return DCA_OK;
+        if ((!comm && native_mode < 2) || stripEmulate) return DCA_OK;
         return do_comm(DCA_COMM_ALL_REDUCE, ctx->dScal + first, (size_t)count, DCA_F64, "all-reduce");
     }
     // make a P-vector whose slices are valid on their owners valid everywhere
     int gather_vector(T* v)
     {
         if (!comm && native_mode < 2) return DCA_OK;
-        if (native_mode == 4) return strip_allgather(v);
+        if (native_mode == 4) return stripEmulate ? DCA_OK : strip_allgather(v);
         return do_comm(DCA_COMM_ALL_GATHER, v, Ppad, (int)sizeof(T) * 8, "all-gather");
     }
     // after a step: every rank needs x where its evaluation reads it
     int publish_x()
     {
-        if (native_mode == 4) return exchange_x();
+        if (native_mode == 4) return stripEmulate ? DCA_OK : exchange_x();
         return gather_vector(dx);
     }
 
@@ -2037,7 +2049,7 @@ struct PlmEngine : PlmEngineBase {
     int scores(int apc, double* out) override
     {
         if (!configured) return DCA_ERR_STATE;
-        if (native_mode == 4) DCA_TRY(strip_allgather(dx));
+        if (native_mode == 4 && !stripEmulate) DCA_TRY(strip_allgather(dx));
         const size_t npairs = (size_t)L * (L - 1) / 2;
         double* dOut = nullptr;
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));

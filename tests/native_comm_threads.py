@@ -38,10 +38,19 @@ def main():
     st_ref = full.plm_lbfgs_iterate(iters)
     x_ref = full.plm_get_x(np.float64)
     full.close()
+    # the shipped float32 path, unsharded, for the float32 run of the column-strip decomposition
+    full32 = _lib.Context(0, _lib.DCA_F32)
+    full32.set_msa(X, q)
+    full32.set_weight_counts(counts)
+    full32.plm_configure(1.0, 20.0)
+    full32.plm_set_x(x0.astype(np.float32))
+    fx32_ref = full32.plm_gradient()
+    g32_ref = full32.plm_get_g(np.float64)
+    full32.close()
     M = golden("mf_toy_protein")
     XM = (M["X"] - 1).astype(np.uint8)
 
-    uid_w, uid_p1, uid_p2, uid_p3, uid_m, uid_p4 = (_lib.comm_unique_id(FAKE) for _ in range(6))
+    uid_w, uid_p1, uid_p2, uid_p3, uid_m, uid_p4, uid_p5 = (_lib.comm_unique_id(FAKE) for _ in range(7))
     out = [None] * world
 
     def run(rank):
@@ -87,6 +96,16 @@ def main():
                     fx_err=abs(fx - fx_ref) / abs(fx_ref), g_err=float(np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref)),
                     status=[st.status, st.iterations, st.evaluations], fx_end_err=abs(st.fx - st_ref.fx) / abs(st_ref.fx),
                     x_err=float(np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref)), x_sum=float(x.sum()), score_sum=float(sc.sum()))
+                s.close()
+                s = _lib.Context(0, _lib.DCA_F32)
+                s.set_msa(X, q)
+                s.set_weight_counts(counts)
+                s.comm_init(uid_p5, world, rank, FAKE)
+                s.plm_configure_strips(1.0, 20.0)
+                s.plm_set_x(x0.astype(np.float32))
+                fx = s.plm_gradient()
+                g = s.plm_get_g(np.float64)
+                res["mode4_f32"] = dict(fx_err=abs(fx - fx32_ref) / abs(fx32_ref), g_err=float(np.linalg.norm(g - g32_ref) / np.linalg.norm(g32_ref)))
                 s.close()
             # mfDCA pair counts summed through the communicator
             m = parallel.make_sharded_mf_context(_lib, XM, int(M["q"]), M["w"], rank, world, 0)

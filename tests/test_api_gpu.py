@@ -294,6 +294,22 @@ def test_native_rccl_communicator_single_rank():
         with pytest.raises(_lib.DcaBackendError):
             ctx.plm_set_native_comm(mode)                            # communicator gone
         ctx.close()
+    # the column-strip decomposition with one rank is the whole window: the unsharded run again; without a communicator: loud
+    ctx = _lib.Context(0, _lib.DCA_F32)
+    ctx.set_msa(X, q)
+    ctx.compute_weights(0.8, _lib.DCA_F32)
+    with pytest.raises(_lib.DcaBackendError):
+        ctx.plm_configure_strips(1.0, 5.0)
+    parallel.init_native_comm(ctx, _lib, 0, 1)
+    assert ctx.comm_info() == (1, 0)
+    ctx.plm_configure_strips(1.0, 5.0)
+    ctx.plm_init_x()
+    assert ctx.plm_gradient() == fx0 and np.array_equal(ctx.plm_get_g(np.float32), g0)
+    ctx.plm_lbfgs_begin(6)
+    st = ctx.plm_lbfgs_iterate(6)
+    assert (st.status, st.iterations, st.evaluations, st.fx) == (st0.status, st0.iterations, st0.evaluations, st0.fx)
+    assert np.array_equal(ctx.plm_get_x(np.float32), x0)
+    ctx.close()
     M = golden("mf_toy_protein")
     mctx = _lib.Context(0, _lib.DCA_F64)
     mctx.set_msa((M["X"] - 1).astype(np.uint8), int(M["q"]))
@@ -594,6 +610,7 @@ def test_native_exchange_path_with_several_ranks(world):
         assert m["status"] == res["reference_status"], m
         assert m["fx_end_err"] <= 1e-9 and m["x_err"] < 1e-7, m
         assert m["x_sum"] == res["ranks"][0]["mode4"]["x_sum"] and m["score_sum"] == res["ranks"][0]["mode4"]["score_sum"]
+        assert r["mode4_f32"]["fx_err"] <= 1e-6 and r["mode4_f32"]["g_err"] < 1e-5, r["mode4_f32"]      # float32: the window changes the slab split
         assert r["mf_err"] < 1e-9
         assert r["mf_stale_counts_dropped"] and r["mf_fi_err"] < 1e-13, r      # reduction switched on after a query; re-weighted afterwards
 
