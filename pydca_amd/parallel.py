@@ -330,6 +330,20 @@ def make_sharded_plm_context(lib_mod, X, q, weights, lambda_h, lambda_J, rank, w
     return ctx
 
 
+def make_strip_plm_context(lib_mod, X, q, weights, lambda_h, lambda_J, rank, world, device, dist=None, group=None,
+                           precision=32, carry_mode=1, chunk=0, warmup=0, rccl_path=None):
+    """Context of one rank of the COLUMN-STRIP decomposition (csrc/plm_engine.hip, exchange mode 4): the whole alignment and
+    all weights on every rank, the library's own RCCL communicator, and the columns of this rank's share of the sites.
+    Per evaluation two grouped point-to-point exchanges (couplings up, gradient-table rows down) instead of a
+    reduce-scatter / all-gather of whole parameter vectors; plm_get_x / plm_get_g / plm_scores are collective."""
+    ctx = lib_mod.Context(device, precision)
+    ctx.set_msa(np.ascontiguousarray(X), q)
+    ctx.set_weights(np.ascontiguousarray(weights, dtype=np.float64))
+    init_native_comm(ctx, lib_mod, rank, world, dist, group, rccl_path)
+    ctx.plm_configure_strips(lambda_h, lambda_J, carry_mode, chunk, warmup)
+    return ctx
+
+
 def initial_x(X, weights, q, dtype=np.float32):
     """PlmDCA::initFieldsAndCouplings (plmdca_numerics.cpp:207-249) on the FULL alignment,
     host side, in `dtype` arithmetic and the reference's accumulation order (ascending n).
