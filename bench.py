@@ -653,6 +653,32 @@ def main():
         out["roofline_mf"] = {"kernel": "mf_inverse", "bound": "mfma_f64", "achieved": inv_tf, "peak": 78.6, "unit": "TFLOP/s",
                               "frac": inv_tf / 78.6, "flop_convention": "n^3", "n": L * (q - 1),
                               "avg_kernel_ms": mctx.kernel_time("mf_inverse")[0] / max(mctx.kernel_time("mf_inverse")[1], 1)}
+        # the other kernels SURVEY 8 d3 names, each against the roof that binds it (K2 weights, K6 optimiser vectors, M2 pair counts)
+        t_cnt = mctx.kernel_time("mf_counts")[0] / max(mctx.kernel_time("mf_counts")[1], 1) / 1e3
+        t_w = mctx.kernel_time("weights")[0] / max(mctx.kernel_time("weights")[1], 1) / 1e3
+        t_vec = ktimes["lbfgs_vec"][0] / max(steps_done, 1) / 1e3
+        more = {}
+        if t_w > 0:
+            cmp_rate = N * N * L / 2.0 / t_w
+            # 5 v_xor + 2 v_or3 + 1 v_bcnt per 32 sites and lane-pair (3 + 1 + 1 for q <= 8): the no-skip integer-VALU roof
+            ops = 8.0 if q > 8 else 5.0
+            peak = 256 * 4 * 16 * 2.4e9 * 32.0 / ops
+            more["weights_K2"] = {"bound": "integer valu", "achieved": cmp_rate / 1e12, "peak": peak / 1e12, "unit": "T site comparisons/s",
+                                  "frac": cmp_rate / peak, "avg_kernel_ms": t_w * 1e3,
+                                  "note": "N^2 L / 2 comparisons of the symmetric half-loop; above 1 where the exact early exit skips work"}
+        if t_vec > 0:
+            vec_bytes = (4 * 5 + 12) * esz * float(P)
+            more["lbfgs_vectors_K6"] = {"bound": "hbm", "achieved": vec_bytes / t_vec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": vec_bytes / t_vec / 1e9 / HBM_PEAK_GBS, "ms_per_iteration": t_vec * 1e3,
+                                        "note": "(4 m + 12) P elements per iteration, m = 5 (SURVEY 8 d3)"}
+        if t_cnt > 0:
+            upd = N * L * (L - 1) / 2.0
+            cnt_bytes = N * L + 8.0 * N + 8.0 * Lq * Lq
+            more["pair_counts_M2"] = {"bound": "lds atomics", "achieved": upd / t_cnt / 1e12, "peak": 256 * 16 * 2.4e9 / 1e12, "unit": "T weighted updates/s",
+                                      "frac": upd / t_cnt / (256 * 16 * 2.4e9), "avg_kernel_ms": t_cnt * 1e3,
+                                      "hbm": {"achieved": cnt_bytes / t_cnt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cnt_bytes / t_cnt / 1e9 / HBM_PEAK_GBS},
+                                      "note": "histogram formulation (N L^2 / 2 ds_add_f64), not the 21 x larger one-hot GEMM; peak = 16 64-bit LDS atomics per clock and CU"}
+        out["roofline_more"] = more
         mctx.close()
 
     if world == 1 and args.precision == 32 and not args.no_modes:
