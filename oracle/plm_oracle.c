@@ -171,7 +171,9 @@ int oracle_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int 
  * (profiles/r04_sensitivity_E_cap100.json) -- the optimisation does not converge and amplifies rounding by ~1.2 x per
  * iteration -- so a device-vs-oracle comparison at 1e-4 needs BOTH to add in the same order; with it the device's
  * float64 gradient equals this oracle's bit for bit up to the last-place differences of the two exp() implementations. */
+#ifndef ORACLE_PLAIN_F64            /* -DORACLE_PLAIN_F64: the reference's order in float64 too (tests: the two differ by rounding only) */
 #define ORACLE_CANONICAL_F64 1
+#endif
 #define REAL double
 #define FN(name) CAT(name, _f64)
 #define REAL_EXP exp

@@ -79,6 +79,38 @@ def test_plm_gradient_matches_reference_at_config_C(oracle_plm):
         assert abs(np.linalg.norm(g) - float(G[name + "_gnorm"])) <= 1e-5 * np.linalg.norm(g)
 
 
+def test_canonical_float64_order_is_a_reordering_only(oracle_plm, tmp_path):
+    """The float64 oracle fixes the order of its additions (ORACLE_CANONICAL_F64 in oracle/plm_oracle.c: coupling rows, field,
+    carry; one rounded residual; compensated field sums).  Built WITHOUT that switch -- the reference's own order of
+    operations, in float64 -- it gives the same objective and gradient up to float64 rounding, with and without carry-over."""
+    import ctypes as C
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "liboracle_plain.so")
+    subprocess.check_call(["gcc", "-O3", "-fopenmp", "-fno-fast-math", "-ffp-contract=off", "-shared", "-fPIC", "-DORACLE_PLAIN_F64",
+                           "-o", so, os.path.join(here, "oracle", "plm_oracle.c"), "-lm"])
+    plain = C.CDLL(so)
+    dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    u8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    f = plain.oracle_gradient_f64
+    f.restype = C.c_double
+    f.argtypes = [u8, dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, C.c_int, C.c_int]
+    for tag in ("toy_rna", "toy_protein", "rf71"):
+        G = golden("plm_" + tag)
+        L, q = int(G["L"]), int(G["q"])
+        X = np.ascontiguousarray(G["X"])
+        w = oracle_plm.weights(X, 0.8, np.float64)
+        x = perturbed(oracle_plm.init_x(X, w, q), L, q)
+        for carry in (1, 0):
+            fx_c, g_c = oracle_plm.gradient(X, w, q, float(G["lambda_h"]), float(G["lambda_J"]), x, carry=bool(carry), threads=4)
+            g_p = np.zeros_like(x)
+            fx_p = f(X, w, X.shape[0], L, q, float(G["lambda_h"]), float(G["lambda_J"]), x, g_p, carry, 4)
+            assert abs(fx_c - fx_p) <= 1e-13 * abs(fx_p), (tag, carry, fx_c, fx_p)
+            assert rel_err(g_c, g_p) < 1e-12, (tag, carry, rel_err(g_c, g_p))
+            assert not np.array_equal(g_c, g_p)            # it IS another order
+
+
 def test_carry_over_is_what_the_reference_does(oracle_plm):
     """without the carried-over probabilities the result is far off."""
     G = golden("plm_toy_rna")
