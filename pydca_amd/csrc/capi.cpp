@@ -443,6 +443,7 @@ int dca_plm_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user)
 {
     CHECK_CTX(ctx);
     DCA_TRY(need_plm(ctx));
+    if (hook && ctx->plm->native_mode == 4) { dca_set_error("configured for column strips: no reduce hook"); return DCA_ERR_STATE; }
     ctx->plm->hook = hook;
     ctx->plm->hook_user = user;
     if (hook && ctx->plm->native_mode == 1) ctx->plm->native_mode = 0;      // the hook replaces the native all-reduce

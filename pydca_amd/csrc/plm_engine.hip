@@ -1686,7 +1686,9 @@ struct PlmEngine : PlmEngineBase {
         int rc = (q == 21) ? launch_eval<21>() : launch_eval<5>();
         if (rc != DCA_OK) return rc;
         o.evals += 1;
-        if (comm || native_mode == 2 || native_mode == 3) {
+        if (native_mode == 4) {
+            // column strips: both exchanges happened inside launch_eval; fx is summed with the caller's scalars
+        } else if (comm || native_mode == 2 || native_mode == 3) {
             // sharded vectors: sum the shards' gradients, keep this rank's slice; fx is summed with the
             // scalars of the caller (eval_scalars / gradient)
             DCA_TRY(do_comm(DCA_COMM_REDUCE_SCATTER, dg, Ppad, (int)sizeof(T) * 8, "reduce-scatter"));
@@ -1797,6 +1799,7 @@ struct PlmEngine : PlmEngineBase {
     {
         if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
         if (o.begun && !o.finished) { dca_set_error("vector sharding cannot change during an optimisation"); return DCA_ERR_STATE; }
+        if (strips) { dca_set_error("configured for column strips: dca_plm_configure again first"); return DCA_ERR_STATE; }
         if (native_mode >= 2) native_mode = 0;
         if (!h || world < 1) { vlo = 0; vn = P; Ppad = P; comm = nullptr; comm_user = nullptr; comm_rank = comm_world = 0; return DCA_OK; }
         DCA_TRY(set_slices(rank, world));
@@ -2067,6 +2070,7 @@ struct PlmEngine : PlmEngineBase {
     int pair_couplings(const int* pairs, int npairs, int shift, double* out) override
     {
         if (!configured) return DCA_ERR_STATE;
+        if (native_mode == 4 && !stripEmulate) DCA_TRY(strip_allgather(dx));
         return dca_pair_blocks(ctx, dx, 0, (int)sizeof(T) * 8, L, q, 0, pairs, npairs, shift, out);
     }
 
@@ -2074,6 +2078,7 @@ struct PlmEngine : PlmEngineBase {
     int di_scores(const double* reg_fi, int apc, double* out) override
     {
         if (!configured) return DCA_ERR_STATE;
+        if (native_mode == 4 && !stripEmulate) DCA_TRY(strip_allgather(dx));
         const size_t npairs = (size_t)L * (L - 1) / 2;
         double *dOut = nullptr, *dFi = nullptr;
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dOut), npairs * sizeof(double)));
