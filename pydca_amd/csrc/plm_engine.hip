@@ -465,19 +465,20 @@ __device__ __forceinline__ void scatter_store_site(const SiteAcc<Q>& acc, unsign
     }
 }
 
-template <typename T, int Q, int JW>
-__global__ __launch_bounds__(kScatWavesC * 64)
+template <typename T, int Q, int JW, int WAVES_>
+__global__ __launch_bounds__(WAVES_ * 64)
 void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT2,
                         T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int NT, int ctBase, int numPairs, int splitX,
                         int numJG, int chunksPerSplit, size_t slabElems)
 {
-    constexpr int WAVES = kScatWavesC;
+    constexpr int WAVES = WAVES_;                      // 16; 8 or 4 in the float64 mode on alignments with few column strips (configure)
     constexpr int JG = WAVES * JW;                     // sites per workgroup
     constexpr int CW = kRowBytes / (int)sizeof(T);     // columns per strip
     constexpr int DMA_PER_WAVE = kNC / 2 / WAVES;      // LDS-DMA instructions per wave and tile
     constexpr int TILE = kNC * kRowBytes;
     static_assert(kNC % (2 * WAVES) == 0, "tile rows must divide over the waves");
     static_assert(JW == 2 && (Q == 21 || Q == 5), "no generated gather block for this shape");
+    static_assert(WAVES == 16 || (sizeof(T) == 8 && (WAVES == 8 || WAVES == 4)), "no generated gather block for this workgroup size");
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
 
     // workgroup id -> (XCD, (column strip, tile-range split) pair, site group): the numJG site groups of a pair run on
@@ -542,12 +543,20 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
         uint32_t vtmp;
         if constexpr (Q == 21 && sizeof(T) == 4)
             DCA_GATHER_Q21_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
-        else if constexpr (Q == 21)
+        else if constexpr (Q == 21 && WAVES == 16)
             DCA_GATHER_Q21_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+        else if constexpr (Q == 21 && WAVES == 8)
+            DCA_GATHER_Q21_F64_SMEM_W8(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+        else if constexpr (Q == 21)
+            DCA_GATHER_Q21_F64_SMEM_W4(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
         else if constexpr (sizeof(T) == 4)
             DCA_GATHER_Q5_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
-        else
+        else if constexpr (WAVES == 16)
             DCA_GATHER_Q5_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+        else if constexpr (WAVES == 8)
+            DCA_GATHER_Q5_F64_SMEM_W8(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+        else
+            DCA_GATHER_Q5_F64_SMEM_W4(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
     }
 
     T* const Gslab = G + (size_t)split * slabElems;
@@ -1220,7 +1229,7 @@ struct PlmEngine : PlmEngineBase {
     bool configured = false;
     int numScanChunks = 0, numScatChunks = 0;
     static constexpr int kScatWaves = 16;
-    int scatSplit = 1, scatChunksPerSplit = 0, scatJW = 2;
+    int scatSplit = 1, scatChunksPerSplit = 0, scatJW = 2, scatWaves = kScatWavesC;
     int scatRemCT = 0, scatRemSplit = 0, scatRemChunksPerSplit = 0;     // left-over strips (numCT % 8) in their own, finer split launch
 
     T *dx = nullptr, *dg = nullptr, *dxp = nullptr, *dgp = nullptr, *dd = nullptr;
@@ -1392,6 +1401,15 @@ struct PlmEngine : PlmEngineBase {
             // (and the reference's one-thread) order of summation, so that the gradient does not depend on the launch
             // geometry; no tile-range split and no separate launch for the left-over strips unless a test forces them
             const bool canonical = sizeof(T) == 8 && !splitEnv && !remEnv;
+            // ... which leaves (strips x site groups) workgroups: where that does not fill the chip (config E: 12 x 5 = 60),
+            // workgroups of 8 waves (16 sites) spread the same chains over twice the CUs (E: 120; scatter 4.53 -> 3.87 ms).
+            // 4 waves (228 workgroups) measured 7.66 ms: one wave per SIMD cannot cover the M0 -> add chain.  DCA_SCATTER_WAVES forces.
+            scatWaves = kScatWavesC;
+            if (canonical) {
+                const char* we = getenv("DCA_SCATTER_WAVES");
+                if (we && (atoi(we) == 16 || atoi(we) == 8 || atoi(we) == 4)) scatWaves = atoi(we);
+                else if ((long long)numCT * ceil_div(L, scatWaves * scatJW) < 192) scatWaves = 8;
+            }
             for (int sp = 1; sp <= (canonical ? 0 : (splitEnv ? numScatChunks : s0)); ++sp) {
                 if (splitEnv && sp != std::max(1, std::min(numScatChunks, atoi(splitEnv)))) continue;
                 const int cps = ceil_div(numScatChunks, sp);
@@ -1620,21 +1638,22 @@ struct PlmEngine : PlmEngineBase {
         {
             constexpr int CW = kRowBytes / (int)sizeof(T);
             const int numCT = ceil_div(Cs, CW);
-            const int numJG = ceil_div(L, kScatWavesC * scatJW);
+            const int numJG = ceil_div(L, scatWaves * scatJW);
+            const int scatThreads = scatWaves * 64;
             const int mainCT = numCT - scatRemCT;            // strips of the main launch (all of them without a left-over launch)
             const size_t lds = (size_t)2 * kNC * kRowBytes;
             auto launch = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ScopedKernelClock kc(ctx, "plm_scatter");
                 if (numCT < kNumXcd)        // E: 6 strips would leave two XCDs idle: deal the (strip, split) pairs to the XCDs instead
-                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(numCT * scatSplit, kNumXcd) * numJG, 1), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG,
+                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(numCT * scatSplit, kNumXcd) * numJG, 1), dim3(scatThreads), lds, st, dR, dXT2, dG,
                                        N, L, Cs, halo, numScatChunks, NT, 0, numCT * scatSplit, scatSplit, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
                 else
-                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(mainCT, kNumXcd) * numJG, scatSplit), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG,
+                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(mainCT, kNumXcd) * numJG, scatSplit), dim3(scatThreads), lds, st, dR, dXT2, dG,
                                        N, L, Cs, halo, numScatChunks, NT, 0, mainCT, 1, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
                 if (scatRemCT) {
                     const int pairs = scatRemCT * scatRemSplit;
-                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(pairs, kNumXcd) * numJG, 1), dim3(kScatWavesC * 64), lds, st, dR, dXT2, dG,
+                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(pairs, kNumXcd) * numJG, 1), dim3(scatThreads), lds, st, dR, dXT2, dG,
                                        N, L, Cs, halo, numScatChunks, NT, mainCT, pairs, scatRemSplit, numJG, scatRemChunksPerSplit, (size_t)Grows * Cs);
                     const int col0 = mainCT * CW, ncols = Cs - col0;
                     hipLaunchKernelGGL(plm_sum_slabs_cols_kernel<T>, dim3((unsigned)(((size_t)Lq * ncols + 255) / 256)), dim3(256), 0, st, dG,
@@ -1642,7 +1661,13 @@ struct PlmEngine : PlmEngineBase {
                 }
                 return DCA_OK;
             };
-            DCA_TRY(launch(plm_scatter_kernel<T, Q, 2>));
+            if constexpr (sizeof(T) == 8) {
+                if (scatWaves == 8) DCA_TRY(launch(plm_scatter_kernel<T, Q, 2, 8>));
+                else if (scatWaves == 4) DCA_TRY(launch(plm_scatter_kernel<T, Q, 2, 4>));
+                else DCA_TRY(launch(plm_scatter_kernel<T, Q, 2, 16>));
+            } else {
+                DCA_TRY(launch(plm_scatter_kernel<T, Q, 2, 16>));
+            }
         }
         DCA_ROUND_STAGE(8, dG, (size_t)std::max(scatSplit, scatRemSplit) * Grows * Cs);
         {

@@ -72,7 +72,11 @@ def temp_base(jw):
 SET_A, SET_B = 36, 68          # two sets of 2 x 16 state words (scalar-load variant, two sites per wave)
 
 
-def body_smem(q, f64):
+# LDS-DMA pieces of the next tile per wave and quarter tile, by workgroup size: 64 pieces per tile over 16 / 8 / 4 waves
+SC_PLANS = {16: SC_DMA_PLAN, 8: [2, 2, 2, 2], 4: [4, 4, 4, 4]}
+
+
+def body_smem(q, f64, waves=16):
     """Two sites per wave, state words through scalar loads.  Moving the words to SGPRs with v_readlane
     costs 0.5 VALU instruction per (row, site) and the VALU is the busiest unit of this block; an
     s_load_dwordx16 per site and quarter tile costs none.  Quarter k uses SGPR set k % 2; the loads of
@@ -107,9 +111,10 @@ def body_smem(q, f64):
             # this wave's LDS-DMA piece qk of the NEXT tile (4 pieces per wave and tile), issued here rather
             # than all 64 pieces of the workgroup at the tile start: no burst of LDS writes in front of everyone's reads
             # SC_DMA_PLAN[qk] pieces are issued at the start of quarter qk (default one per quarter)
-            first = sum(SC_DMA_PLAN[:qk])
+            dplan = SC_PLANS[waves]
+            first = sum(dplan[:qk])
             dma = []
-            for piece in range(first, first + SC_DMA_PLAN[qk]):
+            for piece in range(first, first + dplan[qk]):
                 dma += ["s_cmp_lg_u32 %[npc], 0",
                         "s_cbranch_scc0 .Ldca_sc_skip%d_%%=" % piece,
                         "s_add_u32 m0, %%[ldst], %d" % (piece * 1024),
@@ -153,12 +158,13 @@ def body_smem(q, f64):
     return o
 
 
-def macro_smem(q, f64):
+def macro_smem(q, f64, waves=16):
     d0, acc = plan(q, 2)
     names = "ABC"[:len(tuples(q))]
     params = ["VBASE", "SP0", "SP1", "NPC", "GBASE", "GINC", "VOFF", "LDST", "VTMP"] + ["%s%d" % (n, jj) for jj in range(2) for n in names]
-    lines = ["#define DCA_GATHER_Q%d_%s_SMEM(%s) \\" % (q, "F64" if f64 else "F32", ", ".join(params)), "    asm volatile( \\"]
-    for ln in body_smem(q, f64):
+    suffix = "" if waves == 16 else "_W%d" % waves
+    lines = ["#define DCA_GATHER_Q%d_%s_SMEM%s(%s) \\" % (q, "F64" if f64 else "F32", suffix, ", ".join(params)), "    asm volatile( \\"]
+    for ln in body_smem(q, f64, waves):
         lines.append('        "%s\\n" \\' % ln)
     outs = []
     for jj, base in enumerate(acc):
@@ -477,6 +483,11 @@ def main():
         # tools/experiments, not emitted)
         for f64 in (0, 1):
             out.append(macro_smem(q, f64))
+            out.append("")
+        # float64 only: workgroups of 8 / 4 waves (16 / 8 sites) for the parity mode's single chain per sum on alignments with
+        # few column strips, where the tile-range split that would otherwise fill the chip is not allowed
+        for waves in (8, 4):
+            out.append(macro_smem(q, 1, waves))
             out.append("")
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pydca_amd", "csrc", "scatter_gather_asm.inc")
     with open(path, "w") as fh:
