@@ -442,7 +442,7 @@ def main():
                     if mode != 4:
                         c.plm_set_native_comm(mode)
                     c.plm_set_x(x0)
-                    c.plm_lbfgs_begin(1000)
+                    c.plm_lbfgs_begin(4)                                     # 1 + 3 iterations, then the cap ends the run: the scheme can only change between runs
                     c.plm_lbfgs_iterate(1)                                   # warm: RCCL sets its channels up on first use
                 except Exception as exc:                                     # pragma: no cover (needs a multi-GPU node)
                     print("rank %d: exchange mode %d unavailable (%r)" % (rank, mode, exc), file=sys.stderr)
