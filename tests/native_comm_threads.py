@@ -50,7 +50,7 @@ def main():
     M = golden("mf_toy_protein")
     XM = (M["X"] - 1).astype(np.uint8)
 
-    uid_w, uid_p1, uid_p2, uid_p3, uid_m, uid_p4, uid_p5 = (_lib.comm_unique_id(FAKE) for _ in range(7))
+    uid_w, uid_p1, uid_p2, uid_p3, uid_m, uid_p4, uid_p5, uid_p6 = (_lib.comm_unique_id(FAKE) for _ in range(8))
     out = [None] * world
 
     def run(rank):
@@ -78,6 +78,23 @@ def main():
                     status=[st.status, st.iterations, st.evaluations], fx_end_err=abs(st.fx - st_ref.fx) / abs(st_ref.fx),
                     x_err=float(np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref)), x_sum=float(x.sum()))
                 s.close()
+            # what bench.py --gpus N does at start-up: ONE sharded context, a complete 4-iteration run under each scheme in
+            # turn (the scheme can only change between runs), then the chosen scheme for the real run
+            s = parallel.make_sharded_plm_context(_lib, X, q, w, 1.0, 20.0, rank, world, 0, precision=64)
+            s.comm_init(uid_p6, world, rank, FAKE)
+            seq = []
+            for mode in (1, 2, 3, 2):
+                s.plm_set_native_comm(mode)
+                s.plm_set_x(x0)
+                s.plm_lbfgs_begin(4)
+                s.plm_lbfgs_iterate(1)
+                st = s.plm_lbfgs_iterate(3)
+                seq.append([st.status, st.iterations, st.finished, st.fx])
+            s.plm_set_x(x0)
+            s.plm_lbfgs_begin(iters)
+            st = s.plm_lbfgs_iterate(iters)
+            res["scheme_switching"] = dict(runs=seq, final=[st.status, st.iterations, st.evaluations], fx_end_err=abs(st.fx - st_ref.fx) / abs(st_ref.fx))
+            s.close()
             # mode 4, the column-strip decomposition: every rank holds the WHOLE alignment and the columns of its sites
             if world > 1:
                 s = _lib.Context(0, _lib.DCA_F64)

@@ -602,6 +602,9 @@ def test_native_exchange_path_with_several_ranks(world):
             assert m["status"] == res["reference_status"], m
             assert m["fx_end_err"] <= 1e-9 and m["x_err"] < 1e-7, m
             assert m["x_sum"] == res["ranks"][0][mode]["x_sum"]           # every rank ends with the same x
+        sw = r["scheme_switching"]                # bench.py's start-up sequence: a 4-iteration run per scheme on one context, then the real run
+        assert all(run[1] == 4 and run[2] == 1 for run in sw["runs"]) and len({round(run[3], 3) for run in sw["runs"]}) == 1, sw
+        assert sw["final"] == res["reference_status"] and sw["fx_end_err"] <= 1e-9, sw
         # mode 4, the column-strip decomposition (every rank the whole alignment and the columns of its sites; two grouped
         # point-to-point exchanges per evaluation): the same sums in the same order as the unsharded run, so it follows
         # it even more closely than the sequence-sharded schemes
