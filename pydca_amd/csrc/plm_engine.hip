@@ -90,6 +90,7 @@ typedef float dca_v32f __attribute__((ext_vector_type(32)));
 typedef float dca_v16f __attribute__((ext_vector_type(16)));
 typedef float dca_v8f __attribute__((ext_vector_type(8)));
 typedef float dca_v2f __attribute__((ext_vector_type(2)));
+typedef uint32_t dca_v4u __attribute__((ext_vector_type(4)));
 
 #include "logits_gather_asm.inc"
 
@@ -540,23 +541,24 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
         const uint32_t npc = __builtin_amdgcn_readfirstlane((c + 1 < cEnd && !(DCA_SCATTER_ABLATE & 8)) ? 1u : 0u);
         const unsigned char* gbase = tile_src(c + 1);
         const uint32_t ldst = (uint32_t)(uintptr_t)dca_smem + (buf ^ 1) * TILE + wave * DMA_PER_WAVE * 1024;
-        uint32_t vtmp;
+        uint32_t vtmp, vw;
+        dca_v4u stg;                 // staging registers of the next tile's piece (16-wave blocks; unused by the LDS-DMA variants)
         if constexpr (Q == 21 && sizeof(T) == 4)
-            DCA_GATHER_Q21_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+            DCA_GATHER_Q21_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
         else if constexpr (Q == 21 && WAVES == 16)
-            DCA_GATHER_Q21_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+            DCA_GATHER_Q21_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
         else if constexpr (Q == 21 && WAVES == 8)
-            DCA_GATHER_Q21_F64_SMEM_W8(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+            DCA_GATHER_Q21_F64_SMEM_W8(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
         else if constexpr (Q == 21)
-            DCA_GATHER_Q21_F64_SMEM_W4(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+            DCA_GATHER_Q21_F64_SMEM_W4(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
         else if constexpr (sizeof(T) == 4)
-            DCA_GATHER_Q5_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+            DCA_GATHER_Q5_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
         else if constexpr (WAVES == 16)
-            DCA_GATHER_Q5_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+            DCA_GATHER_Q5_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
         else if constexpr (WAVES == 8)
-            DCA_GATHER_Q5_F64_SMEM_W8(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+            DCA_GATHER_Q5_F64_SMEM_W8(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
         else
-            DCA_GATHER_Q5_F64_SMEM_W4(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+            DCA_GATHER_Q5_F64_SMEM_W4(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
     }
 
     T* const Gslab = G + (size_t)split * slabElems;

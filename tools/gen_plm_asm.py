@@ -74,6 +74,14 @@ SET_A, SET_B = 36, 68          # two sets of 2 x 16 state words (scalar-load var
 
 # LDS-DMA pieces of the next tile per wave and quarter tile, by workgroup size: 64 pieces per tile over 16 / 8 / 4 waves
 SC_PLANS = {16: SC_DMA_PLAN, 8: [2, 2, 2, 2], 4: [4, 4, 4, 4]}
+# How the next tile of R reaches LDS in the 16-wave scatter block.  "dma": global_load_lds_dwordx4 (no staging registers).
+# "vgpr" (round 4): global_load_dwordx4 into four VGPRs at the start of a quarter tile, ds_write_b128 at the start of the next:
+# the LDS-DMA path fills LDS at ~12 B/clk/CU, and the scatter kernel needs 64 KiB per ~6100-clk tile (10.7 B/clk/CU) -- it
+# looked as if it ran at the DMA's ceiling as much as at the adds' (dropping the staging altogether: 7.0 -> 5.9 ms at config D).
+# MEASURED (profiles/r04_scatter_vgpr_staging.txt): slower -- D 7.62 against 7.04 ms, E 0.78 against 0.71, float64 D 15.5 against
+# 13.9: the register path pays a vmcnt wait and a 1 KiB LDS write per piece in the instruction stream of waves that have no
+# slack, and the fill rate was not the limit.  The product ships "dma"; the option stays for the record.
+SC_STAGE = os.environ.get("DCA_GEN_SC_STAGE", "dma")
 
 
 def body_smem(q, f64, waves=16):
@@ -98,8 +106,12 @@ def body_smem(q, f64, waves=16):
     def sload(qk, base):
         return ["s_load_dwordx16 s[%d:%d], %%[sp%d], 0x%x" % (base + 16 * jj, base + 16 * jj + 15, jj, qk * 64) for jj in range(2)]
 
+    vstage = SC_STAGE == "vgpr" and waves == 16 and SC_PLANS[waves] == [1, 1, 1, 1]
     o += sload(0, sets[0])
     o.append("v_mov_b32 %[vtmp], %[voff]")
+    if vstage:      # LDS address of this lane's 16 bytes of the wave's first piece of the next tile
+        o += ["v_mbcnt_lo_u32_b32 %[vw], -1, 0", "v_mbcnt_hi_u32_b32 %[vw], -1, %[vw]", "v_lshlrev_b32 %[vw], 4, %[vw]",
+              "v_add_u32 %[vw], %[ldst], %[vw]"]
     for r in range(DEPTH):
         o.append(ds(r))
     quarter = ROWS // 4
@@ -114,7 +126,13 @@ def body_smem(q, f64, waves=16):
             dplan = SC_PLANS[waves]
             first = sum(dplan[:qk])
             dma = []
-            for piece in range(first, first + dplan[qk]):
+            if vstage:
+                dma += ["s_cmp_lg_u32 %[npc], 0", "s_cbranch_scc0 .Ldca_sc_skip%d_%%=" % qk]
+                if qk:
+                    dma += ["s_waitcnt vmcnt(0)", "ds_write_b128 %%[vw], %%[stg] offset:%d" % ((qk - 1) * 1024)]
+                dma += ["global_load_dwordx4 %[stg], %[vtmp], %[gbase]" + SC_DMA_AUX, "v_add_u32 %[vtmp], %[ginc], %[vtmp]",
+                        ".Ldca_sc_skip%d_%%=:" % qk]
+            for piece in range(first, first + dplan[qk]) if not vstage else ():
                 dma += ["s_cmp_lg_u32 %[npc], 0",
                         "s_cbranch_scc0 .Ldca_sc_skip%d_%%=" % piece,
                         "s_add_u32 m0, %%[ldst], %d" % (piece * 1024),
@@ -154,6 +172,9 @@ def body_smem(q, f64, waves=16):
     if SC_EXP:
         o.append("s_waitcnt lgkmcnt(0)")
     o.append("s_set_gpr_idx_off")
+    if vstage:      # the last piece; everything this wave stages is in LDS when the block ends (the tile barrier follows)
+        o += ["s_cmp_lg_u32 %[npc], 0", "s_cbranch_scc0 .Ldca_sc_skipend_%=", "s_waitcnt vmcnt(0)",
+              "ds_write_b128 %[vw], %[stg] offset:3072", "s_waitcnt lgkmcnt(0)", ".Ldca_sc_skipend_%=:"]
     o.append("s_mov_b32 m0, vcc_lo")
     return o
 
@@ -161,7 +182,7 @@ def body_smem(q, f64, waves=16):
 def macro_smem(q, f64, waves=16):
     d0, acc = plan(q, 2)
     names = "ABC"[:len(tuples(q))]
-    params = ["VBASE", "SP0", "SP1", "NPC", "GBASE", "GINC", "VOFF", "LDST", "VTMP"] + ["%s%d" % (n, jj) for jj in range(2) for n in names]
+    params = ["VBASE", "SP0", "SP1", "NPC", "GBASE", "GINC", "VOFF", "LDST", "VTMP", "STG", "VW"] + ["%s%d" % (n, jj) for jj in range(2) for n in names]
     suffix = "" if waves == 16 else "_W%d" % waves
     lines = ["#define DCA_GATHER_Q%d_%s_SMEM%s(%s) \\" % (q, "F64" if f64 else "F32", suffix, ", ".join(params)), "    asm volatile( \\"]
     for ln in body_smem(q, f64, waves):
@@ -173,6 +194,8 @@ def macro_smem(q, f64, waves=16):
             outs.append('"+{v[%d:%d]}"(%s%d)' % (r, r + sz - 1, n, jj))
             r += sz
     outs.append('[vtmp] "=&v"(VTMP)')
+    if SC_STAGE == "vgpr" and waves == 16 and SC_PLANS[waves] == [1, 1, 1, 1]:
+        outs += ['[stg] "=&v"(STG)', '[vw] "=&v"(VW)']
     lines.append("        : %s \\" % ", ".join(outs))
     lines.append('        : [vbase] "v"(VBASE), [sp0] "s"(SP0), [sp1] "s"(SP1), [npc] "s"(NPC), [gbase] "s"(GBASE), [ginc] "s"(GINC), '
                  '[voff] "v"(VOFF), [ldst] "s"(LDST) \\')
