@@ -541,8 +541,9 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
         const uint32_t npc = __builtin_amdgcn_readfirstlane((c + 1 < cEnd && !(DCA_SCATTER_ABLATE & 8)) ? 1u : 0u);
         const unsigned char* gbase = tile_src(c + 1);
         const uint32_t ldst = (uint32_t)(uintptr_t)dca_smem + (buf ^ 1) * TILE + wave * DMA_PER_WAVE * 1024;
-        uint32_t vtmp, vw;
-        dca_v4u stg;                 // staging registers of the next tile's piece (16-wave blocks; unused by the LDS-DMA variants)
+        uint32_t vtmp;
+        [[maybe_unused]] uint32_t vw;       // LDS address / staging registers of the generator's register-staged variant
+        [[maybe_unused]] dca_v4u stg;       // (DCA_GEN_SC_STAGE=vgpr; the shipped LDS-DMA blocks do not use them)
         if constexpr (Q == 21 && sizeof(T) == 4)
             DCA_GATHER_Q21_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
         else if constexpr (Q == 21 && WAVES == 16)
