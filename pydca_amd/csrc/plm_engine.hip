@@ -301,7 +301,11 @@ void plm_softmax_kernel(const T* __restrict__ SR, T* __restrict__ Rout, const T*
 {
     constexpr int ROWB = 64 * Q * (int)sizeof(T);        // bytes of a wave's span of one row
     constexpr int NP = (ROWB + 1023) / 1024;             // 16-byte pieces per lane
+#ifdef DCA_SOFTMAX_DEPTH
+    constexpr int DEPTH = DCA_SOFTMAX_DEPTH;             // experiments
+#else
     constexpr int DEPTH = NP > 6 ? 2 : 3;                // rows in flight
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
