@@ -231,6 +231,12 @@ def precision_modes(_lib, X, q, lh, lJ, device, workload, f32_value, f32_ms, ste
             modes["f32"]["vs_float64_oracle_at_cap_100"] = {k: f.get(k) for k in (
                 "status", "max_rel_fn", "max_rel_fn_apc_vs_fn", "max_rel_fn_apc_topL_self", "topL_same_fn_apc", "topL_overlap_fn_apc")}
             modes["f32"]["meets_north_star_tolerance"] = bool(f.get("max_rel_fn", 1) <= 1e-4 and f.get("topL_same_fn_apc"))
+            spath = os.path.join(ROOT, "profiles", "r04_reference_spread_%s.json" % workload)
+            if os.path.exists(spath):      # the reference's own run-to-run spread at this configuration (two thread counts), where it could be afforded
+                sp = json.load(open(spath))
+                k = [v for name, v in sp["pairs"].items() if "oracle" not in name]
+                if k:
+                    modes["f32"]["reference_vs_reference_at_cap_100"] = dict(k[0], file=os.path.relpath(spath, ROOT))
         except Exception as exc:   # pragma: no cover
             modes["parity_report_error"] = repr(exc)
     else:
