@@ -304,7 +304,11 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0)
     args = ap.parse_args()
 
-    selftest = os.environ.get("DCA_BENCH_SELFTEST") == "1"
+    # DCA_BENCH_SELFTEST: several ranks on ONE GPU (tests): "1" = gloo + torch.distributed hooks; "native" = the library's
+    # own communicators over the stand-in librccl named by DCA_RCCL_PATH (tests/fake_rccl/libfake_rccl_mp.so), i.e. the
+    # very code path a multi-GPU node runs -- scheme timing, selection, column strips -- with host-staged transfers
+    selftest = os.environ.get("DCA_BENCH_SELFTEST") in ("1", "native")
+    selftest_native = os.environ.get("DCA_BENCH_SELFTEST") == "native"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run,
         # the launcher the driver uses), instead of silently measuring one GPU
@@ -367,7 +371,8 @@ def main():
     full.set_profiling(True)
     # exchange scheme of a multi-GPU run: the library's own RCCL communicator on its stream (default), or the
     # torch.distributed hooks (DCA_BENCH_TORCH_COMM=1; always in the gloo self-test, where RCCL cannot run)
-    native = world > 1 and not selftest and os.environ.get("DCA_BENCH_TORCH_COMM") != "1"
+    native = world > 1 and (not selftest or selftest_native) and os.environ.get("DCA_BENCH_TORCH_COMM") != "1"
+    tdev = "cpu" if selftest else "cuda"           # tensors of the torch.distributed calls (gloo in the self-tests)
     if world == 1:
         full.compute_weights(0.8, _lib.DCA_F32)
 
@@ -380,7 +385,7 @@ def main():
         except Exception as exc:               # pragma: no cover (needs a multi-GPU node)
             print("rank %d: native communicator unavailable (%r): torch.distributed hooks instead" % (rank, exc), file=sys.stderr)
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
@@ -453,7 +458,7 @@ def main():
                 except Exception as exc:                                     # pragma: no cover (needs a multi-GPU node)
                     print("rank %d: exchange mode %d unavailable (%r)" % (rank, mode, exc), file=sys.stderr)
                     ok = 0
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)                  # a mode is timed only if it came up on every rank
                 if not bool(flag.item()):
                     return None
@@ -461,7 +466,7 @@ def main():
                 t1 = time.perf_counter()
                 c.plm_lbfgs_iterate(3)
                 barrier()
-                tm = torch.tensor([(time.perf_counter() - t1) / 3.0], dtype=torch.float64, device="cuda")
+                tm = torch.tensor([(time.perf_counter() - t1) / 3.0], dtype=torch.float64, device=tdev)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 return float(tm.item()) * 1e3
 
@@ -531,7 +536,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     steps_done = st.iterations - it0

@@ -651,6 +651,42 @@ def test_bench_two_process_selftest(mode):
     assert "modes" in d1 and d1["modes"]["f64"]["iterations_per_s"] > 0
 
 
+@pytest.mark.parametrize("scheme", ["timed", "4", "3"])
+def test_bench_native_path_two_processes(scheme):
+    """`python bench.py --gpus 2` through its NATIVE multi-rank path -- the path an 8-GPU node runs: self-launch of the ranks,
+    the library's own communicators (sharded weights, one per context), the start-up timing of the four exchange schemes,
+    the selection, the column-strip decomposition, the asserted rank counts -- on one GPU, with two PROCESSES over the
+    stand-in tests/fake_rccl/libfake_rccl_mp.so (DCA_BENCH_SELFTEST=native; real RCCL refuses two ranks on one device).
+    The optimiser must follow the single-process run whatever scheme runs."""
+    import json
+    import subprocess
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl_mp.so")
+    assert os.path.exists(fake), "build it: python -c 'import __graft_entry__ as g; g.build()'"
+    env = dict(os.environ, DCA_BENCH_SELFTEST="native", DCA_RCCL_PATH=fake, MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DCA_BENCH_SCHEME"):
+        env.pop(k, None)
+    if scheme != "timed":
+        env["DCA_BENCH_SCHEME"] = scheme
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "C"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-3000:]
+    d2 = json.loads(two.stdout.strip().splitlines()[-1])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--workload", "C",
+                          "--no-cpu-baseline", "--no-mfdca", "--no-e2e", "--no-modes"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    sel = d2["comm_selection"]
+    assert d2["n_gpus"] == 2 and sel["rccl_ranks"] == 2 and d2["steps"] == 4, d2
+    if scheme == "timed":
+        assert sorted(sel["ms_per_iteration"]) == ["1", "2", "3", "4"], sel          # all four schemes came up and were timed
+        assert str(sel["chosen_mode"]) == min(sel["ms_per_iteration"], key=lambda m: sel["ms_per_iteration"][m])
+    else:
+        assert sel["chosen_mode"] == int(scheme)
+    if sel["chosen_mode"] == 4:
+        assert "column strips" in d2["config"]["parallelism"]
+    assert abs(d2["fx"] - d1["fx"]) <= 1e-6 * abs(d1["fx"]), (d2["fx"], d1["fx"])
+
+
 def test_msa_numerics_direct_information_functions():
     """Module-level DI functions of both msa_numerics mirrors against the
     reference's own output (goldens): two-site model fields and DI from caller-provided arrays."""
