@@ -822,13 +822,16 @@ __device__ __forceinline__ void leaf_step_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#ifndef DCA_LEAF_WAVES128
+#define DCA_LEAF_WAVES128 8          // waves of the 128-leaf (experiments: 12, 16 -- fewer tiles per worker wave, fewer registers for the chain)
+#endif
 template <int NB>
-__global__ __launch_bounds__(NB == 128 ? 512 : 320)
+__global__ __launch_bounds__(NB == 128 ? DCA_LEAF_WAVES128 * 64 : 320)
 void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info)
 {
     constexpr int NT = NB / 16;                       // tiles per side
     constexpr int NTILES = NT * (NT + 1) / 2;         // lower tiles
-    constexpr int WAVES = NB == 128 ? 8 : 5;           // 8 x 64 = 4 NB lanes for step c.; 256 VGPRs for the unrolled 4 x 4 chain
+    constexpr int WAVES = NB == 128 ? DCA_LEAF_WAVES128 : 5;           // 8 x 64 = 4 NB lanes for step c.; 256 VGPRs for the unrolled 4 x 4 chain
     constexpr int WORKERS = WAVES - 1;
     constexpr int SLOTS = (NTILES + WORKERS - 1) / WORKERS;
     constexpr int STEPS = NB / 4;
@@ -1159,7 +1162,7 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
         return DCA_OK;
     }
     if (n == 128 && leaf128) {
-        if (leafMfma) hipLaunchKernelGGL(cholinv_leaf_mfma_kernel<128>, dim3(1), dim3(512), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
+        if (leafMfma) hipLaunchKernelGGL(cholinv_leaf_mfma_kernel<128>, dim3(1), dim3(DCA_LEAF_WAVES128 * 64), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
         else hipLaunchKernelGGL(cholinv_leaf_kernel<128>, dim3(1), dim3(1024), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
         return DCA_OK;
     }
