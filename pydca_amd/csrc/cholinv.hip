@@ -1118,7 +1118,7 @@ constexpr int kSideDepths = DCA_SIDE_DEPTHS;
 // made once per process and device and lent to one inverse at a time (contexts of several host threads get a set each).
 struct SideSet {
     hipStream_t s[kSideDepths] = {};
-    hipEvent_t fork[kSideDepths] = {}, join[kSideDepths] = {};
+    hipEvent_t fork[kSideDepths] = {}, join[kSideDepths] = {}, mid[kSideDepths] = {};
     int device = -1;
     bool busy = false;
 };
@@ -1138,7 +1138,8 @@ SideSet* side_set_acquire(int device)
     for (int d = 0; d < kSideDepths && good; ++d) {
         good = hipStreamCreateWithFlags(&S->s[d], hipStreamNonBlocking) == hipSuccess &&
                hipEventCreateWithFlags(&S->fork[d], hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&S->join[d], hipEventDisableTiming) == hipSuccess;
+               hipEventCreateWithFlags(&S->join[d], hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&S->mid[d], hipEventDisableTiming) == hipSuccess;
     }
     if (!good) { delete S; return nullptr; }      // the products then run in line
     S->busy = true;
@@ -1152,7 +1153,9 @@ void side_set_release(SideSet* S)
     S->busy = false;
 }
 
-int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws, int* dInfo, SideSet* side, int depth = 0)
+// pending: an event on a side stream after which the blocks (2,1) and (2,2) of M have received their update from the
+// PARENT's panel (see the deferred SYRK below); the main stream waits for it only when it first touches those blocks.
+int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws, int* dInfo, SideSet* side, int depth = 0, hipEvent_t pending = nullptr)
 {
     static const bool leaf128 = !(getenv("DCA_CHOLINV_LEAF128") && atoi(getenv("DCA_CHOLINV_LEAF128")) == 0);
     static const bool leafMfma = !(getenv("DCA_CHOLINV_LEAF_MFMA") && atoi(getenv("DCA_CHOLINV_LEAF_MFMA")) == 0);
@@ -1174,6 +1177,7 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     double* M21 = M + (size_t)n1 * ld;
     double* M22 = M + (size_t)n1 * ld + n1;
     DCA_TRY(cholinv_rec(ctx, M11, ld, n1, pivotBase, ws, dInfo, side, depth + 1));
+    if (pending) HIP_TRY(hipStreamWaitEvent(ctx->stream, pending, 0));        // M21 and M22 are read / updated from here on
     const size_t mark = ws.top;
     double* L21 = ws.alloc((size_t)n2 * n1);
     double* Tt = ws.alloc((size_t)n1 * n2);
@@ -1207,9 +1211,26 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     // background bands take what its ragged second round leaves idle
     static const bool forkBeforeSyrk = !(getenv("DCA_CHOLINV_SIDE_FORK") && atoi(getenv("DCA_CHOLINV_SIDE_FORK")) == 0);
     const bool useSide = !paired && side && sideMode && depth < kSideDepths && n1 >= sideMinN1 && sideBudget[depth] > 0;
+    // Deferred SYRK (round 4).  The A22 subtree starts with the recursion on A22's OWN first diagonal block (h x h): only that
+    // quadrant of the update A22 -= L21 L21^T is needed at once.  The other three quarters of its flop -- the blocks (2,1)
+    // and (2,2) of A22 -- go to the side stream as banded launches IN FRONT of T^T and run next to that first, chain-heavy
+    // half of the subtree; the child waits for them (`pending`) where it first touches those blocks.
+    // MEASURED (round 4, opt-in DCA_CHOLINV_DEFER_SYRK=1, NOT adopted): n = 10 048 23.5 - 23.8 ms against 23.5, n = 8000 14.8
+    // against 14.5, n = 6000 7.8 against 8.0, n = 4000 3.9 against 3.8 -- the background bands take from the foreground's
+    // mid-size products what they give to the leaf chain, as every other background product tried at this depth did.
+    static const bool deferSyrk = getenv("DCA_CHOLINV_DEFER_SYRK") && atoi(getenv("DCA_CHOLINV_DEFER_SYRK")) == 1;
+    const int h = (leaf128 && n2 >= 256) ? (n2 / 128 / 2) * 128 : (n2 / 64 / 2) * 64;       // the child's split of n2
+    bool deferred = false;
     auto fork_side = [&]() -> int {
         HIP_TRY(hipEventRecord(side->fork[depth], ctx->stream));                  // L21 (and X11) are complete
         HIP_TRY(hipStreamWaitEvent(side->s[depth], side->fork[depth], 0));
+        if (deferSyrk && !paired && n2 >= 2048 && h >= 128 && n2 - h >= 128) {
+            const double* Lh = L21 + (size_t)h * n1;
+            DCA_TRY(launch_gemm_banded(ctx, side->s[depth], GemmArgs{Lh, n1, MASK_NONE, L21, n1, MASK_NONE, M22 + (size_t)h * ld, ld, nullptr, 0, n2 - h, h, n1, -1.0, 1.0, 0}, sideBudget[depth]));
+            DCA_TRY(launch_gemm_banded(ctx, side->s[depth], GemmArgs{Lh, n1, MASK_NONE, Lh, n1, MASK_NONE, M22 + (size_t)h * ld + h, ld, nullptr, 0, n2 - h, n2 - h, n1, -1.0, 1.0, 1}, sideBudget[depth]));
+            HIP_TRY(hipEventRecord(side->mid[depth], side->s[depth]));
+            deferred = true;
+        }
         DCA_TRY(launch_gemm_banded(ctx, side->s[depth], ttArgs, sideBudget[depth]));
         HIP_TRY(hipEventRecord(side->join[depth], side->s[depth]));
         onSide = true;
@@ -1225,9 +1246,13 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     };
     int rc = DCA_OK;
     if (useSide && forkBeforeSyrk && (rc = fork_side()) != DCA_OK) return bail(rc);
-    if (!paired && (rc = launch_gemm(ctx, syrkArgs)) != DCA_OK) return bail(rc);
+    if (!paired) {
+        // with the deferred form only the first diagonal quadrant runs here
+        const GemmArgs q00{L21, n1, MASK_NONE, L21, n1, MASK_NONE, M22, ld, nullptr, 0, h, h, n1, -1.0, 1.0, 1};
+        if ((rc = launch_gemm(ctx, deferred ? q00 : syrkArgs)) != DCA_OK) return bail(rc);
+    }
     if (useSide && !forkBeforeSyrk && (rc = fork_side()) != DCA_OK) return bail(rc);
-    if ((rc = cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo, side, depth + 1)) != DCA_OK) return bail(rc);
+    if ((rc = cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo, side, depth + 1, deferred ? side->mid[depth] : nullptr)) != DCA_OK) return bail(rc);
     if (onSide) {
         if (hipStreamWaitEvent(ctx->stream, side->join[depth], 0) != hipSuccess) { dca_set_error("cholinv: join of the side stream failed"); return bail(DCA_ERR_HIP); }
     } else if (!paired) DCA_TRY(launch_gemm(ctx, ttArgs));
