@@ -31,6 +31,14 @@ enum { WALK_ROWS = 0, WALK_ROWS_REVERSED = 1 /* lower triangular A */, WALK_COLU
 
 constexpr int BM = 64, BN = 64;
 
+// The kernels of the factorisation's serial chain (leaves, few-tile products) raise their waves' issue priority: when the
+// look-ahead bulk products of another stream share a CU with them, the chain's instructions go first on the shared SIMDs
+// and matrix pipes (s_setprio arbitrates between the waves of a CU; it is not a queue priority -- those made the chain slower, round 3).
+#ifndef DCA_CHAIN_PRIO_LEVEL
+#define DCA_CHAIN_PRIO_LEVEL 3
+#endif
+#define DCA_CHAIN_PRIO() __builtin_amdgcn_s_setprio(DCA_CHAIN_PRIO_LEVEL)
+
 struct GemmArgs {
     const double* A; int lda; int maskA;
     const double* B; int ldb; int maskB;
@@ -42,6 +50,10 @@ struct GemmArgs {
     int walk;                      // order in which the tiles are started, so that with a triangular operand the tiles with the
                                    // longest k range are not the ones that start last (WALK_*)
     int row0 = 0;                  // first tile row of this launch (WALK_ROWS only): a product issued as several row bands
+    // split-k form (gemm_nt_f64_dma_kernel only): blockIdx.z = slice of kChunk columns of the k range; slice z writes its partial
+    // product (alpha, beta = 0) to C + z * sliceStride -- summed in slice order by gemm_slices_reduce_kernel
+    int kSlices = 1, kChunk = 0;
+    size_t sliceStride = 0;
 };
 
 // BK = 16: the throughput form (35 KB of LDS, three workgroups per CU).  BK = 64: for the many products of
@@ -261,6 +273,7 @@ __device__ __forceinline__ void gemm_nt_f64_small_tile(const GemmArgs& g, int bx
     constexpr int LDS_STRIDE = BK + 2;
     constexpr int PG = BK / 16;
     typedef double double2_t __attribute__((ext_vector_type(2)));
+    DCA_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];
     double* const As = reinterpret_cast<double*>(dca_gemm_smem);      // [2][TM * LDS_STRIDE]
     double* const Bs = As + 2 * TM * LDS_STRIDE;
@@ -377,8 +390,12 @@ void gemm_nt_f64_small_pair_kernel(GemmArgs g0, int gx0, int gy0, GemmArgs g1, i
 // MFMA tiles per wave along M and N: <2,2> -> 64 x 64 output tile per workgroup, <4,4> -> 128 x 128 (twice the flop per
 // operand byte), <4,2> -> 128 x 64 (10.7 instead of 8 flop per operand byte at three workgroups per CU: for the products
 // with two triangular operands, where the 128 x 128 form loses to its tails)
-template <int TWM, int TWN = TWM>
-__global__ __launch_bounds__(256, (TWM == 4 && TWN == 4) ? 2 : (TWM == 4 || TWN == 4) ? 3 : 4)
+// KW = 2 (round 5): TWO groups of four waves in one workgroup work on the SAME output tile, group w on the k-tiles
+// t = w (mod 2), each with its own double-buffered operand tiles; group 1 hands its accumulators over through LDS at the end.
+// For the look-ahead bulk products, which run as ONE workgroup per CU so that whole CUs stay free for the chain: with four
+// waves a SIMD's matrix pipe idles whenever its only wave waits (48 TF with 240 workgroups), with eight it has a second one.
+template <int TWM, int TWN = TWM, int KW = 1>
+__global__ __launch_bounds__(256 * KW, KW == 2 ? 1 : (TWM == 4 && TWN == 4) ? 2 : (TWM == 4 || TWN == 4) ? 3 : 4)
 void gemm_nt_f64_dma_kernel(GemmArgs g)
 {
     constexpr int BK = 16;
@@ -391,14 +408,22 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
     const int tj = g.walk == WALK_COLUMNS_REVERSED ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x;
     if (g.lowerOnly && tj * BN >= (ti + 1) * BM) return;       // the tile lies entirely above the diagonal
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, waveAll = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = waveAll & 3, grp = waveAll >> 2;           // grp: the k-tile group of this wave (KW == 2)
     const int wm = wave >> 1, wn = wave & 1;
+    unsigned char* const smem = dca_gemm_smem + grp * 2 * (OPA + OPB);
 
     int kLo = 0, kHi = g.K;
     if (g.maskA == MASK_LOWER) kHi = min(kHi, (ti + 1) * BM);
     if (g.maskA == MASK_UPPER) kLo = max(kLo, ti * BM);
     if (g.maskB == MASK_LOWER) kHi = min(kHi, (tj + 1) * BN);
     if (g.maskB == MASK_UPPER) kLo = max(kLo, tj * BN);
+    double* Cout = g.C;
+    if (g.kSlices > 1) {
+        kLo = max(kLo, (int)blockIdx.z * g.kChunk);
+        kHi = min(kHi, ((int)blockIdx.z + 1) * g.kChunk);
+        Cout += (size_t)blockIdx.z * g.sliceStride;
+    }
     kLo = kLo / BK * BK;
     const int nk = (kHi - kLo + BK - 1) / BK;
 
@@ -429,15 +454,15 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
 #pragma unroll
         for (int i = 0; i < PWA; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * (OPA + OPB) + (PWA * wave + i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(smem + buf * (OPA + OPB) + (PWA * wave + i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < PWB; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(dca_gemm_smem + buf * (OPA + OPB) + OPA + (PWB * wave + i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(smem + buf * (OPA + OPB) + OPA + (PWB * wave + i) * 1024), 16, 0, 0);
     };
     const int fr = lane & 15, fg = lane >> 4, swz = (fr >> 1) & 7;
     auto mma_tile = [&](int buf, int k0) {
-        const unsigned char* as = dca_gemm_smem + buf * (OPA + OPB);
+        const unsigned char* as = smem + buf * (OPA + OPB);
         const unsigned char* bs = as + OPA;
         const bool diagA = g.maskA != MASK_NONE && k0 + BK > ti * BM && k0 < (ti + 1) * BM;    // wave-uniform
         const bool diagB = g.maskB != MASK_NONE && k0 + BK > tj * BN && k0 < (tj + 1) * BN;
@@ -491,15 +516,44 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
         }
     };
 
-    if (nk > 0) issue(0, kLo);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nk) issue(buf ^ 1, kLo + (t + 1) * BK);
-        mma_tile(buf, kLo + t * BK);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next tile have landed
-        __syncthreads();                                       // ... everyone's; and the tile just used may be overwritten
+    if constexpr (KW == 1) {
+        if (nk > 0) issue(0, kLo);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < nk) issue(buf ^ 1, kLo + (t + 1) * BK);
+            mma_tile(buf, kLo + t * BK);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next tile have landed
+            __syncthreads();                                       // ... everyone's; and the tile just used may be overwritten
+        }
+    } else {
+        // group grp takes the k-tiles grp, grp + KW, ...; both groups make the same number of trips (the barriers are the workgroup's)
+        const int trips = (nk + KW - 1) / KW;
+        if (grp < nk) issue(0, kLo + grp * BK);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int u = 0; u < trips; ++u) {
+            const int buf = u & 1, t = u * KW + grp;
+            if (t + KW < nk) issue(buf ^ 1, kLo + (t + KW) * BK);
+            if (t < nk) mma_tile(buf, kLo + t * BK);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // group 1 -> LDS -> group 0 (one double4 per lane and MFMA tile: 16 x 4 x 64 lanes x 32 B = 128 KiB, the operand buffers' space)
+        double4_t* const xfer = reinterpret_cast<double4_t*>(dca_gemm_smem);
+        if (grp == 1) {
+#pragma unroll
+            for (int m = 0; m < TWM; ++m)
+#pragma unroll
+                for (int n = 0; n < TWN; ++n) xfer[((m * TWN + n) * 4 + wave) * 64 + lane] = acc[m][n];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int m = 0; m < TWM; ++m)
+#pragma unroll
+            for (int n = 0; n < TWN; ++n) acc[m][n] += xfer[((m * TWN + n) * 4 + wave) * 64 + lane];
     }
 
 #pragma unroll
@@ -513,7 +567,7 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
                 if (i >= g.M || j >= g.N) continue;
                 if (g.lowerOnly && j > i) continue;
                 double v = g.alpha * acc[m][n][r];
-                double* cp = g.C + (size_t)i * g.ldc + j;
+                double* cp = Cout + (size_t)i * g.ldc + j;
                 if (g.beta != 0.0) v += g.beta * (*cp);
                 *cp = v;
                 if (g.Cm && !(g.lowerOnly && i == j)) g.Cm[(size_t)j * g.ldcm + i] = v;
@@ -829,6 +883,7 @@ template <int NB>
 __global__ __launch_bounds__(NB == 128 ? DCA_LEAF_WAVES128 * 64 : 320)
 void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info)
 {
+    DCA_CHAIN_PRIO();
     constexpr int NT = NB / 16;                       // tiles per side
     constexpr int NTILES = NT * (NT + 1) / 2;         // lower tiles
     constexpr int WAVES = NB == 128 ? DCA_LEAF_WAVES128 : 5;           // 8 x 64 = 4 NB lanes for step c.; 256 VGPRs for the unrolled 4 x 4 chain
@@ -1262,6 +1317,269 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     return DCA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: factorisation with look-ahead, triangular inverse as its own tree.
+//
+// cholinv_rec fuses factorisation and inversion in ONE serial walk: every leaf and every few-tile product of every level
+// lies on the critical path, and while they run (one workgroup, a handful of workgroups) the chip idles -- 9 of the 23 ms
+// at n = 10 048 for 17 % of the flop.  Here the walk is cut in two:
+//
+//  (a) Left-looking blocked Cholesky over panels of W columns.  The CHAIN (context stream) of panel j is
+//        X_jj = inv(chol(D_j))                 the fused recursion above on the W x W diagonal block only
+//        L_j  = A[below, j] X_jj^T             ONE product: the panel of the factor below the block (kept in `Lm`)
+//        D_j+1 -= L_j[top] L_j[top]^T          the next diagonal block's update from this panel (a few tiles)
+//      and everything else is BULK on a side stream, one panel ahead of the chain:
+//        A[below j+1, j+1] -= L_j[below] L_j[top]^T        rows of the next panel under its diagonal block (K = W)
+//        A[from j+2, j+2]  -= Lm[from j+2, 0 .. j] Lm[j+2, 0 .. j]^T     the panel after that, all earlier panels at once (deep K)
+//      issued as launches of at most 240 workgroups of 128 x 128 tiles: MI355X places one such workgroup per CU before it
+//      doubles up, so whole CUs stay free and the chain's single-workgroup leaves run next to the bulk at their own pace
+//      (tools/experiments/overlap_bench.hip).  Events order the two streams: the chain's panel product waits for the rows
+//      under its block, the diagonal update for the deep-K update of the same columns; the bulk waits for L_j.
+//  (b) X = L^-1 above the diagonal blocks as a tree of products X21 = -X22 (L21 X11) over Lm: no leaf, no chain -- every
+//      launch is a GEMM of at least 2 W rows.
+//  (c) inv(A) = X^T X as before.
+// Same arithmetic per product as the fused recursion; the sums are split at other places, so results differ from it
+// in the last places (both are ~1e-15 from LAPACK relative to the norm).
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    hipEvent_t get(size_t i)
+    {
+        while (ev.size() <= i) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            ev.push_back(e);
+        }
+        return ev[i];
+    }
+};
+std::mutex g_poolMu;
+std::vector<std::pair<SideSet*, EventPool*>> g_eventPools;     // one pool per side set, never destroyed (as the sets)
+EventPool* event_pool_of(SideSet* S)
+{
+    std::lock_guard<std::mutex> lk(g_poolMu);
+    for (auto& p : g_eventPools) if (p.first == S) return p.second;
+    g_eventPools.emplace_back(S, new EventPool());
+    return g_eventPools.back().second;
+}
+
+// A product on `stream` as 128 x 128 tiles in launches of at most maxWGs ACTIVE workgroups each (bands of tile rows of about
+// equal tile count; with lowerOnly the tiles right of the diagonal are not launched).  WALK_ROWS only.
+// the bulk kernel: 128 x 128 tiles; DCA_CHOLINV_BULK_KW=2 selects the eight-wave form (two k-tile groups per workgroup)
+static int bulk_kw()
+{
+    // measured at n = 10 048: 1 -> 21.6 ms, 2 -> 22.3 ms.  The eight-wave form is faster per product but takes the whole register file of
+    // its CU, so the chain's few-tile products find no room beside it (their average goes from 15 to 21 us, single ones wait 280 us)
+    static const int v = (getenv("DCA_CHOLINV_BULK_KW") && atoi(getenv("DCA_CHOLINV_BULK_KW")) == 2) ? 2 : 1;
+    return v;
+}
+int bulk_kernel_prepare()
+{
+    static std::atomic<bool> done{false};
+    if (!done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 16 * 8));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 16 * 8));
+        done = true;
+    }
+    return DCA_OK;
+}
+void bulk_kernel_launch(hipStream_t stream, dim3 grid, const GemmArgs& g)
+{
+    if (bulk_kw() == 2) hipLaunchKernelGGL((gemm_nt_f64_dma_kernel<4, 4, 2>), grid, dim3(512), (size_t)8 * 128 * 16 * sizeof(double), stream, g);
+    else hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<4>, grid, dim3(256), (size_t)4 * 128 * 16 * sizeof(double), stream, g);
+}
+
+int launch_gemm_capped(hipStream_t stream, GemmArgs g, int maxWGs)
+{
+    DCA_TRY(bulk_kernel_prepare());
+    const int gx = (g.N + 127) / 128, gy = (g.M + 127) / 128;
+    auto active = [&](int r) { return g.lowerOnly ? std::min(gx, r + 1) : gx; };
+    long long total = 0;
+    for (int r = 0; r < gy; ++r) total += active(r);
+    const int bands = (int)((total + maxWGs - 1) / maxWGs);
+    const long long target = (total + bands - 1) / std::max(1, bands);
+    for (int r = 0; r < gy;) {
+        int r1 = r;
+        long long wgs = 0;
+        while (r1 < gy && (r1 == r || (wgs + active(r1) <= maxWGs && wgs < target))) wgs += active(r1++);
+        g.row0 = r;
+        bulk_kernel_launch(stream, dim3(active(r1 - 1), r1 - r), g);
+        r = r1;
+    }
+    HIP_TRY(hipGetLastError());
+    return DCA_OK;
+}
+
+// C[i][j] -= sum_z P[z][i][j] in slice order (the partial products of a split-k launch; P rows are N long)
+__global__ __launch_bounds__(256)
+void gemm_slices_reduce_kernel(double* __restrict__ C, int ldc, const double* __restrict__ P, size_t sliceStride, int slices, int M, int N)
+{
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    const size_t pairs = (size_t)M * N / 2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < pairs; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = 2 * e / N, j = 2 * e % N;
+        double2_t s = *reinterpret_cast<const double2_t*>(P + 2 * e);
+        for (int z = 1; z < slices; ++z) s += *reinterpret_cast<const double2_t*>(P + (size_t)z * sliceStride + 2 * e);
+        double2_t* cp = reinterpret_cast<double2_t*>(C + i * ldc + j);
+        *cp -= s;
+    }
+}
+
+// tile rows per launch of a split-k product: as many as fit under the cap, evened out over the launches
+static int splitk_band_rows(int gx, int gy, int slices, int maxWGs)
+{
+    const int fit = std::max(1, maxWGs / (gx * slices));
+    const int bands = (gy + fit - 1) / fit;
+    return (gy + bands - 1) / bands;
+}
+
+// C -= A B^T (no masks, every tile) on `stream` with the k range cut into `slices` concurrent partial products: for the
+// tall, narrow, deep-k updates of the look-ahead factorisation, whose few output tiles would otherwise each walk the whole
+// k range on one CU while the others idle.  At most maxWGs workgroups per launch, as launch_gemm_capped.
+int launch_gemm_splitk_capped(hipStream_t stream, const double* A, int lda, const double* B, int ldb, double* C, int ldc, int M, int N, int K,
+                              int slices, double* P, int maxWGs)
+{
+    GemmArgs g{A, lda, MASK_NONE, B, ldb, MASK_NONE, P, N, nullptr, 0, M, N, K, 1.0, 0.0, 0};
+    g.kSlices = slices;
+    g.kChunk = ((K + slices - 1) / slices + 15) / 16 * 16;
+    g.sliceStride = (size_t)M * N;
+    DCA_TRY(bulk_kernel_prepare());
+    const int gx = (N + 127) / 128, gy = (M + 127) / 128;
+    const int rows = splitk_band_rows(gx, gy, slices, maxWGs);
+    for (int r = 0; r < gy; r += rows) {
+        g.row0 = r;
+        bulk_kernel_launch(stream, dim3(gx, std::min(rows, gy - r), slices), g);
+    }
+    hipLaunchKernelGGL(gemm_slices_reduce_kernel, dim3(std::min<size_t>(2048, ((size_t)M * N / 2 + 255) / 256)), dim3(256), 0, stream, C, ldc, P, g.sliceStride, slices, M, N);
+    HIP_TRY(hipGetLastError());
+    return DCA_OK;
+}
+
+struct BlockedCfg { int W, cap, overlap, minN, splitMinK, roundK; };
+static const BlockedCfg& blocked_cfg()
+{
+    static const BlockedCfg c = [] {
+        // measured (tools/experiments/inv_sizes.sh; fused walk -> blocked, ms): n = 4032 3.75 -> 3.83, 5056 5.33 -> 5.24, 6016 8.00 -> 7.53,
+        // 8000 14.36 -> 12.62, 10 048 23.48 -> 21.83; panels of 256 / 1024 columns lose 0.1 - 0.8 ms at every size
+        BlockedCfg v{512, 248, 1, 5000, 512, 300};
+        if (const char* e = getenv("DCA_CHOLINV_PANEL")) v.W = std::max(128, atoi(e) / 128 * 128);   // 0 / unparsable -> 128; DCA_CHOLINV_BLOCKED=0 selects the fused walk
+        if (const char* e = getenv("DCA_CHOLINV_SIDE_CAP")) v.cap = std::max(1, atoi(e));
+        if (const char* e = getenv("DCA_CHOLINV_OVERLAP")) v.overlap = atoi(e);
+        if (const char* e = getenv("DCA_CHOLINV_BLOCKED_MIN")) v.minN = atoi(e);
+        if (const char* e = getenv("DCA_CHOLINV_ROUNDK")) v.roundK = atoi(e);
+        if (const char* e = getenv("DCA_CHOLINV_SPLITK_MIN")) v.splitMinK = atoi(e);       // k per slice at least this (0: never split)
+        if (const char* e = getenv("DCA_CHOLINV_BLOCKED")) if (atoi(e) == 0) v.minN = INT_MAX;
+        return v;
+    }();
+    return c;
+}
+
+// X = L^-1 above the diagonal blocks b[lo] .. b[hi]: X21 = -X22 (L21 X11) per node, children first
+int trtri_tree(dca_ctx* ctx, double* A, const double* Lm, int ld, const std::vector<int>& b, int lo, int hi, Arena& ws)
+{
+    if (hi - lo <= 1) return DCA_OK;
+    int mid = lo + 1;                                            // the split nearest to half of the columns
+    for (int k = lo + 1; k < hi; ++k)
+        if (std::abs(2 * b[k] - b[lo] - b[hi]) < std::abs(2 * b[mid] - b[lo] - b[hi])) mid = k;
+    DCA_TRY(trtri_tree(ctx, A, Lm, ld, b, lo, mid, ws));
+    DCA_TRY(trtri_tree(ctx, A, Lm, ld, b, mid, hi, ws));
+    const int n1 = b[mid] - b[lo], n2 = b[hi] - b[mid];
+    double* M11 = A + (size_t)b[lo] * ld + b[lo];
+    double* M12 = A + (size_t)b[lo] * ld + b[mid];
+    double* M21 = A + (size_t)b[mid] * ld + b[lo];
+    double* M22 = A + (size_t)b[mid] * ld + b[mid];
+    const double* L21 = Lm + (size_t)b[mid] * ld + b[lo];
+    const size_t mark = ws.top;
+    double* Tt = ws.alloc((size_t)n1 * n2);
+    if (!Tt) { dca_set_error("cholinv workspace exhausted"); return DCA_ERR_NOMEM; }
+    // T^T[j][i] = sum_k X11^T[j][k] L21[i][k]  (X11^T rows: the mirrored upper part, k >= j), then X21[i][j] = -sum_k X22[i][k] T^T[j][k]
+    DCA_TRY(launch_gemm(ctx, GemmArgs{M11, ld, MASK_UPPER, L21, ld, MASK_NONE, Tt, n2, nullptr, 0, n1, n2, n1, 1.0, 0.0, 0}));
+    DCA_TRY(launch_gemm(ctx, GemmArgs{M22, ld, MASK_LOWER, Tt, n2, MASK_NONE, M21, ld, M12, ld, n2, n1, n2, -1.0, 0.0, 0, WALK_ROWS_REVERSED}));
+    ws.top = mark;
+    return DCA_OK;
+}
+
+int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* dInfo, SideSet* side)
+{
+    const BlockedCfg& cfg = blocked_cfg();
+    const int ld = n, W = cfg.W;
+    std::vector<int> b;
+    for (int c = 0; c < n; c += W) b.push_back(c);
+    b.push_back(n);
+    const int nb = (int)b.size() - 1;
+    EventPool* pool = (side && cfg.overlap) ? event_pool_of(side) : nullptr;
+    const bool twoStreams = pool != nullptr;
+    hipStream_t bulk = twoStreams ? side->s[0] : ctx->stream;
+    // events: 3 j trsm (L_j complete), 3 j + 1 rows (rows of panel j under its block complete), 3 j + 2 deep (deep-K update of panel j complete)
+    auto ev = [&](int kind, int j) { return pool->get((size_t)3 * j + kind); };
+    if (twoStreams && !ev(2, nb)) { dca_set_error("cholinv: event creation failed"); return DCA_ERR_HIP; }
+    // partial products of the split-k updates: a fixed piece at the top of the arena (the chain's diagonal blocks use its bottom)
+    const size_t sidePartialsCap = ws.cap / 2;
+    double* sidePartials = ws.base + (ws.cap - sidePartialsCap);
+    Arena chainWs{ws.base, ws.cap - sidePartialsCap};
+    int rc = DCA_OK;
+    bool bulkInFlight = false;
+    auto bail = [&](int r) -> int {
+        if (twoStreams && bulkInFlight) hipStreamSynchronize(bulk);     // the bulk writes A and reads Lm: drain it before the caller may free them
+        return r;
+    };
+    for (int j = 0; j < nb && rc == DCA_OK; ++j) {
+        const int c = b[j], w = b[j + 1] - c, m = n - c - w;
+        double* D = A + (size_t)c * ld + c;
+        if ((rc = cholinv_rec(ctx, D, ld, w, c, chainWs, dInfo, nullptr)) != DCA_OK) break;
+        if (m == 0) break;
+        // ---- chain: the panel of the factor below the block
+        if (twoStreams && j > 0) HIP_TRY(hipStreamWaitEvent(ctx->stream, ev(1, j), 0));
+        double* Lj = Lm + (size_t)(c + w) * ld + c;
+        if ((rc = launch_gemm(ctx, GemmArgs{A + (size_t)(c + w) * ld + c, ld, MASK_NONE, D, ld, MASK_LOWER, Lj, ld, nullptr, 0, m, w, w, 1.0, 0.0, 0, WALK_COLUMNS_REVERSED})) != DCA_OK) break;
+        if (twoStreams) {
+            HIP_TRY(hipEventRecord(ev(0, j), ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(bulk, ev(0, j), 0));
+        }
+        const int w1 = b[j + 2] - b[j + 1];
+        // ---- bulk: rows of panel j + 1 under its diagonal block, from L_j
+        if (m - w1 > 0) {
+            if ((rc = launch_gemm_capped(bulk, GemmArgs{Lj + (size_t)w1 * ld, ld, MASK_NONE, Lj, ld, MASK_NONE, A + (size_t)(c + w + w1) * ld + c + w, ld, nullptr, 0,
+                                                         m - w1, w1, w, -1.0, 1.0, 0}, cfg.cap)) != DCA_OK) break;
+            bulkInFlight = true;
+            if (twoStreams) HIP_TRY(hipEventRecord(ev(1, j + 1), bulk));
+            // ---- bulk: panel j + 2 from all the panels up to j at once
+            const int c2 = b[j + 2], w2 = b[j + 3 <= nb ? j + 3 : nb] - c2;
+            if (w2 > 0) {
+                const double* Lrows = Lm + (size_t)c2 * ld;
+                // few output tiles and a deep k range: split k so that the launch has about `cap` workgroups
+                const int K = c + w;
+                // a launch of T tiles in s slices takes ceil(T s / cap) rounds of K / s (+ the tile's fixed part, ~64 k) each
+                int slices = 1;
+                if (cfg.splitMinK > 0) {
+                    const int maxS = std::min({K / cfg.splitMinK, 16, (int)(sidePartialsCap / ((size_t)(n - c2) * w2))});
+                    const int gx2 = (w2 + 127) / 128, gy2 = (n - c2 + 127) / 128;
+                    long long best = LLONG_MAX;
+                    for (int sl = 1; sl <= maxS || sl == 1; ++sl) {
+                        // launches x (k per slice + what a launch costs beside its k walk, in k units: ~40 us)
+                        const int rows = splitk_band_rows(gx2, gy2, sl, cfg.cap);
+                        const long long cost = (long long)((gy2 + rows - 1) / rows) * (K / sl + cfg.roundK);
+                        if (cost < best) { best = cost; slices = sl; }
+                    }
+                }
+                if (slices > 1) rc = launch_gemm_splitk_capped(bulk, Lrows, ld, Lrows, ld, A + (size_t)c2 * ld + c2, ld, n - c2, w2, K, slices, sidePartials, cfg.cap);
+                else rc = launch_gemm_capped(bulk, GemmArgs{Lrows, ld, MASK_NONE, Lrows, ld, MASK_NONE, A + (size_t)c2 * ld + c2, ld, nullptr, 0,
+                                                            n - c2, w2, K, -1.0, 1.0, 1}, cfg.cap);
+                if (rc != DCA_OK) break;
+                if (twoStreams) HIP_TRY(hipEventRecord(ev(2, j + 2), bulk));
+            }
+        }
+        // ---- chain: the next diagonal block from L_j (after the deep-K update of the same block)
+        if (twoStreams && j >= 1) HIP_TRY(hipStreamWaitEvent(ctx->stream, ev(2, j + 1), 0));
+        if ((rc = launch_gemm(ctx, GemmArgs{Lj, ld, MASK_NONE, Lj, ld, MASK_NONE, A + (size_t)(c + w) * ld + c + w, ld, nullptr, 0, w1, w1, w, -1.0, 1.0, 1})) != DCA_OK) break;
+    }
+    if (rc != DCA_OK) return bail(rc);
+    if (twoStreams && bulkInFlight) {
+        HIP_TRY(hipEventRecord(ev(0, nb), bulk));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ev(0, nb), 0));
+    }
+    return trtri_tree(ctx, A, Lm, ld, b, 0, nb, ws);
+}
+
 }  // namespace
 
 int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* info_out, double scale, double** result)
@@ -1278,7 +1596,9 @@ int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* 
         // a set of side streams only where the recursion will use one (see cholinv_rec); everything they run is joined
         // into ctx->stream before the recursion returns, so the set can go back as soon as the launches are enqueued
         SideSet* side = n >= 2048 ? side_set_acquire(ctx->device) : nullptr;
-        rc = cholinv_rec(ctx, dA, n, n, 0, ws, dInfo, side);
+        // the blocked form keeps the factor's panels in the second half of the workspace, which X^T X overwrites at the end
+        if (n >= blocked_cfg().minN && n > 2 * blocked_cfg().W) rc = cholinv_blocked(ctx, dA, n, ws, dWork + (size_t)n * n, dInfo, side);
+        else rc = cholinv_rec(ctx, dA, n, n, 0, ws, dInfo, side);
         side_set_release(side);
     }
     if (rc == DCA_OK) {

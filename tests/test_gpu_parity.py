@@ -329,6 +329,48 @@ def test_spd_inverse_alternative_leaves(env):
     assert float(p.stdout.strip().splitlines()[-1]) < 1e-11
 
 
+@pytest.mark.parametrize("env", [{"DCA_CHOLINV_PANEL": "128"}, {"DCA_CHOLINV_PANEL": "128", "DCA_CHOLINV_OVERLAP": "0"},
+                                 {"DCA_CHOLINV_PANEL": "256", "DCA_CHOLINV_SIDE_CAP": "7"}, {"DCA_CHOLINV_PANEL": "128", "DCA_CHOLINV_BULK_KW": "2"}])
+def test_spd_inverse_blocked_form_at_small_sizes(env):
+    """Round 5: the look-ahead factorisation + separate triangular-inverse tree (cholinv_blocked) is what runs for n >= 5000;
+    forced here onto small matrices (panels of 128 / 256 columns, split-k from 128 columns on, one stream, tiny launch caps,
+    the eight-wave bulk kernel) so that every branch of it -- ragged last panel, split-k with its reduction, band
+    splitting, the event chain -- is compared with LAPACK."""
+    import subprocess
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from pydca_amd import _lib\n"
+        "worst = 0.0\n"
+        "for n in (320, 448, 500, 1000, 1472, 2100):\n"
+        "    rng = np.random.default_rng(n); B = rng.standard_normal((n, n + 8)); A = B @ B.T / n + 0.5 * np.diag(rng.random(n) + 0.5)\n"
+        "    ctx = _lib.Context(0, _lib.DCA_F64); inv = ctx.spd_inverse(A); ctx.close(); ref = np.linalg.inv(A)\n"
+        "    worst = max(worst, float(np.linalg.norm(inv - ref) / np.linalg.norm(ref))); assert np.array_equal(inv, inv.T)\n"
+        "A[7, 7] = -1.0\n"
+        "ctx = _lib.Context(0, _lib.DCA_F64)\n"
+        "try:\n"
+        "    ctx.spd_inverse(A); raise SystemExit('an indefinite matrix was accepted')\n"
+        "except _lib.DcaBackendError as e:\n"
+        "    assert e.code == _lib.DCA_ERR_NOT_SPD, e\n"
+        "print(worst)\n" % ROOT)
+    full = dict(os.environ, DCA_CHOLINV_BLOCKED_MIN="0", DCA_CHOLINV_SPLITK_MIN="128", **env)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=full)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert float(p.stdout.strip().splitlines()[-1]) < 1e-11
+
+
+def test_spd_inverse_blocked_form_at_its_own_size(L_):
+    """n = 5056: above the size from which dca_spd_inverse_device takes the blocked form by itself (default settings)."""
+    n = 5056
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n + 8))
+    A = B @ B.T / n + 0.5 * np.diag(rng.random(n) + 0.5)
+    ctx = L_.Context(0, L_.DCA_F64)
+    inv = ctx.spd_inverse(A)
+    ctx.close()
+    assert rel_err(inv, np.linalg.inv(A)) < 1e-11
+    assert np.array_equal(inv, inv.T)
+
+
 def test_scores_kernel(L_, oracle_mf):
     """FN / FN_APC kernel vs plmdca.py:437-524 restated in numpy (float64)."""
     rng = np.random.default_rng(3)

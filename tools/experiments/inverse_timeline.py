@@ -8,7 +8,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 min_us = float(sys.argv[3]) if len(sys.argv) > 3 else 150.0
-g = [r for r in rows if "gemm_nt" in r["Kernel_Name"] or "leaf" in r["Kernel_Name"]]
+g = [r for r in rows if "gemm_" in r["Kernel_Name"] or "leaf" in r["Kernel_Name"]]
 g.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last repetition: launches after the last gap of more than 2 ms
 cut = 0
