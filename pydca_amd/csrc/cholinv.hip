@@ -1045,6 +1045,25 @@ struct Arena {
     double* alloc(size_t n) { if (top + n > cap) return nullptr; double* p = base + top; top += n; return p; }
 };
 
+// Dynamic LDS sizes above the default limit need an attribute per kernel AND PER DEVICE; set for all of them the first time an
+// inverse runs on a device (contexts may live on several host threads and several devices).
+int gemm_kernels_prepare(int device)
+{
+    static std::mutex mu;
+    static std::vector<int> done;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int d : done) if (d == device) return DCA_OK;
+    const int small = (int)((size_t)2 * (32 + 32) * (64 + 2) * sizeof(double));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 16 * 8));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 16 * 8));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 16 * 8));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, small));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, small));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<64>()));
+    done.push_back(device);
+    return DCA_OK;
+}
+
 // Background form of a product (side stream of the recursion): 128 x 128 tiles, issued as bands of tile rows of at most
 // `maxWGs` workgroups each.  MI355X places one such workgroup per CU before it doubles up, so a launch of fewer
 // workgroups than CUs leaves whole CUs to the kernels of another stream: the chain of single-workgroup leaves and
@@ -1053,11 +1072,6 @@ struct Arena {
 // 256).  WALK_ROWS only.
 int launch_gemm_banded(dca_ctx* ctx, hipStream_t stream, GemmArgs g, int maxWGs)
 {
-    static std::atomic<bool> attr128{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
-    if (!attr128) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 16 * 8));
-        attr128 = true;
-    }
     const int gx = (g.N + 127) / 128, gy = (g.M + 127) / 128;
     const int band = std::max(1, maxWGs / gx);
     for (int r = 0; r < gy; r += band) {
@@ -1082,11 +1096,6 @@ bool launch_gemm_small_pair(dca_ctx* ctx, const GemmArgs& a, const GemmArgs& b)
     const dim3 ga = grid64(a), gb = grid64(b);
     if (!on || (long long)ga.x * ga.y > small32_max() || (long long)gb.x * gb.y > small32_max()) return false;
     const size_t lds = (size_t)2 * (32 + 32) * (64 + 2) * sizeof(double);
-    static std::atomic<bool> attr{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        attr = true;
-    }
     const dim3 grid(std::max(ga.x, gb.x) * 2, std::max(ga.y, gb.y) * 2, 2);
     hipLaunchKernelGGL(gemm_nt_f64_small_pair_kernel, grid, dim3(256), lds, ctx->stream, a, (int)ga.x * 2, (int)ga.y * 2, b, (int)gb.x * 2, (int)gb.y * 2);
     return true;
@@ -1102,21 +1111,10 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
     if ((long long)grid.x * grid.y <= small32Max) {          // far fewer tiles than CUs: 32 x 32 tiles on four times as many CUs
         dim3 g32(grid.x * 2, grid.y * 2);
         const size_t lds = (size_t)2 * (32 + 32) * (64 + 2) * sizeof(double);
-        static std::atomic<bool> attr32{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
-        if (!attr32) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr32 = true;
-        }
         hipLaunchKernelGGL(gemm_nt_f64_small_kernel, g32, dim3(256), lds, ctx->stream, g);
         return DCA_OK;
     }
     if ((long long)grid.x * grid.y <= deepMaxTiles) {       // under two workgroups per CU: latency bound (measured: 0 -> 37.7, 128 -> 37.0, 400 -> 36.4, 1600 -> 36.9 ms)
-        static std::atomic<bool> attr{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
-        if (!attr) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)gemm_lds_bytes<64>()));
-            attr = true;
-        }
         hipLaunchKernelGGL(gemm_nt_f64_kernel<64>, grid, dim3(256), gemm_lds_bytes<64>(), ctx->stream, g);
     } else {
         static const bool ahead2 = getenv("DCA_GEMM_AHEAD2") && atoi(getenv("DCA_GEMM_AHEAD2")) != 0;
@@ -1141,18 +1139,8 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
             const bool walkOk = g.walk != WALK_COLUMNS_REVERSED;
             if (!use128 && walkOk && rect && (masks == 2 || (rect == 2 && masks == 1)) && (long long)grid.x * grid.y >= 2048) {
                 // 128 x 64 tiles: grid.y counts 128-row tiles
-                static std::atomic<bool> attrR{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
-                if (!attrR) {
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 16 * 8));
-                    attrR = true;
-                }
                 hipLaunchKernelGGL((gemm_nt_f64_dma_kernel<4, 2>), dim3(grid.x, gy), dim3(256), (size_t)2 * (128 + 64) * 16 * sizeof(double), ctx->stream, g);
             } else if (use128) {
-                static std::atomic<bool> attr128{false};      // idempotent call; the flag only saves repeating it (contexts may live on several host threads)
-                if (!attr128) {
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 16 * 8));
-                    attr128 = true;
-                }
                 dim3 grid128(gx, gy);
                 if (g.walk == WALK_COLUMNS_REVERSED) grid128 = dim3((g.M + 127) / 128, (g.N + 127) / 128);
                 hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<4>, grid128, dim3(256), (size_t)4 * 128 * 16 * sizeof(double), ctx->stream, g);
@@ -1372,16 +1360,6 @@ static int bulk_kw()
     static const int v = (getenv("DCA_CHOLINV_BULK_KW") && atoi(getenv("DCA_CHOLINV_BULK_KW")) == 2) ? 2 : 1;
     return v;
 }
-int bulk_kernel_prepare()
-{
-    static std::atomic<bool> done{false};
-    if (!done) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 16 * 8));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 16 * 8));
-        done = true;
-    }
-    return DCA_OK;
-}
 void bulk_kernel_launch(hipStream_t stream, dim3 grid, const GemmArgs& g)
 {
     if (bulk_kw() == 2) hipLaunchKernelGGL((gemm_nt_f64_dma_kernel<4, 4, 2>), grid, dim3(512), (size_t)8 * 128 * 16 * sizeof(double), stream, g);
@@ -1390,7 +1368,6 @@ void bulk_kernel_launch(hipStream_t stream, dim3 grid, const GemmArgs& g)
 
 int launch_gemm_capped(hipStream_t stream, GemmArgs g, int maxWGs)
 {
-    DCA_TRY(bulk_kernel_prepare());
     const int gx = (g.N + 127) / 128, gy = (g.M + 127) / 128;
     auto active = [&](int r) { return g.lowerOnly ? std::min(gx, r + 1) : gx; };
     long long total = 0;
@@ -1442,7 +1419,6 @@ int launch_gemm_splitk_capped(hipStream_t stream, const double* A, int lda, cons
     g.kSlices = slices;
     g.kChunk = ((K + slices - 1) / slices + 15) / 16 * 16;
     g.sliceStride = (size_t)M * N;
-    DCA_TRY(bulk_kernel_prepare());
     const int gx = (N + 127) / 128, gy = (M + 127) / 128;
     const int rows = splitk_band_rows(gx, gy, slices, maxWGs);
     for (int r = 0; r < gy; r += rows) {
@@ -1585,6 +1561,7 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
 int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* info_out, double scale, double** result)
 {
     if (n % 64 != 0 || n <= 0) { dca_set_error("dca_spd_inverse_device: n must be a positive multiple of 64"); return DCA_ERR_ARG; }
+    DCA_TRY(gemm_kernels_prepare(ctx->device));
     ScopedKernelClock kc(ctx, "mf_inverse");
     int* dInfo = nullptr;
     HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dInfo), sizeof(int)));

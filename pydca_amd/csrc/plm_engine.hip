@@ -769,7 +769,7 @@ constexpr int kVecThreads = 256;
 // iv*VEC + k; the n % VEC tail is handled by the first threads with scalar accesses.  The mapping
 // of elements to threads is fixed, so every reduction is deterministic.
 template <typename T> struct Pack { T v[16 / sizeof(T)]; };
-template <typename T> __device__ __forceinline__ Pack<T> ldp(const T* p, size_t iv)
+template <typename T> __device__ __forceinline__ Pack<T> ldp_at(const T* p, size_t iv)
 {
     using V = typename V16<T>::type;
     const V r = reinterpret_cast<const V*>(p)[iv];
@@ -778,7 +778,7 @@ template <typename T> __device__ __forceinline__ Pack<T> ldp(const T* p, size_t 
     else { o.v[0] = r.x; o.v[1] = r.y; }
     return o;
 }
-template <typename T> __device__ __forceinline__ void stp(T* p, size_t iv, const Pack<T>& o)
+template <typename T> __device__ __forceinline__ void stp_at(T* p, size_t iv, const Pack<T>& o)
 {
     using V = typename V16<T>::type;
     V r;
@@ -786,19 +786,32 @@ template <typename T> __device__ __forceinline__ void stp(T* p, size_t iv, const
     else { r.x = o.v[0]; r.y = o.v[1]; }
     reinterpret_cast<V*>(p)[iv] = r;
 }
-#define DCA_VEC_LOOP(n, BODY_PACK, BODY_TAIL)                                                             \
+// The vectors of one call all start at the SAME element offset of 256-byte aligned allocations (base + vlo), so they share
+// their misalignment.  With sequence sharding vlo is a multiple of four elements (set_slices); with column strips (exchange
+// mode 4) it is the start of the rank's pair range, L q + pairs q^2 -- any parity.  ALIGNP names one of the vectors: the
+// head_ elements in front of its first 16-byte boundary are handled with the tail, one element per thread, and the packs
+// start at that boundary (ldp / stp inside the loop body index from there), so every 16-byte access is aligned.
+#define ldp(p, iv) ldp_at((p) + head_, iv)
+#define stp(p, iv, o) stp_at((p) + head_, iv, o)
+#define DCA_VEC_LOOP(n, ALIGNP, BODY_PACK, BODY_TAIL)                                                     \
     {                                                                                                      \
         constexpr int VEC = 16 / (int)sizeof(T);                                                           \
-        const size_t nv_ = (n) / VEC, stride_ = (size_t)gridDim.x * blockDim.x;                            \
+        const size_t lead_ = ((16 - (reinterpret_cast<uintptr_t>(ALIGNP) & 15)) & 15) / sizeof(T);         \
+        const size_t head_ = lead_ < (size_t)(n) ? lead_ : (size_t)(n);                                    \
+        const size_t nv_ = ((n) - head_) / VEC, stride_ = (size_t)gridDim.x * blockDim.x;                  \
         const size_t t0_ = blockIdx.x * (size_t)blockDim.x + threadIdx.x;                                  \
         for (size_t iv = t0_; iv < nv_; iv += stride_) { BODY_PACK }                                       \
-        for (size_t i = nv_ * VEC + t0_; i < (n); i += stride_) { BODY_TAIL }                              \
+        const size_t rest_ = (n) - nv_ * VEC;                     /* head_ + tail, fewer than 2 VEC */      \
+        for (size_t r_ = t0_; r_ < rest_; r_ += stride_) {                                                 \
+            const size_t i = r_ < head_ ? r_ : r_ + nv_ * VEC;                                             \
+            BODY_TAIL                                                                                      \
+        }                                                                                                  \
     }
 
 template <typename T>
 __global__ void vec_neg_kernel(T* __restrict__ d, const T* __restrict__ g, size_t n)
 {
-    DCA_VEC_LOOP(n,
+    DCA_VEC_LOOP(n, d,
         Pack<T> a = ldp(g, iv);
         _Pragma("unroll") for (int k = 0; k < VEC; ++k) a.v[k] = -a.v[k];
         stp(d, iv, a);,
@@ -807,7 +820,7 @@ __global__ void vec_neg_kernel(T* __restrict__ d, const T* __restrict__ g, size_
 template <typename T>
 __global__ void vec_axpy_kernel(T* __restrict__ y, T a, const T* __restrict__ x, size_t n)
 {
-    DCA_VEC_LOOP(n,
+    DCA_VEC_LOOP(n, y,
         Pack<T> yy = ldp(y, iv); const Pack<T> xx = ldp(x, iv);
         _Pragma("unroll") for (int k = 0; k < VEC; ++k) yy.v[k] += a * xx.v[k];
         stp(y, iv, yy);,
@@ -816,7 +829,7 @@ __global__ void vec_axpy_kernel(T* __restrict__ y, T a, const T* __restrict__ x,
 template <typename T>
 __global__ void vec_scale_kernel(T* __restrict__ y, T a, size_t n)
 {
-    DCA_VEC_LOOP(n,
+    DCA_VEC_LOOP(n, y,
         Pack<T> yy = ldp(y, iv);
         _Pragma("unroll") for (int k = 0; k < VEC; ++k) yy.v[k] *= a;
         stp(y, iv, yy);,
@@ -826,7 +839,7 @@ __global__ void vec_scale_kernel(T* __restrict__ y, T a, size_t n)
 template <typename T>
 __global__ void vec_step_kernel(T* __restrict__ x, const T* __restrict__ xp, T stpv, const T* __restrict__ d, size_t n)
 {
-    DCA_VEC_LOOP(n,
+    DCA_VEC_LOOP(n, x,
         const Pack<T> dd = ldp(d, iv); Pack<T> xx = ldp(xp, iv);
         _Pragma("unroll") for (int k = 0; k < VEC; ++k) { const T v = stpv * dd.v[k]; xx.v[k] = xx.v[k] + v; }
         stp(x, iv, xx);,
@@ -885,7 +898,7 @@ void vec_dot3_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* 
 {
     __shared__ double red[kVecThreads / 64][6];
     DotAcc<sizeof(T) == 8> s0, s1, s2;
-    DCA_VEC_LOOP(n,
+    DCA_VEC_LOOP(n, a,
         const Pack<T> pa = ldp(a, iv); const Pack<T> pb = ldp(b, iv); const Pack<T> pc = ldp(c, iv);
         _Pragma("unroll") for (int k = 0; k < VEC; ++k) {
             const double av = pa.v[k]; const double bv = pb.v[k]; const double cv = pc.v[k];
@@ -905,7 +918,7 @@ void vec_dot_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n, 
 {
     __shared__ double red[kVecThreads / 64][2];
     DotAcc<sizeof(T) == 8> s0;
-    DCA_VEC_LOOP(n,
+    DCA_VEC_LOOP(n, a,
         const Pack<T> pa = ldp(a, iv); const Pack<T> pb = ldp(b, iv);
         _Pragma("unroll") for (int k = 0; k < VEC; ++k) s0.add((double)pa.v[k], (double)pb.v[k]);,
         s0.add((double)a[i], (double)b[i]);)
@@ -984,7 +997,7 @@ void vec_diff_gram_kernel(VecPtrs5 P, T* __restrict__ se, T* __restrict__ ye, co
 {
     __shared__ double red[kVecThreads / 64][54];
     DotAcc<sizeof(T) == 8> acc[27];
-    DCA_VEC_LOOP(n,
+    DCA_VEC_LOOP(n, se,
         const Pack<T> px = ldp(x, iv); const Pack<T> pxp = ldp(xp, iv); const Pack<T> pg = ldp(g, iv); const Pack<T> pgp = ldp(gp, iv);
         Pack<T> pse; Pack<T> pye;
         _Pragma("unroll") for (int u = 0; u < VEC; ++u) {
@@ -1022,7 +1035,7 @@ template <typename T>
 __global__ void vec_compose_kernel(T* __restrict__ d, const T* __restrict__ g, VecPtrs5 P, const DirCoefs* __restrict__ cp, size_t n)
 {
     const DirCoefs c = *cp;
-    DCA_VEC_LOOP(n,
+    DCA_VEC_LOOP(n, d,
         const Pack<T> pg = ldp(g, iv);
         double v[VEC];
         _Pragma("unroll") for (int u = 0; u < VEC; ++u) v[u] = c.g * (double)pg.v[u];
@@ -1038,6 +1051,8 @@ __global__ void vec_compose_kernel(T* __restrict__ d, const T* __restrict__ g, V
               v += c.s[k] * (double)static_cast<const T*>(P.s[k])[i] + c.y[k] * (double)static_cast<const T*>(P.y[k])[i];
           d[i] = (T)v; })
 }
+#undef ldp
+#undef stp
 
 // out[k] = sum_b of the (hi, lo) pairs partials[2 * (k*nb + b)], k < nk, rounded once; one block per k, fixed tree
 __global__ __launch_bounds__(256)
@@ -1314,6 +1329,9 @@ struct PlmEngine : PlmEngineBase {
         if (!ctx->have_weights) { dca_set_error("weights must be computed or set before dca_plm_configure"); return DCA_ERR_STATE; }
         if (halo_ < 0 || halo_ >= N) { dca_set_error("halo out of range"); return DCA_ERR_ARG; }
         if (L > 65535) { dca_set_error("L too large"); return DCA_ERR_ARG; }
+        // from here on members are overwritten: an engine that fails below must not keep running with the half-updated window
+        // (arrays, siteB and the receive offsets would still be sized for the old one)
+        configured = false;
         lambda_h = lh; lambda_J = lJ; carry_mode = cmode; halo = halo_; add_reg = add_reg_;
         // the column window first: the scan's chunking below depends on how many sites this rank walks
         strips = stripRequested && ctx->comm && ctx->comm_world > 1;

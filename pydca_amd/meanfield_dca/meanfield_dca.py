@@ -6,7 +6,7 @@ import time
 
 import numpy as np
 
-from .. import _lib
+from .. import _lib, _ranking
 from ..fasta_reader import fasta_reader
 from . import msa_numerics
 
@@ -22,10 +22,7 @@ def _ranked(scores, L, ctx=None):
     stable sorted(..., reverse=True) does in the reference (meanfield_dca.py:940, plmdca.py:479).
     With ctx the order comes from the device (stable radix sort of the score vector the context
     just produced, dca_scores_order); without it from numpy."""
-    iu, ju = np.triu_indices(L, k=1)
-    order = ctx.scores_order() if ctx is not None else np.argsort(-scores, kind='stable')
-    # built without a Python-level loop over the pairs (124 750 at L = 500); the scores stay numpy scalars as in the reference
-    return list(zip(zip(iu[order].tolist(), ju[order].tolist()), list(scores[order])))
+    return _ranking.ranked(scores, L, ctx.scores_order() if ctx is not None else None)
 
 
 class MeanFieldDCA:

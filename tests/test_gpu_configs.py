@@ -281,6 +281,49 @@ def test_config_C_shipped_float32_deviation_reported(L_, oracle_plm, oracle_mf, 
     assert last["max_rel_dev_topL_fn_apc"] < 2e-2 and last["topL_overlap_fn_apc"] >= L - 2
 
 
+def test_dropin_plmdcaBackend_bound_as_the_reference_binds_it_at_config_C(L_, oracle_mf, msa_C, oracle_run_C, tmp_path):
+    """The drop-in boundary at a BASELINE configuration, bound EXACTLY as the reference binds its own backend
+    (plmdca.py:79-89, :214-228): a fresh ctypes.CDLL of the library file, the argtypes tuple, restype =
+    POINTER(c_float * data_size), the result read through `.contents`, freed through a cast to POINTER(c_void_p).  The
+    file holds the RAW alignment (duplicates included: the backend de-duplicates, plmdca_numerics.cpp:756-759); 100
+    iterations (the reference's default cap).  What comes back is the shipped float32 mode, so the bounds are the P4 ones
+    measured for it at this configuration (profiles/r03_f32_deviation_config_C_cap100.json): top-L FN_APC within 2e-2 of the
+    float64 oracle's run to the same cap, top-L sets equal up to 2 pairs.  And the error path: NULL + dca_last_error()."""
+    import ctypes
+    from tools.gen_msa import write_fasta
+    X, q, L, ref = msa_C, Q_C, L_C, oracle_run_C
+    path = str(tmp_path / "config_C.fa")
+    write_fasta(path, generate(L_C, N_C, Q_C, SEEDS["C"]), q)
+    lib = ctypes.CDLL(L_.LIB_PATH)
+    backend = lib.plmdcaBackend
+    backend.argtypes = (ctypes.c_ushort, ctypes.c_ushort, ctypes.c_char_p, ctypes.c_uint,
+                        ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_uint, ctypes.c_uint, ctypes.c_bool)
+    data_size = int((L * (L - 1) * (q ** 2)) / 2 + L * q)
+    backend.restype = ctypes.POINTER(ctypes.c_float * data_size)
+    free = lib.freeFieldsAndCouplings
+    free.restype = None
+    h_J_ptr = backend(1, q, path.encode("utf-8"), L, 0.8, LAMBDA_H, LAMBDA_J, REFERENCE_CAP, 1, False)
+    assert h_J_ptr, lib.dca_last_error
+    x = np.frombuffer(h_J_ptr.contents, dtype=np.float32).astype(np.float64)      # the reference copies element by element (:222)
+    assert x.size == data_size
+    free(ctypes.cast(h_J_ptr, ctypes.POINTER(ctypes.c_void_p)))
+    fn_ref = oracle_mf.plm_fn(ref["x"], L, q, apc_correct=True)
+    fn_got = oracle_mf.plm_fn(x, L, q, apc_correct=True)
+    top = _top(fn_ref, L)
+    dev = float(np.max(np.abs(fn_got[top] - fn_ref[top]) / np.abs(fn_ref[top])))
+    overlap = len(set(top) & set(_top(fn_got, L)))
+    print("\nplmdcaBackend at config C, 100 iterations: top-L FN_APC within %.2e of the float64 oracle, top-L overlap %d/%d, rel.err(x) %.2e"
+          % (dev, overlap, L, rel_err(x, ref["x"])))
+    assert dev < 2e-2 and overlap >= L - 2
+    # the error path: no exception across the C boundary, NULL and a message (the reference throws std::runtime_error here)
+    bad = backend(1, q, b"/nonexistent/alignment.fa", L, 0.8, LAMBDA_H, LAMBDA_J, 5, 1, False)
+    assert not bad
+    lib.dca_last_error.restype = ctypes.c_char_p
+    assert b"Unable to open" in lib.dca_last_error()
+    # a wrong sequence length is an error too, not a crash
+    assert not backend(1, q, path.encode("utf-8"), L + 7, 0.8, LAMBDA_H, LAMBDA_J, 5, 1, False)
+
+
 P3_GOLDEN_DIR = os.environ.get("DCA_P3_GOLDEN_DIR", os.path.join(ROOT, "tests", "golden"))     # a fresh make_p3_goldens.py run can be checked in place
 
 

@@ -385,6 +385,9 @@ def test_scores_kernel(L_, oracle_mf):
         ctx.close()
 
 
+DROPIN_TOY_BOUNDS = (2e-2, 2e-2)
+
+
 def test_dropin_plmdcaBackend_symbol(L_, oracle_plm, oracle_mf):
     """The reference's own FFI (plmdcaBackend.cpp:151-156), bound as plmdca.py:79-89 does."""
     G = golden("plm_toy_rna")
@@ -397,6 +400,16 @@ def test_dropin_plmdcaBackend_symbol(L_, oracle_plm, oracle_mf):
     lib.freeFieldsAndCouplings(ptr)
     fn_ref = oracle_mf.plm_fn(G["run_a"], L, q)
     fn_our = oracle_mf.plm_fn(x, L, q)
+    # The float32 oracle reproduces the reference's own lbfgs() run on this alignment BIT FOR BIT (plm_runs.npz, exit -1001 at
+    # iteration 15: tests/test_oracle_golden.py), so the reference's run is one definite vector here and the device's float32
+    # run is compared with it directly.  The device adds the same float32 terms in another order (chunk-parallel scan,
+    # tiled gather sums), which the 15 iterations and the line search's exit amplify; DROPIN_TOY_BOUNDS is what was
+    # measured on MI355X with a margin of 4 (printed below so that a drift shows up in the log before it fails).
+    runs = golden("plm_runs")
+    assert np.array_equal(G["run_a"], runs["toy_rna_x"]) or rel_err(G["run_a"], runs["toy_rna_x"]) < 2e-2    # as-run vs recorded run (thread order)
+    dx, dfn = rel_err(x, runs["toy_rna_x"]), rel_err(fn_our, oracle_mf.plm_fn(runs["toy_rna_x"], L, q))
+    print("\nplmdcaBackend on toy_rna against the reference's recorded run: rel.err(x) %.3e, rel.err(FN) %.3e" % (dx, dfn))
+    assert dx < DROPIN_TOY_BOUNDS[0] and dfn < DROPIN_TOY_BOUNDS[1]
     assert rel_err(fn_our, fn_ref) < 2e-2
     # error path: NULL + message instead of a C++ exception across the boundary
     assert not lib.plmdcaBackend(2, q, b"/nonexistent.fa", L, 0.8, 1.0, 1.0, 5, 1, False)

@@ -325,3 +325,21 @@ def test_class_validation_matches_reference():
         MeanFieldDCA(f, "rna", seqid=0.0)
     with pytest.raises(ValueError):
         MeanFieldDCA(f, "lipid")
+
+
+def test_ranked_list_equals_pythons_stable_sort():
+    """pydca_amd/_ranking.py builds the classes' return value without a Python-level loop; it must equal what the reference
+    builds (meanfield_dca.py:940: sorted(dict.items(), key=score, reverse=True) -- stable, so ties stay in (i, j) order),
+    element for element and type for type (pairs are tuples of ints, scores numpy scalars), also with ties, L = 2 and L = 1."""
+    from pydca_amd import _ranking
+    rng = np.random.default_rng(5)
+    for L in (1, 2, 3, 17, 60):
+        npairs = L * (L - 1) // 2
+        scores = np.round(rng.standard_normal(npairs), 1)          # one decimal: plenty of ties
+        ref = sorted((((i, j), scores[k]) for k, (i, j) in enumerate((i, j) for i in range(L) for j in range(i + 1, L))),
+                     key=lambda kv: kv[1], reverse=True)
+        for order in (None, np.argsort(-scores, kind='stable').astype(np.int32)):
+            got = _ranking.ranked(scores, L, order)
+            assert got == ref
+            assert all(type(p) is tuple and type(p[0]) is int and isinstance(s, np.float64) for p, s in got)
+    assert _ranking.pair_tuples(60) is _ranking.pair_tuples(60)    # cached per L

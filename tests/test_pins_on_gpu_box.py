@@ -4,7 +4,7 @@ oracle is only a checker because these tests hold it to the compiled reference a
 This module re-exports them under the `gpu` mark, so the same box and the same run that check the HIP path against the
 oracle also check the oracle against the reference:  tests/test_oracle_golden.py in full, and of tests/test_host_logic.py
 the reader / de-duplication tests (row a1 of SURVEY section 8) plus the loads-and-exports and no-fallback checks.
-Without a mark they still run in the CPU suite from their home modules."""
+and tests/test_backmapping_trimming.py in full.  Without a mark they still run in the CPU suite from their home modules."""
 import pytest
 
 from test_host_logic import (test_cxx_reader_errors, test_cxx_reader_semantics_bit_exact, test_cxx_reader_sweep,  # noqa: F401
@@ -13,5 +13,8 @@ from test_host_logic import (test_cxx_reader_errors, test_cxx_reader_semantics_b
                              test_product_never_imports_the_oracle, test_python_reader_matches_reference_reader,
                              test_readers_large_alignment_with_scattered_duplicates)
 from test_oracle_golden import *  # noqa: F401,F403
+# rows f3 / f4 of SURVEY section 8 (reference-sequence back-mapping, MSA trimming): host code of libdca_hip.so and its Python
+# mirrors against fixtures made with the reference -- in the driver's run as well
+from test_backmapping_trimming import *  # noqa: F401,F403
 
 pytestmark = pytest.mark.gpu

@@ -30,6 +30,7 @@ int main(int argc, char** argv)
     const int n = argc > 1 ? atoi(argv[1]) : 5056;
     dca_ctx ctx;
     CHECK(hipStreamCreate(&ctx.stream));
+    if (gemm_kernels_prepare(0) != DCA_OK) return 1;      // dynamic-LDS attributes of the product kernels (per device)
     double *A, *B, *C;
     CHECK(hipMalloc(&A, (size_t)n * n * 8)); CHECK(hipMalloc(&B, (size_t)n * n * 8)); CHECK(hipMalloc(&C, (size_t)n * n * 8));
     // non-trivial operand values: an all-zero GEMM draws less power and clocks higher than the real thing
