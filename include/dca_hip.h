@@ -70,6 +70,10 @@ void freeFieldsAndCouplings(void* h_and_J);
  * receives the number of sequence lines read. */
 int dca_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int capacity, int* raw_count);
 int dca_count_msa_lines(const char* path);
+/* The same reader in ONE pass over the file (what plmdcaBackend itself uses): allocates *rows (unique rows x L bytes; release
+ * with dca_host_free) and returns the number of unique rows.  The two-call form above opens the file twice, which a pipe
+ * does not survive. */
+int dca_read_msa_alloc(const char* path, int biomolecule, int L, uint8_t** rows, int* raw_count);
 
 /* The mfDCA path's FASTA reader, pydca/fasta_reader/fasta_reader.py:81-163 (there through Biopython): multi-line
  * records, upper-casing, every character outside the alphabet is the gap state (:138-149), exact duplicates dropped
@@ -226,6 +230,10 @@ typedef struct {
  * reference's cap (-997 when exceeded; 0 = unlimited). */
 int dca_plm_lbfgs_begin(dca_ctx* ctx, int max_iterations, int verbose);
 int dca_plm_lbfgs_iterate(dca_ctx* ctx, int iterations, dca_plm_stats* stats_out);
+/* Abandons the optimisation in progress (x and g keep their current values): the exchange scheme, the decomposition and the
+ * communicator may change again.  A run that reached its cap or converged has ended by itself.  No reference counterpart
+ * (lbfgs() runs to completion, lbfgs.cpp:248-644); needed because dca_plm_lbfgs_iterate is resumable. */
+int dca_plm_lbfgs_end(dca_ctx* ctx);
 
 /* Frobenius-norm scores of the current x: PlmDCA.get_couplings_no_gap_state +
  * compute_sorted_FN / compute_sorted_FN_APC (plmdca.py:246-268, :437-524), in pair

@@ -69,6 +69,7 @@ def lib():
         "dca_read_fasta": (i, [C.c_char_p, i, i, vp, i, C.POINTER(i)]),
         "dca_read_fasta_alloc": (i, [C.c_char_p, i, C.POINTER(vp), C.POINTER(i), C.POINTER(i)]),
         "dca_host_free": (None, [vp]),
+        "dca_read_msa_alloc": (i, [C.c_char_p, i, i, C.POINTER(vp), C.POINTER(i)]),
         "dca_create": (i, [C.POINTER(vp), i, i]),
         "dca_destroy": (None, [vp]),
         "dca_set_msa": (i, [vp, vp, i, i, i]),
@@ -101,6 +102,7 @@ def lib():
         "dca_plm_set_vector_sharding": (i, [vp, i, i, COMM_HOOK, vp]),
         "dca_plm_lbfgs_begin": (i, [vp, i, i]),
         "dca_plm_lbfgs_iterate": (i, [vp, i, C.POINTER(PlmStats)]),
+        "dca_plm_lbfgs_end": (i, [vp]),
         "dca_plm_scores": (i, [vp, i, vp]),
         "dca_plm_di_scores": (i, [vp, vp, i, vp]),
         "dca_mf_di_scores": (i, [vp, i, vp]),
@@ -136,11 +138,11 @@ def lib():
 
 EXPORTS = ["dca_compute_weights_sharded", "dca_weights_partial_counts", "dca_set_weight_counts", "dca_comm_unique_id",
            "dca_comm_init", "dca_comm_destroy", "dca_comm_info", "dca_plm_set_native_comm", "dca_mf_set_native_comm",
-           "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_fasta_shape", "dca_read_fasta", "dca_read_fasta_alloc", "dca_host_free", "dca_create",
+           "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_read_msa_alloc", "dca_fasta_shape", "dca_read_fasta", "dca_read_fasta_alloc", "dca_host_free", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_configure_strips", "dca_plm_num_params", "dca_plm_init_x",
            "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_di_from_arrays", "dca_di_from_fields", "dca_plm_set_vector_sharding",
-           "dca_plm_lbfgs_begin", "dca_plm_lbfgs_iterate", "dca_plm_scores", "dca_plm_di_scores",
+           "dca_plm_lbfgs_begin", "dca_plm_lbfgs_iterate", "dca_plm_lbfgs_end", "dca_plm_scores", "dca_plm_di_scores",
            "dca_mf_di_scores", "dca_plm_pair_couplings", "dca_mf_fields", "dca_mf_pair_couplings",
            "dca_mf_single_site_freqs",
            "dca_mf_pair_site_freqs", "dca_mf_corr_mat", "dca_mf_couplings", "dca_mf_scores", "dca_mf_run",
@@ -172,15 +174,18 @@ def _ptr(a):
 def read_msa(path, biomolecule, L):
     """Reference C++ reader semantics (plmdca_numerics.cpp:685-767) -> (uint8[N',L], raw_count)."""
     l = lib()
-    cap = l.dca_count_msa_lines(os.fsencode(path))
-    if cap < 0:
-        check(cap)
-    out = np.empty((max(cap, 1), L), dtype=np.uint8)         # every row handed back is written by the reader
-    raw = C.c_int(0)
-    n = l.dca_read_msa(os.fsencode(path), int(biomolecule), int(L), _ptr(out), cap, C.byref(raw))
-    if n < 0:
-        check(n)
-    return np.ascontiguousarray(out[:n]), raw.value
+    rows, raw = C.c_void_p(), C.c_int(0)
+    n = l.dca_read_msa_alloc(os.fsencode(path), int(biomolecule), int(L), C.byref(rows), C.byref(raw))     # one pass over the file
+    try:
+        if n < 0:
+            check(n)
+        out = np.empty((n, int(L)), dtype=np.uint8)
+        if n:
+            C.memmove(out.ctypes.data, rows, out.nbytes)
+        return out, raw.value
+    finally:
+        if rows:
+            l.dca_host_free(rows)
 
 
 def fasta_shape(path):
@@ -386,6 +391,9 @@ class Context:
 
     def plm_lbfgs_begin(self, max_iterations, verbose=False):
         check(self._l.dca_plm_lbfgs_begin(self._h, int(max_iterations), int(bool(verbose))))
+
+    def plm_lbfgs_end(self):
+        check(self._l.dca_plm_lbfgs_end(self._h))
 
     def plm_lbfgs_iterate(self, iterations):
         st = PlmStats()

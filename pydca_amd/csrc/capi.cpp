@@ -180,6 +180,11 @@ int dca_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int cap
 }
 
 int dca_count_msa_lines(const char* path) { return dca_count_msa_lines_impl(path); }
+int dca_read_msa_alloc(const char* path, int biomolecule, int L, uint8_t** rows, int* raw_count)
+{
+    if (!rows) { dca_set_error("dca_read_msa_alloc: bad arguments"); return DCA_ERR_ARG; }
+    return dca_read_msa_owned(path, biomolecule, L, rows, raw_count);
+}
 
 int dca_create(dca_ctx** out, int device, int precision)
 {
@@ -451,6 +456,7 @@ int dca_plm_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user)
 }
 int dca_plm_lbfgs_begin(dca_ctx* ctx, int max_iterations, int verbose) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->lbfgs_begin(max_iterations, verbose); }
 int dca_plm_lbfgs_iterate(dca_ctx* ctx, int iterations, dca_plm_stats* st) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->lbfgs_iterate(iterations, st); }
+int dca_plm_lbfgs_end(dca_ctx* ctx) { CHECK_CTX(ctx); if (ctx->plm) ctx->plm->lbfgs_end(); return DCA_OK; }
 int dca_plm_scores(dca_ctx* ctx, int apc, double* out) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->scores(apc, out); }
 int dca_plm_di_scores(dca_ctx* ctx, const double* reg_fi, int apc, double* out)
 {
@@ -515,6 +521,9 @@ int dca_comm_init(dca_ctx* ctx, const char* rccl_path, const void* id128, int wo
 int dca_comm_destroy(dca_ctx* ctx)
 {
     CHECK_CTX(ctx);
+    // giving the communicator back ends whatever optimisation was being driven over it (a caller that stops calling
+    // dca_plm_lbfgs_iterate below its cap never reaches `finished`; without this the communicator could not be released)
+    if (ctx->comm && ctx->plm) ctx->plm->lbfgs_end();
     if (ctx->comm && ctx->plm && ctx->plm->configured_for_comm()) DCA_TRY(ctx->plm->set_native_comm(0));
     if (ctx->mf) dca_mf_engine_set_native(ctx->mf, false);
     dca_comm_destroy_impl(ctx);

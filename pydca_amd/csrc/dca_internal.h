@@ -155,6 +155,7 @@ struct PlmEngineBase {
     virtual int gradient(double* fx_out) = 0;
     virtual int lbfgs_begin(int max_iterations, int verbose) = 0;
     virtual int lbfgs_iterate(int iterations, dca_plm_stats* st) = 0;
+    virtual void lbfgs_end() = 0;       // abandons the optimisation in progress (x, g stay as they are)
     virtual int scores(int apc, double* out) = 0;
     virtual int di_scores(const double* reg_fi, int apc, double* out) = 0;
     virtual int pair_couplings(const int* pairs, int npairs, int shift, double* out) = 0;

@@ -1551,10 +1551,15 @@ struct PlmEngine : PlmEngineBase {
     {
         if (!ctx->comm) { dca_set_error("column strips need a communicator: dca_comm_init first"); return DCA_ERR_STATE; }
         if (o.begun && !o.finished) { dca_set_error("the decomposition cannot change during an optimisation"); return DCA_ERR_STATE; }
+        // the caller's hooks go only if the new decomposition stands: a failed call leaves them as they were (the engine
+        // itself is then unconfigured -- configure() says so -- and must be configured again either way)
+        const auto hook0 = hook; const auto hookUser0 = hook_user; const auto comm0 = comm; const auto commUser0 = comm_user;
+        const int commRank0 = comm_rank, commWorld0 = comm_world;
         hook = nullptr; hook_user = nullptr; comm = nullptr; comm_user = nullptr; comm_rank = comm_world = 0;
         stripRequested = true;
         const int rc = configure(lh, lJ, cmode, chunk_, warm_, 0, 1);
         stripRequested = false;
+        if (rc != DCA_OK) { hook = hook0; hook_user = hookUser0; comm = comm0; comm_user = commUser0; comm_rank = commRank0; comm_world = commWorld0; strips = false; }
         return rc;
     }
 
@@ -2034,6 +2039,7 @@ struct PlmEngine : PlmEngineBase {
         }
     }
 
+    void lbfgs_end() override { o = decltype(o)(); }
     int lbfgs_iterate(int iterations, dca_plm_stats* st) override
     {
         if (!o.begun) { dca_set_error("dca_plm_lbfgs_begin first"); return DCA_ERR_STATE; }

@@ -255,6 +255,34 @@ def test_reduce_hook_through_torch_distributed():
         dist.destroy_process_group()
 
 
+def test_an_optimisation_left_below_its_cap_can_be_abandoned():
+    """dca_plm_lbfgs_iterate is resumable, so a caller may stop driving a run below its cap (bench.py does).  Such a run is
+    never `finished`: the exchange scheme refuses to change under it -- until dca_plm_lbfgs_end, or until the communicator is
+    given back (dca_comm_destroy ends the run itself instead of refusing for ever)."""
+    from pydca_amd import _lib, parallel
+    G = golden("plm_toy_protein")
+    ctx = _lib.Context(0, _lib.DCA_F32)
+    ctx.set_msa(G["X"], int(G["q"]))
+    ctx.compute_weights(0.8, _lib.DCA_F32)
+    parallel.init_native_comm(ctx, _lib, 0, 1)
+    ctx.plm_configure(1.0, 5.0)
+    ctx.plm_init_x()
+    ctx.plm_set_native_comm(2)
+    ctx.plm_lbfgs_begin(50)
+    st = ctx.plm_lbfgs_iterate(2)
+    assert st.iterations == 2 and not st.finished
+    with pytest.raises(_lib.DcaBackendError):
+        ctx.plm_set_native_comm(1)                     # in the middle of a run
+    ctx.plm_lbfgs_end()
+    ctx.plm_set_native_comm(1)
+    ctx.plm_lbfgs_begin(50)
+    assert ctx.plm_lbfgs_iterate(2).iterations == 2
+    ctx.comm_destroy()                                 # ends the unfinished run and releases the communicator
+    ctx.plm_lbfgs_begin(3)
+    assert ctx.plm_lbfgs_iterate(3).iterations == 3    # the engine lives on, unsharded
+    ctx.close()
+
+
 def test_native_rccl_communicator_single_rank():
     """The library's own RCCL communicator (csrc/comm_rccl.cpp) with one rank: every collective runs on the context's
     stream and is an identity, so all-reduce mode, sharded-vector mode, the sharded weights and the mfDCA count
