@@ -153,6 +153,9 @@ int dca_comm_destroy(dca_ctx* ctx);
  * it that its N processes form ONE communicator of N ranks.  dca_comm_init / dca_comm_destroy answer DCA_ERR_STATE, and
  * change nothing, while an optimisation whose vectors are cut for the current communicator is in progress. */
 int dca_comm_info(dca_ctx* ctx, int* world, int* rank);
+/* Small host-side exchange over the context's communicator: every rank hands in n doubles, every rank receives all world * n of
+ * them in rank order (timings, status flags of a start-up protocol; collective, synchronises the context's stream). */
+int dca_comm_allgather_host(dca_ctx* ctx, const double* mine, int n, double* all);
 
 /* Exchange step of the sharded plmDCA evaluation through the context's communicator (after dca_plm_configure):
  *   mode 1: all-reduce(sum) of the gradient and of fx after every evaluation, optimiser vectors replicated;
@@ -180,6 +183,12 @@ int dca_plm_configure_strips(dca_ctx* ctx, double lambda_h, double lambda_J, int
 
 /* mfDCA pair counts summed over the shards through the communicator (instead of dca_mf_set_reduce_hook). */
 int dca_mf_set_native_comm(dca_ctx* ctx, int on);
+/* The decomposition behind MeanFieldDCA(devices = ...): every rank holds the WHOLE alignment and all weights (tens of MB) and
+ * counts the sequences [first, first + count) only; with dca_mf_set_native_comm(ctx, 1) the raw pair counts of the windows are
+ * summed over the ranks (Meff is the global one everywhere).  Frequencies, correlation matrix, inverse and scores then run as
+ * on one GPU on every rank that asks for them; a rank that gives its communicator back afterwards keeps the summed counts.
+ * count < 0: the whole alignment again.  (The reference has one process and no counterpart.) */
+int dca_mf_set_row_window(dca_ctx* ctx, int first, int count);
 
 /* Sequence weights with the N^2 L / 2 comparisons divided over the ranks (every rank holds the whole alignment --
  * tens of MB -- and counts every world-th tile pair of the upper triangle of the identity matrix; the symmetric

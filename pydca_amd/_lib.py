@@ -103,6 +103,8 @@ def lib():
         "dca_plm_lbfgs_begin": (i, [vp, i, i]),
         "dca_plm_lbfgs_iterate": (i, [vp, i, C.POINTER(PlmStats)]),
         "dca_plm_lbfgs_end": (i, [vp]),
+        "dca_mf_set_row_window": (i, [vp, i, i]),
+        "dca_comm_allgather_host": (i, [vp, vp, i, vp]),
         "dca_plm_scores": (i, [vp, i, vp]),
         "dca_plm_di_scores": (i, [vp, vp, i, vp]),
         "dca_mf_di_scores": (i, [vp, i, vp]),
@@ -138,7 +140,7 @@ def lib():
 
 EXPORTS = ["dca_compute_weights_sharded", "dca_weights_partial_counts", "dca_set_weight_counts", "dca_comm_unique_id",
            "dca_comm_init", "dca_comm_destroy", "dca_comm_info", "dca_plm_set_native_comm", "dca_mf_set_native_comm",
-           "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_read_msa_alloc", "dca_fasta_shape", "dca_read_fasta", "dca_read_fasta_alloc", "dca_host_free", "dca_create",
+           "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_read_msa_alloc", "dca_mf_set_row_window", "dca_comm_allgather_host", "dca_fasta_shape", "dca_read_fasta", "dca_read_fasta_alloc", "dca_host_free", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_configure_strips", "dca_plm_num_params", "dca_plm_init_x",
            "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_di_from_arrays", "dca_di_from_fields", "dca_plm_set_vector_sharding",
@@ -294,6 +296,18 @@ class Context:
         """0 off, 1 all-reduce of g and fx per evaluation, 2 sharded optimiser vectors (RCCL reduce-scatter / all-gather),
         3 sharded optimiser vectors by direct exchange (grouped send / recv + rank-ordered local sum)."""
         check(self._l.dca_plm_set_native_comm(self._h, int(mode)))
+
+    def mf_set_row_window(self, first, count):
+        """Count only the sequences [first, first + count) of the (whole) alignment this context holds; count < 0: all."""
+        check(self._l.dca_mf_set_row_window(self._h, int(first), int(count)))
+
+    def comm_allgather(self, values):
+        """Every rank's `values` (a few doubles) on every rank, in rank order: array [world, len(values)].  Collective."""
+        mine = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        world = self.comm_info()[0]
+        out = np.zeros((world, mine.size), dtype=np.float64)
+        check(self._l.dca_comm_allgather_host(self._h, _ptr(mine), mine.size, _ptr(out)))
+        return out
 
     def mf_set_native_comm(self, on=True):
         check(self._l.dca_mf_set_native_comm(self._h, int(bool(on))))

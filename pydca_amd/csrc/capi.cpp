@@ -548,6 +548,30 @@ int dca_mf_set_native_comm(dca_ctx* ctx, int on)
     dca_mf_engine_set_native(ctx->mf, on != 0);
     return DCA_OK;
 }
+int dca_mf_set_row_window(dca_ctx* ctx, int first, int count)
+{
+    CHECK_CTX(ctx);
+    DCA_TRY(need_mf(ctx));
+    return dca_mf_engine_set_row_window(ctx->mf, first, count);
+}
+int dca_comm_allgather_host(dca_ctx* ctx, const double* mine, int n, double* all)
+{
+    CHECK_CTX(ctx);
+    if (!mine || !all || n <= 0) return DCA_ERR_ARG;
+    if (!ctx->comm) { dca_set_error("no communicator: dca_comm_init first"); return DCA_ERR_STATE; }
+    const size_t total = (size_t)n * ctx->comm_world;
+    double* d = nullptr;
+    HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&d), total * sizeof(double)));
+    int rc = DCA_OK;
+    // every rank contributes its values at its own offset of a zero vector: the sum IS the gathered vector (only sums are bound)
+    if (hipMemsetAsync(d, 0, total * sizeof(double), ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d + (size_t)n * ctx->comm_rank, mine, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = DCA_ERR_HIP;
+    if (rc == DCA_OK) rc = dca_comm_native(ctx, DCA_COMM_ALL_REDUCE, d, total, DCA_F64);
+    if (rc == DCA_OK && (hipMemcpyAsync(all, d, total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                         hipStreamSynchronize(ctx->stream) != hipSuccess)) rc = DCA_ERR_HIP;
+    dca_dev_free(d);
+    return rc;
+}
 int dca_mf_set_reduce_hook(dca_ctx* ctx, dca_reduce_hook hook, void* user)
 {
     CHECK_CTX(ctx);

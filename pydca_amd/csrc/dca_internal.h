@@ -197,6 +197,7 @@ int dca_mf_engine_di(MfEngine*, int apc, double* out);
 int dca_mf_engine_fields(MfEngine*, double* out);
 void dca_mf_engine_set_hook(MfEngine*, dca_reduce_hook hook, void* user);
 void dca_mf_engine_set_native(MfEngine*, bool on);
+int dca_mf_engine_set_row_window(MfEngine*, int first, int count);   // count < 0: all rows
 void dca_mf_engine_invalidate(MfEngine*);      // weights changed: counts, frequencies, C and J are recomputed on demand
 int dca_mf_engine_pair_couplings(MfEngine*, const int* pairs, int npairs, int shift, double* out);
 

@@ -315,6 +315,11 @@ struct MfEngine {
     dca_reduce_hook hook = nullptr;   // sequence sharding: sums Craw and Meff over the shards
     void* hook_user = nullptr;
     bool native_reduce = false;       // the same sum through ctx->comm (RCCL on the context's stream)
+    // Row window (dca_mf_set_row_window): the context holds the WHOLE alignment and all weights, this rank counts the sequences
+    // [winFirst, winFirst + winCount) only and the native reduction sums the raw counts over the ranks -- the decomposition of
+    // MeanFieldDCA(devices = ...): everything after the counts (and everything that needs the alignment) stays as on one GPU.
+    int winFirst = 0, winCount = -1;  // -1: all rows
+    bool counts_global = false;       // the cached counts are the sum over all ranks' windows (= the whole alignment's)
     double meff = 0.0;                // Meff the frequencies are normalised by: ctx->meff (this context's weights) summed over
                                       // the shards when a hook / the native reduction is set; ctx->meff itself stays local
     ~MfEngine() { dca_dev_free(dRegFi); dca_dev_free(dPerm); dca_dev_free(dOff); dca_dev_free(dXT); dca_dev_free(dDom); dca_dev_free(dCnt1); dca_dev_free(dCraw); dca_dev_free(dFi); dca_dev_free(dC); dca_dev_free(dWork); }
@@ -337,6 +342,11 @@ static int mf_counts(MfEngine* m)
     dca_ctx* ctx = m->ctx;
     if (m->q > 32) { dca_set_error("q too large"); return DCA_ERR_ARG; }
     const int Nt = (int)round_up((size_t)m->N, 64);
+    const bool windowed = m->winCount >= 0;
+    const int rowFirst = windowed ? m->winFirst : 0, Nw = windowed ? m->winCount : m->N;      // the rows this context counts
+    if (windowed && !m->native_reduce) { dca_set_error("a row window needs the native count reduction (dca_mf_set_native_comm)"); return DCA_ERR_STATE; }
+    const uint8_t* Xw = ctx->dX + (size_t)rowFirst * m->Ls;
+    const double* Ww = ctx->dWd + rowFirst;
     if (!m->dPerm) {
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dPerm), (size_t)m->L * m->N * sizeof(uint32_t), false));
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dOff), (size_t)m->L * (m->q + 1) * sizeof(int)));
@@ -348,20 +358,20 @@ static int mf_counts(MfEngine* m)
     }
     {
         ScopedKernelClock kc(ctx, "mf_sort");
-        hipLaunchKernelGGL(mf_transpose_kernel, dim3(ceil_div(m->N, 64), ceil_div(m->L, 64)), dim3(256), 0, ctx->stream,
-                           ctx->dX, m->dXT, m->N, m->L, m->Ls, Nt);
-        hipLaunchKernelGGL(mf_site_sort_kernel, dim3(m->L), dim3(kSortThreads), 0, ctx->stream, m->dXT, ctx->dWd, m->dPerm,
-                           m->dOff, m->dDom, m->dCnt1, m->N, Nt, m->q);
+        hipLaunchKernelGGL(mf_transpose_kernel, dim3(std::max(1, ceil_div(Nw, 64)), ceil_div(m->L, 64)), dim3(256), 0, ctx->stream,
+                           Xw, m->dXT, Nw, m->L, m->Ls, Nt);
+        hipLaunchKernelGGL(mf_site_sort_kernel, dim3(m->L), dim3(kSortThreads), 0, ctx->stream, m->dXT, Ww, m->dPerm,
+                           m->dOff, m->dDom, m->dCnt1, Nw, Nt, m->q);
     }
     {
         ScopedKernelClock kc(ctx, "mf_counts");
         const size_t lds = (size_t)m->q * kCountThreads * sizeof(double);
         if (m->q <= 8)
-            hipLaunchKernelGGL(mf_counts_kernel<true>, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, ctx->dX, ctx->dWd,
-                               m->dPerm, m->dOff, m->dDom, m->dCraw, m->N, m->L, m->Ls, m->q, m->Lq);
+            hipLaunchKernelGGL(mf_counts_kernel<true>, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, Xw, Ww,
+                               m->dPerm, m->dOff, m->dDom, m->dCraw, Nw, m->L, m->Ls, m->q, m->Lq);
         else
-            hipLaunchKernelGGL(mf_counts_kernel<false>, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, ctx->dX, ctx->dWd,
-                               m->dPerm, m->dOff, m->dDom, m->dCraw, m->N, m->L, m->Ls, m->q, m->Lq);
+            hipLaunchKernelGGL(mf_counts_kernel<false>, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, Xw, Ww,
+                               m->dPerm, m->dOff, m->dDom, m->dCraw, Nw, m->L, m->Ls, m->q, m->Lq);
         hipLaunchKernelGGL(mf_complete_kernel, dim3(m->L, m->L), dim3(64), 0, ctx->stream, m->dCraw, m->dCnt1, m->dDom,
                            m->L, m->q, m->Lq);
     }
@@ -371,7 +381,9 @@ static int mf_counts(MfEngine* m)
         // GLOBAL weights, the hook sums the Lq x Lq raw counts and the effective sequence number in place
         HIP_TRY(hipMemcpyAsync(ctx->dScal, &m->meff, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         if (m->native_reduce) {
-            DCA_TRY(dca_comm_native_reduce(ctx, m->dCraw, (size_t)m->Lq * m->Lq, DCA_F64, ctx->dScal));
+            // with a row window every rank holds ALL weights: Meff is already the global one (the very number a single GPU computes)
+            DCA_TRY(dca_comm_native_reduce(ctx, m->dCraw, (size_t)m->Lq * m->Lq, DCA_F64, windowed ? nullptr : ctx->dScal));
+            m->counts_global = windowed;
         } else {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             if (m->hook(m->hook_user, m->dCraw, (size_t)m->Lq * m->Lq, DCA_F64, ctx->dScal) != 0) {
@@ -588,9 +600,23 @@ int dca_mf_engine_pair_couplings(MfEngine* m, const int* pairs, int npairs, int 
 
 // Counts, frequencies, correlation matrix and couplings cached so far were summed under the previous exchange scheme (or the
 // previous weights): they are recomputed by the next query instead of answering for a single shard.
-void dca_mf_engine_invalidate(MfEngine* m) { m->have_counts = m->have_corr = m->have_J = m->corr_on_device = false; }
+void dca_mf_engine_invalidate(MfEngine* m) { m->have_counts = m->have_corr = m->have_J = m->corr_on_device = false; m->counts_global = false; }
+int dca_mf_engine_set_row_window(MfEngine* m, int first, int count)
+{
+    if (count < 0) { first = 0; count = -1; }
+    else if (first < 0 || (long long)first + count > m->N) { dca_set_error("row window outside the alignment"); return DCA_ERR_ARG; }
+    if (first != m->winFirst || count != m->winCount) dca_mf_engine_invalidate(m);
+    m->winFirst = first; m->winCount = count;
+    return DCA_OK;
+}
 void dca_mf_engine_set_native(MfEngine* m, bool on)
 {
+    if (!on && m->native_reduce && m->have_counts && m->counts_global) {
+        // the communicator goes away AFTER the windows were summed: what is cached are the whole alignment's counts, which is what
+        // this context -- it holds the whole alignment -- would count alone; keep them, drop the window
+        m->native_reduce = false; m->winFirst = 0; m->winCount = -1;
+        return;
+    }
     if (on != m->native_reduce || (on && m->hook)) dca_mf_engine_invalidate(m);
     m->native_reduce = on;
     if (on) { m->hook = nullptr; m->hook_user = nullptr; }

@@ -6,7 +6,7 @@ import time
 
 import numpy as np
 
-from .. import _lib, _ranking
+from .. import _lib, _ranking, multi_gpu
 from ..fasta_reader import fasta_reader
 from . import msa_numerics
 
@@ -28,7 +28,7 @@ def _ranked(scores, L, ctx=None):
 class MeanFieldDCA:
     """Mean-field DCA (meanfield_dca.py:43-139)."""
 
-    def __init__(self, msa, biomolecule, pseudocount=None, seqid=None, device=0):
+    def __init__(self, msa, biomolecule, pseudocount=None, seqid=None, device=0, devices=None):
         self.__pseudocount = pseudocount if pseudocount is not None else 0.5
         self.__seqid = seqid if seqid is not None else 0.8
         if self.__pseudocount >= 1.0 or self.__pseudocount < 0:
@@ -62,13 +62,24 @@ class MeanFieldDCA:
         self.__num_sequences, self.__sequences_len = (int(v) for v in self.__X0.shape)
         self.__biomolecule = biomolecule
         t1 = time.perf_counter()
-        self.__ctx = _lib.Context(int(device), _lib.DCA_F64)
-        self.__ctx.set_msa(self.__X0, self.__num_site_states)
-        if self.__seqid < 1.0:
-            self.__sequences_weight = self.compute_sequences_weight()
+        devices = multi_gpu.parse_devices(devices)          # ValueError on a malformed list, as for the other arguments
+        if devices and len(devices) > 1:
+            # one rank per GPU for the two stages that scale with the number of sequences: the weights (N^2 L comparisons divided
+            # over the ranks) and the pair counts (a window of the sequences each, ONE all-reduce); what follows runs here
+            try:
+                self.__ctx = multi_gpu.run_mf_counts(self.__X0, self.__num_site_states, self.__seqid, devices)
+            except multi_gpu.MultiGpuError as exc:
+                logger.error('\n\tA GPU rank failed: {}'.format(exc))
+                raise MeanFieldDCAException(str(exc))
+            self.__sequences_weight = self.__ctx.weights()
         else:
-            self.__sequences_weight = np.ones((self.__num_sequences,), dtype=np.float64)
-            self.__ctx.set_weights(self.__sequences_weight)
+            self.__ctx = _lib.Context(int(devices[0] if devices else device), _lib.DCA_F64)
+            self.__ctx.set_msa(self.__X0, self.__num_site_states)
+            if self.__seqid < 1.0:
+                self.__sequences_weight = self.compute_sequences_weight()
+            else:
+                self.__sequences_weight = np.ones((self.__num_sequences,), dtype=np.float64)
+                self.__ctx.set_weights(self.__sequences_weight)
         self.last_timings.update(reader=t1 - t0, upload_and_weights=time.perf_counter() - t1)
         self.__effective_num_sequences = np.sum(self.__sequences_weight)
         self.__couplings = None

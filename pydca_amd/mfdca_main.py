@@ -19,10 +19,10 @@ def configure_logging():
 
 def execute_from_command_line(msa_file=None, biomolecule=None, seqid=None, pseudocount=None, the_command=None,
                               refseq_file=None, verbose=False, output_dir=None, apc=False, ranked_by=None,
-                              linear_dist=None, num_site_pairs=None, device=0):
+                              linear_dist=None, num_site_pairs=None, device=0, devices=None):
     if verbose:
         configure_logging()
-    mfdca_instance = meanfield_dca.MeanFieldDCA(msa_file, biomolecule, pseudocount=pseudocount, seqid=seqid, device=device)
+    mfdca_instance = meanfield_dca.MeanFieldDCA(msa_file, biomolecule, pseudocount=pseudocount, seqid=seqid, device=device, devices=devices)
     seqbackmapper = None
     if refseq_file:   # do backmapping when a reference sequence file is provided
         seqbackmapper = SequenceBackmapper(alignment_data=mfdca_instance.alignment, refseq_file=refseq_file,
@@ -101,6 +101,8 @@ def run_meanfield_dca(argv=None):
         p.add_argument('--verbose', action='store_true')
         p.add_argument('--apc', action='store_true')
         p.add_argument('--device', type=int, default=0, help='GPU index (addition)')
+        p.add_argument('--devices', help='comma-separated GPU indices: one rank per GPU for the sequence weights and the pair counts '
+                       '(ONE all-reduce of the counts over RCCL); the inverse and the scores run on the first (addition)')
         if name == 'compute_params':
             p.add_argument('--ranked_by', choices=('FN', 'FN_APC', 'DI', 'DI_APC', 'fn', 'fn_apc', 'di', 'di_apc'))
             p.add_argument('--linear_dist', type=int)
@@ -112,7 +114,7 @@ def run_meanfield_dca(argv=None):
         pseudocount=args.get('pseudocount'), the_command=args.get('subcommand_name'), refseq_file=args.get('refseq_file'),
         verbose=args.get('verbose'), output_dir=args.get('output_dir'), apc=args.get('apc'),
         ranked_by=args.get('ranked_by'), linear_dist=args.get('linear_dist'), num_site_pairs=args.get('num_site_pairs'),
-        device=args.get('device'))
+        device=args.get('device'), devices=args.get('devices'))
 
 
 if __name__ == '__main__':

@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-from .. import _lib, _ranking
+from .. import _lib, _ranking, multi_gpu
 
 logger = logging.getLogger(__name__)
 
@@ -32,7 +32,7 @@ class PlmDCA:
     reference's carried-over probabilities)."""
 
     def __init__(self, msa_file, biomolecule, seqid=None, lambda_h=None, lambda_J=None, max_iterations=None,
-                 num_threads=None, verbose=False, device=0, precision=32, exact_gradient=False):
+                 num_threads=None, verbose=False, device=0, precision=32, exact_gradient=False, devices=None):
         self.__biomolecule = biomolecule.strip().upper()
         if self.__biomolecule not in ('PROTEIN', 'RNA'):
             logger.error('\n\tBiomolecule {!r} is neither PROTEIN nor RNA'.format(self.__biomolecule))
@@ -56,7 +56,14 @@ class PlmDCA:
         self.__max_iterations = max_iterations if max_iterations is not None else 100
         self.__num_threads = 1 if num_threads is None else num_threads   # accepted, unused: the work runs on the GPU
         self.__verbose = True if verbose else False
-        self.__device = int(device)
+        # devices=[0, 1, ...]: one rank per GPU (pydca_amd/multi_gpu.py) -- the counterpart of the reference's num_threads, its
+        # one parallel knob (plmdca_main.py:77-78,131); a single entry is the same as device=
+        try:
+            self.__devices = multi_gpu.parse_devices(devices)
+        except ValueError as exc:
+            logger.error('\n\t{}'.format(exc))
+            raise PlmDCAException(str(exc))
+        self.__device = int(device) if not self.__devices else self.__devices[0]
         self.__precision = _lib.DCA_F64 if int(precision) == 64 else _lib.DCA_F32
         self.__carry = _lib.CARRY_EXACT if exact_gradient else _lib.CARRY_CHUNKED
         self.__data_size = int((self.__seqs_len * (self.__seqs_len - 1) * (self.__num_site_states ** 2)) / 2
@@ -130,6 +137,21 @@ class PlmDCA:
         t1 = time.perf_counter()
         if self.__ctx is not None:
             self.__ctx.close()
+            self.__ctx = None
+        if self.__devices and len(self.__devices) > 1:
+            try:
+                _x, st, selection, ctx = multi_gpu.run_plm(X, self.__num_site_states, self.__seqid, self.__lambda_h, self.__lambda_J,
+                                                           self.__max_iterations, self.__precision, self.__carry, self.__devices,
+                                                           verbose=self.__verbose)
+            except multi_gpu.MultiGpuError as exc:
+                logger.error('\n\tA GPU rank failed: {}'.format(exc))
+                if exc.kind == 'FileNotFoundError':
+                    raise FileNotFoundError(exc.message)
+                raise PlmDCAException(str(exc))
+            t3 = time.perf_counter()
+            self.last_status = dict(st, multi_gpu=selection, stages_s=dict(reader=t1 - t0, setup_and_optimise=t3 - t1))
+            self.__ctx = ctx
+            return ctx
         ctx = _lib.Context(self.__device, self.__precision)
         ctx.set_msa(X, self.__num_site_states)
         # the reference's C++ compares in float (plmdca_numerics.cpp:642); the float64 checking

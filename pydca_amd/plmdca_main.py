@@ -20,12 +20,12 @@ def configure_logging():
 def execute_from_command_line(biomolecule, msa_file, the_command=None, refseq_file=None, seqid=None, lambda_h=None,
                               lambda_J=None, max_iterations=None, apc=False, verbose=False, output_dir=None,
                               num_threads=None, ranked_by=None, linear_dist=None, num_site_pairs=None, device=0,
-                              exact_gradient=False, precision=32):
+                              exact_gradient=False, precision=32, devices=None):
     if verbose:
         configure_logging()
     plmdca_instance = plmdca.PlmDCA(msa_file, biomolecule, seqid=seqid, lambda_h=lambda_h, lambda_J=lambda_J,
                                     max_iterations=max_iterations, num_threads=num_threads, verbose=verbose,
-                                    device=device, exact_gradient=exact_gradient, precision=precision or 32)
+                                    device=device, exact_gradient=exact_gradient, precision=precision or 32, devices=devices)
     if the_command in DCA_COMPUTATION_SUBCOMMANDS:
         param_metadata = dca_utilities.plmdca_param_metadata(plmdca_instance)
         if not output_dir:
@@ -96,6 +96,8 @@ def run_plm_dca(argv=None):
             p.add_argument('--apc', action='store_true')
         p.add_argument('--output_dir')
         p.add_argument('--device', type=int, default=0, help='GPU index (addition)')
+        p.add_argument('--devices', help='comma-separated GPU indices, e.g. 0,1,2,3,4,5,6,7: one rank per GPU, sequences (or sites) '
+                       'sharded, gradients exchanged over RCCL each iteration -- the counterpart of --num_threads (addition)')
         p.add_argument('--exact_gradient', action='store_true', help='exact pseudolikelihood gradient instead of '
                        'the reference semantics (addition)')
         p.add_argument('--precision', type=int, choices=(32, 64), default=32, help='32: float32 as the reference (default); 64: the '
@@ -112,7 +114,8 @@ def run_plm_dca(argv=None):
         lambda_J=args.get('lambda_J'), max_iterations=args.get('max_iterations'), num_threads=args.get('num_threads'),
         apc=args.get('apc'), output_dir=args.get('output_dir'), verbose=args.get('verbose'),
         ranked_by=args.get('ranked_by'), linear_dist=args.get('linear_dist'), num_site_pairs=args.get('num_site_pairs'),
-        device=args.get('device'), exact_gradient=args.get('exact_gradient'), precision=args.get('precision'))
+        device=args.get('device'), exact_gradient=args.get('exact_gradient'), precision=args.get('precision'),
+        devices=args.get('devices'))
 
 
 if __name__ == '__main__':

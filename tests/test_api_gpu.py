@@ -749,3 +749,86 @@ def test_msa_numerics_direct_information_functions():
     np.testing.assert_array_equal(plm_num.compute_sequences_weight(alignment_data=X1, sequence_identity=0.8), M["w"])
     with pytest.raises(ValueError):
         plm_num.compute_direct_info(couplings=blocks[:-1], reg_fi=D["plm_reg_fi"], seqs_len=L, num_site_states=q)
+
+
+# ------------------------------------------------------------------------------------------------ devices= / --devices (row N1)
+FAKE_MP = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl_mp.so")
+
+
+def _scores_of(path):
+    rows = [ln.split() for ln in open(path).read().splitlines() if ln and not ln.startswith("#")]
+    return [(int(r[0]), int(r[1])) for r in rows], np.array([float(r[2]) for r in rows])
+
+
+def _cli(module, argv, env=None, timeout=900):
+    import subprocess
+    e = dict(os.environ, PYTHONPATH=ROOT, **(env or {}))
+    p = subprocess.run([sys.executable, "-m", "pydca_amd." + module] + argv, env=e, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    return p
+
+
+@pytest.mark.parametrize("msa,bio", [("MSA_RF00167_trimmed71.fa", "rna"), ("toy_protein.fa", "protein")])
+def test_plmdca_command_line_devices_equals_one_gpu_float64(tmp_path, msa, bio):
+    """Row N1: `plmdca compute_fn ... --devices 0,0` -- the calling process as rank 0 plus one helper process, the library's
+    own communicators over the multi-process stand-in for librccl (two ranks on the one GPU of the box; on a node the same
+    code runs over RCCL) -- writes the same ranked file as the one-GPU run.  float64 takes the column strips, whose
+    gradient is bit-identical to the unsharded one: the same pairs in the same order, the scores equal to 1e-12 (the
+    optimiser's dot products are summed per rank and then over the ranks -- in double-double, so usually to the last bit)."""
+    assert os.path.exists(FAKE_MP), "build it: python -c 'import __graft_entry__ as g; g.build()'"
+    common = ["compute_fn", bio, data_file(msa), "--max_iterations", "12", "--apc", "--precision", "64"]
+    _cli("plmdca_main", common + ["--output_dir", str(tmp_path / "one")])
+    _cli("plmdca_main", common + ["--output_dir", str(tmp_path / "two"), "--devices", "0,0"], env={"DCA_RCCL_PATH": FAKE_MP})
+    name = "PLMDCA_apc_fn_scores_%s.txt" % os.path.splitext(msa)[0]
+    p1, s1 = _scores_of(str(tmp_path / "one" / name))
+    p2, s2 = _scores_of(str(tmp_path / "two" / name))
+    assert p1 == p2
+    np.testing.assert_allclose(s2, s1, rtol=1e-12, atol=1e-15)
+    print("\n%s: identical order; %d of %d scores byte-identical" % (msa, int(np.sum(s1 == s2)), len(s1)))
+
+
+def test_plmdca_devices_float32_times_the_schemes_and_follows_one_gpu():
+    """The default float32 mode with devices=[0, 0]: all four exchange schemes come up and are timed at start-up, the fastest
+    runs, and the result follows the one-GPU run (another order of float32 sums: the P4 regime, bounded loosely); the
+    exception type of a failing rank is the class's own."""
+    import subprocess
+    code = (
+        "import json, sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from pydca_amd.plmdca import plmdca\n"
+        "f = %r\n"
+        "a = plmdca.PlmDCA(f, 'rna', max_iterations=10)\n"
+        "sa = a.compute_sorted_FN_APC()\n"
+        "b = plmdca.PlmDCA(f, 'rna', max_iterations=10, devices=[0, 0])\n"
+        "sb = b.compute_sorted_FN_APC()\n"
+        "sel = b.last_status['multi_gpu']\n"
+        "da = dict(sa); top = [p for p, _ in sa[:20]]\n"
+        "dev = max(abs(dict(sb)[p] - da[p]) / abs(da[p]) for p in top)\n"
+        "try:\n"
+        "    plmdca.PlmDCA(f, 'rna', max_iterations=2, devices=[0, 4097]).compute_sorted_FN()\n"
+        "    err = 'no error'\n"
+        "except plmdca.PlmDCAException as e:\n"
+        "    err = 'PlmDCAException'\n"
+        "print(json.dumps(dict(sel=sel, dev=dev, status=[a.last_status['status'], b.last_status['status']],\n"
+        "                      its=[a.last_status['iterations'], b.last_status['iterations']], err=err)))\n" % (ROOT, data_file("MSA_RF00167_trimmed71.fa")))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, DCA_RCCL_PATH=FAKE_MP))
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert sorted(d["sel"]["ms_per_iteration"]) == ["1", "2", "3", "4"], d
+    assert str(d["sel"]["chosen_scheme"]) == min(d["sel"]["ms_per_iteration"], key=lambda m: d["sel"]["ms_per_iteration"][m])
+    assert d["sel"]["ranks"] == 2 and d["its"] == [10, 10] and d["status"][0] == d["status"][1], d
+    assert d["dev"] < 1e-3, d
+    assert d["err"] == "PlmDCAException", d
+
+
+def test_mfdca_command_line_devices_equals_one_gpu(tmp_path):
+    """`mfdca compute_fn ... --devices 0,0`: weights with the comparisons divided over two ranks, each rank counting half of the
+    sequences, ONE all-reduce of the raw pair counts, then the one-GPU chain on rank 0 -- same ranking, scores to 1e-10 (the
+    count sums are split at the window boundary)."""
+    common = ["compute_fn", "rna", data_file("MSA_RF00167.fa"), "--pseudocount", "0.5", "--apc"]
+    _cli("mfdca_main", common + ["--output_dir", str(tmp_path / "one")])
+    _cli("mfdca_main", common + ["--output_dir", str(tmp_path / "two"), "--devices", "0,0"], env={"DCA_RCCL_PATH": FAKE_MP})
+    p1, s1 = _scores_of(str(tmp_path / "one" / "MFDCA_apc_fn_scores_MSA_RF00167.txt"))
+    p2, s2 = _scores_of(str(tmp_path / "two" / "MFDCA_apc_fn_scores_MSA_RF00167.txt"))
+    assert p1 == p2
+    np.testing.assert_allclose(s2, s1, rtol=1e-10, atol=1e-14)

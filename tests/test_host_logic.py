@@ -343,3 +343,19 @@ def test_ranked_list_equals_pythons_stable_sort():
             assert got == ref
             assert all(type(p) is tuple and type(p[0]) is int and isinstance(s, np.float64) for p, s in got)
     assert _ranking.pair_tuples(60) is _ranking.pair_tuples(60)    # cached per L
+
+
+def test_devices_argument_is_validated_like_the_other_arguments():
+    """devices= / --devices (the counterpart of the reference's num_threads): parsing and validation need no GPU."""
+    from pydca_amd import multi_gpu
+    from pydca_amd.plmdca import plmdca
+    assert multi_gpu.parse_devices("0, 1,2") == [0, 1, 2] and multi_gpu.parse_devices([5]) == [5]
+    assert multi_gpu.parse_devices(None) is None and multi_gpu.parse_devices("") is None
+    for bad in ("a,b", "-1", "0,0", [1, 1]):
+        os.environ.pop("DCA_RCCL_PATH", None)
+        with pytest.raises(ValueError):
+            multi_gpu.parse_devices(bad)
+    with pytest.raises(plmdca.PlmDCAException):
+        plmdca.PlmDCA(data_file("toy_rna.fa"), "rna", devices="0;1")
+    p = plmdca.PlmDCA(data_file("toy_rna.fa"), "rna", devices=[3])             # one entry: the same as device=3; nothing runs yet
+    assert p.sequences_len == 10
