@@ -165,14 +165,24 @@ int oracle_read_msa(const char* path, int biomolecule, int L, uint8_t* out, int 
  *   residual   one rounded value r = w p(a) - w delta(a, x) is added to every sum (the reference adds -w and +w p(a) one
  *              after the other, :541-566);
  *   fields     the gradient sums of the fields are compensated like the objective (order-independent).
- * The per-slot chains of the coupling gradient stay plain sequential sums over n in ascending order, and the two site
- * views are merged as (2 lambda x + view_i) + view_j, as before.  Why: at config E two float64 runs that differ in nothing
+ *   chains     (round 5) the per-slot sums of the coupling gradient run over blocks of ORACLE_CANONICAL_BLOCK = 16384
+ *              consecutive sequences, each block summed from zero in ascending n, the block sums added in ascending
+ *              block order ((B0 + B1) + B2) + ... -- a fixed order that a device can follow with as many independent
+ *              chains as there are blocks (round 4's single chain over all N left 60 workgroups on 256 CUs at config E:
+ *              13 blocks there, 4 at config D); alignments of at most one block (config C, the test alignments) are one
+ *              plain chain as before.  Why 16384 and not less: a device workgroup that walks several blocks has to add
+ *              each finished block into the running sum in memory (a read-modify-write of its part of the gradient
+ *              table), which at config D cost 3 ms of a 34 ms evaluation with blocks of 4096 (12 such passes, measured).
+ * The two site views are merged as (2 lambda x + view_i) + view_j, as before.  Why: at config E two float64 runs that differ in nothing
  * but the order of these sums (1e-13 relative) end 7.5e-5 apart in FN after the reference's 100 iterations
  * (profiles/r04_sensitivity_E_cap100.json) -- the optimisation does not converge and amplifies rounding by ~1.2 x per
  * iteration -- so a device-vs-oracle comparison at 1e-4 needs BOTH to add in the same order; with it the device's
  * float64 gradient equals this oracle's bit for bit up to the last-place differences of the two exp() implementations. */
 #ifndef ORACLE_PLAIN_F64            /* -DORACLE_PLAIN_F64: the reference's order in float64 too (tests: the two differ by rounding only) */
 #define ORACLE_CANONICAL_F64 1
+#ifndef ORACLE_CANONICAL_BLOCK
+#define ORACLE_CANONICAL_BLOCK 16384  /* tests build a single-chain variant with a larger value */
+#endif
 #endif
 #define REAL double
 #define FN(name) CAT(name, _f64)

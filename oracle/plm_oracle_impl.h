@@ -117,6 +117,10 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
     {
         REAL* Wi = (REAL*)malloc((size_t)L * q2 * sizeof(REAL));
         REAL* Ti = (REAL*)malloc((size_t)L * q2 * sizeof(REAL));
+#ifdef ORACLE_CANONICAL_F64
+        REAL* Tt = (REAL*)malloc((size_t)L * q2 * sizeof(REAL));      /* running sum of the finished blocks */
+        if (!Tt) { free(Ti); Ti = NULL; }
+#endif
         if (!Wi || !Ti) {
 #pragma omp atomic write
             failed = 1;
@@ -140,6 +144,9 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
                 for (int a = 0; a < q; ++a) for (int b = 0; b < q; ++b) Wj[(size_t)b * q + a] = Jij[(size_t)a * q + b];
             }
             memset(Ti, 0, (size_t)L * q2 * sizeof(REAL));
+#ifdef ORACLE_CANONICAL_F64
+            int blocksDone = 0;                   /* blocks of ORACLE_CANONICAL_BLOCK sequences already folded into Tt */
+#endif
             for (int a = 0; a < q; ++a) p[a] = 0;
             for (int n = 0; n < N; ++n) {
                 const uint8_t* s = X + (size_t)n * L;
@@ -203,7 +210,21 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
                     for (int a = 0; a < q; ++a) row[a] += wp[a];
                 }
 #endif
+#ifdef ORACLE_CANONICAL_F64
+                /* float64 instantiation: the per-slot chains run over BLOCKS of ORACLE_CANONICAL_BLOCK consecutive sequences,
+                 * each summed from zero in ascending n, and the block sums are added in ascending block order
+                 * (((B0 + B1) + B2) + ...) -- see plm_oracle.c.  An alignment of at most one block is one plain chain. */
+                if ((n + 1) % ORACLE_CANONICAL_BLOCK == 0 && n + 1 < N) {
+                    if (blocksDone == 0) memcpy(Tt, Ti, (size_t)L * q2 * sizeof(REAL));
+                    else for (size_t k = 0; k < (size_t)L * q2; ++k) Tt[k] += Ti[k];
+                    memset(Ti, 0, (size_t)L * q2 * sizeof(REAL));
+                    ++blocksDone;
+                }
+#endif
             }
+#ifdef ORACLE_CANONICAL_F64
+            if (blocksDone > 0) for (size_t k = 0; k < (size_t)L * q2; ++k) Ti[k] = Tt[k] + Ti[k];     /* the last block */
+#endif
             /* back into the pair orientation (state of the smaller site first), as :494,:541-567 */
             for (int j = 0; j < i; ++j) memcpy(cgi + (size_t)j * q2, Ti + (size_t)j * q2, q2 * sizeof(REAL));
             for (int j = i + 1; j < L; ++j) {
@@ -218,6 +239,9 @@ REAL FN(oracle_gradient)(const uint8_t* X, const REAL* w, int N, int L, int q,
 #endif
         }
         free(Wi); free(Ti);
+#ifdef ORACLE_CANONICAL_F64
+        free(Tt);
+#endif
     }
     if (failed) { free(cg); free(hg); free(fsite); return (REAL)NAN; }
 

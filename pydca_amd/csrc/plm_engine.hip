@@ -94,8 +94,17 @@ typedef uint32_t dca_v4u __attribute__((ext_vector_type(4)));
 
 #include "logits_gather_asm.inc"
 
-__host__ __device__ constexpr int logits_waves(int q) { return q == 21 ? DCA_LOGITS_WAVES_Q21 : DCA_LOGITS_WAVES_Q5; }
-__host__ __device__ constexpr int logits_nseq(int q) { return q == 21 ? DCA_LOGITS_NSEQ_Q21 : DCA_LOGITS_NSEQ_Q5; }   // per wave
+// "q = 25" in the helpers and kernel templates below is the SITE-PAIR ALPHABET of q = 5 (float32 only, round 5): the unit a
+// gather block walks is a pair of neighbouring sites (2 jp, 2 jp + 1) with the combined state 5 x1 + x2.  Logits: the 25
+// sums W[(j1, b1)] + W[(j2, b2)] are formed once per wave and pair in registers (10 row reads + 25 packed adds), after which
+// a sequence costs ONE M0 write and ONE indexed add per PAIR of sites -- (25 + 80) adds per 160 (sequence, site) units.
+// Scatter: 25 accumulators per pair selected by the combined state, one add per row and pair, marginalised to 5 + 5 sums
+// when the workgroup stores.  An odd L pairs its last site with a padding site (state 0; its rows of W are zero, its rows
+// of G lie in the padding of the allocation).  The sums are re-associated, so this is a float32 formulation; the
+// float64 (parity) mode keeps the per-site blocks.
+constexpr int kPairQ = 25;
+__host__ __device__ constexpr int logits_waves(int q) { return q == 21 ? DCA_LOGITS_WAVES_Q21 : q == kPairQ ? DCA_LOGITS_WAVES_Q25 : DCA_LOGITS_WAVES_Q5; }
+__host__ __device__ constexpr int logits_nseq(int q) { return q == 21 ? DCA_LOGITS_NSEQ_Q21 : q == kPairQ ? DCA_LOGITS_NSEQ_Q25 : DCA_LOGITS_NSEQ_Q5; }   // per wave
 __host__ __device__ constexpr int logits_seq_per_wg(int q) { return logits_waves(q) * logits_nseq(q); }
 // 64-byte lines that the 2*nseq bytes of one wave's state words of one site can span (their offset
 // is a multiple of 2*nseq)
@@ -105,7 +114,8 @@ __host__ __device__ constexpr int logits_lines_per_site(int nseq)
     const int g = (bytes & -bytes) > 64 ? 64 : (bytes & -bytes);
     return (64 - g + bytes + 63) / 64;
 }
-__host__ __device__ constexpr int logits_jt(int q) { return q == 21 ? 6 : 25; }   // sites per LDS tile (<= 128 rows)
+__host__ __device__ constexpr int logits_jt(int q) { return q == 21 ? 6 : q == kPairQ ? 12 : 25; }   // sites (q = 25: site pairs) per LDS tile (<= 128 rows)
+__host__ __device__ constexpr int logits_tile_rows(int q) { return q == kPairQ ? 12 * 2 * 5 : logits_jt(q) * q; }
 
 // XL[j][n] = 0x2000 | 2 * x_nj (M0 image: src1-relative + register-pair offset); state 0 past N and for
 // the padding sites j >= L of the last tile (their rows of W are zero)
@@ -116,6 +126,24 @@ __global__ void plm_build_logit_states_kernel(const uint8_t* __restrict__ X, uin
     const int j = blockIdx.y;
     if (n >= Npad) return;
     XL[(size_t)j * Npad + n] = (uint16_t)(0x2000u | ((n < N && j < L) ? 2u * X[(size_t)n * Ls + j] : 0u));
+}
+
+// site-pair alphabet (q = 5): the same M0 images over the combined state 5 x_{n,2jp} + x_{n,2jp+1}; `tag` = 0x2000 for the
+// logits kernel (row stride Npad, sequences from 0), 0x9000 for the scatter kernel (row stride NT, owned sequences from halo);
+// state 0 past N, for the padding pairs of the last tile and for the padding site that an odd L pairs its last site with
+__global__ void plm_build_pair_states_kernel(const uint8_t* __restrict__ X, uint16_t* __restrict__ XP, int N, int stride, int L, int Ls,
+                                             int first, uint32_t tag)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int jp = blockIdx.y;
+    if (k >= stride) return;
+    const int n = first + k;
+    uint32_t st = 0;
+    if (n < N && 2 * jp < L) {
+        const uint8_t* row = X + (size_t)n * Ls;
+        st = 5u * row[2 * jp] + (2 * jp + 1 < L ? (uint32_t)row[2 * jp + 1] : 0u);
+    }
+    XP[(size_t)jp * stride + k] = (uint16_t)(tag | 2u * st);
 }
 
 template <int NP>
@@ -149,8 +177,10 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
     constexpr int WAVES = logits_waves(Q);
     constexpr int NSEQ = logits_nseq(Q);
     constexpr int JT = logits_jt(Q);
+    constexpr int TROWS = logits_tile_rows(Q);      // rows of W per tile (Q = 25: 12 site pairs = 24 sites of 5 rows)
     constexpr int CW = 512 / (int)sizeof(T);
-    constexpr int TILE = 128 * 512;                 // bytes of one LDS buffer (JT*Q <= 128 rows)
+    constexpr int TILE = 128 * 512;                 // bytes of one LDS buffer (TROWS <= 128 rows)
+    static_assert(Q != kPairQ || sizeof(T) == 4, "the site-pair alphabet is a float32 formulation");
     constexpr int PIECES = TILE / 1024;             // 1 KiB (two rows) per LDS-DMA instruction
     constexpr int DMA_PER_WAVE = (PIECES + WAVES - 1) / WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
@@ -195,7 +225,7 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
             const int pairIdx = wave + i * WAVES;                     // wave-uniform
             if (PIECES % WAVES != 0 && pairIdx >= PIECES) break;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(Wbytes + (size_t)(jt * (JT * Q) + pairIdx * 2) * rowStrideBytes + voff),
+                (const __attribute__((address_space(1))) void*)(Wbytes + (size_t)(jt * TROWS + pairIdx * 2) * rowStrideBytes + voff),
                 (__attribute__((address_space(3))) void*)(dca_smem + buf * TILE + pairIdx * 1024), 16, 0, 0);
         }
     };
@@ -229,9 +259,10 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
         const uint32_t strideBytes = (uint32_t)Npad * 2u;
         // the block also issues this wave's LDS-DMA pieces of tile jt+1 (piece i = wave + i*WAVES), spread over its sites
         const uint32_t npc = __builtin_amdgcn_readfirstlane((jt + 1 < numJT && !(DCA_LOGITS_ABLATE & 2)) ? (uint32_t)((PIECES - wave + WAVES - 1) / WAVES) : 0u);
-        const unsigned char* gbase = Wbytes + (size_t)((jt + 1) * (JT * Q) + wave * 2) * rowStrideBytes;     // wave-uniform
+        const unsigned char* gbase = Wbytes + (size_t)((jt + 1) * TROWS + wave * 2) * rowStrideBytes;     // wave-uniform
         const uint32_t ldst = (uint32_t)(uintptr_t)dca_smem + (buf ^ 1) * TILE + wave * 1024;
-        if constexpr (Q == 21 && sizeof(T) == 4) DCA_LOGITS_Q21_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
+        if constexpr (Q == kPairQ) DCA_LOGITS_Q25_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
+        else if constexpr (Q == 21 && sizeof(T) == 4) DCA_LOGITS_Q21_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
         else if constexpr (Q == 21) DCA_LOGITS_Q21_F64(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
         else if constexpr (sizeof(T) == 4) DCA_LOGITS_Q5_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
         else DCA_LOGITS_Q5_F64(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
@@ -416,6 +447,8 @@ void plm_softmax_kernel(const T* __restrict__ SR, T* __restrict__ Rout, const T*
 constexpr int kNC = 128;           // sequences per scatter tile
 constexpr int kRowBytes = 512;     // bytes of one staged row (64 lanes x 8 B)
 constexpr int kScatWavesC = 16;
+constexpr int kCanonBlock = 16384;  // float64 mode: sequences per block of the canonical summation order (= ORACLE_CANONICAL_BLOCK)
+static_assert(kCanonBlock % kNC == 0, "canonical blocks are whole tiles");
 
 // XT2[j][k] = 0x9000 | 2 * x_{halo+k, j}: the M0 image that selects the accumulator of the state
 // (index-enable bits for src0 and dst + register-pair offset); state 0 past N (zero rows); row stride NT
@@ -461,6 +494,38 @@ template <> struct SiteAcc<5> {
     }
 };
 
+template <> struct SiteAcc<kPairQ> {            // a site PAIR of q = 5: accumulator 5 b1 + b2
+    dca_v32f a; dca_v16f b; dca_v2f c;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[i] = 0.f;
+        c[0] = c[1] = 0.f;
+    }
+    template <int S> __device__ __forceinline__ dca_v2f get() const {
+        if constexpr (S < 16) return dca_v2f{a[2 * S], a[2 * S + 1]};
+        else if constexpr (S < 24) return dca_v2f{b[2 * (S - 16)], b[2 * (S - 16) + 1]};
+        else return c;
+    }
+};
+
+// site pair -> the 5 + 5 rows of its two sites: G[(2 jp, b1)] = sum_b2 A[5 b1 + b2], G[(2 jp + 1, b2)] = sum_b1 A[5 b1 + b2],
+// each in ascending order of the summed state; rowBase = row (2 jp, 0) of the strip
+template <int B = 0>
+__device__ __forceinline__ void scatter_store_pair(const SiteAcc<kPairQ>& acc, unsigned char* rowBase, size_t rowStrideBytes)
+{
+    if constexpr (B < 5) {
+        const dca_v2f first = (((acc.template get<5 * B>() + acc.template get<5 * B + 1>()) + acc.template get<5 * B + 2>()) +
+                               acc.template get<5 * B + 3>()) + acc.template get<5 * B + 4>();
+        const dca_v2f second = (((acc.template get<B>() + acc.template get<5 + B>()) + acc.template get<10 + B>()) +
+                                acc.template get<15 + B>()) + acc.template get<20 + B>();
+        *reinterpret_cast<dca_v2f*>(rowBase + (size_t)B * rowStrideBytes) = first;
+        *reinterpret_cast<dca_v2f*>(rowBase + (size_t)(5 + B) * rowStrideBytes) = second;
+        scatter_store_pair<B + 1>(acc, rowBase, rowStrideBytes);
+    }
+}
+
 template <int Q, int S = 0>
 __device__ __forceinline__ void scatter_store_site(const SiteAcc<Q>& acc, unsigned char* rowBase, size_t rowStrideBytes)
 {
@@ -470,19 +535,50 @@ __device__ __forceinline__ void scatter_store_site(const SiteAcc<Q>& acc, unsign
     }
 }
 
+// float64 mode, end of a canonical block that is not the workgroup's first: G = G + (the block's sums) -- the running sum
+// of the finished blocks on the left, as the oracle adds them (oracle/plm_oracle.c, ORACLE_CANONICAL_BLOCK).  A lane's 8
+// bytes are one double; every address is read and written by this lane only.
+template <int Q, int S, int GROUP, int K = 0>
+__device__ __forceinline__ void scatter_add_rows_f64(const SiteAcc<Q>& acc, const double (&v)[GROUP], unsigned char* rowBase, uint32_t laneOff,
+                                                     size_t rowStrideBytes)
+{
+    if constexpr (K < GROUP && S + K < Q) {
+        *reinterpret_cast<double*>(rowBase + (size_t)(S + K) * rowStrideBytes + laneOff) = v[K] + __builtin_bit_cast(double, acc.template get<S + K>());
+        scatter_add_rows_f64<Q, S, GROUP, K + 1>(acc, v, rowBase, laneOff, rowStrideBytes);
+    }
+}
+
+// rowBase: the wave-uniform address of row (site, 0) of the strip, laneOff = 8 * lane -- kept apart so that the row
+// addresses are scalar base + 32-bit lane offset (no 64-bit address registers per row).
+template <int Q, int S = 0>
+__device__ __forceinline__ void scatter_add_site_f64(const SiteAcc<Q>& acc, unsigned char* rowBase, uint32_t laneOff, size_t rowStrideBytes)
+{
+    if constexpr (S < Q) {
+        constexpr int GROUP = 7;          // rows in flight: the accumulators are pinned and the kernel has 128 registers
+        double v[GROUP];
+#pragma unroll
+        for (int k = 0; k < GROUP; ++k)
+            if (S + k < Q) v[k] = *reinterpret_cast<const double*>(rowBase + (size_t)(S + k) * rowStrideBytes + laneOff);
+        scatter_add_rows_f64<Q, S, GROUP>(acc, v, rowBase, laneOff, rowStrideBytes);
+        asm volatile("" ::: "memory");
+        scatter_add_site_f64<Q, S + GROUP>(acc, rowBase, laneOff, rowStrideBytes);
+    }
+}
+
 template <typename T, int Q, int JW, int WAVES_>
 __global__ __launch_bounds__(WAVES_ * 64)
 void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT2,
                         T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int NT, int ctBase, int numPairs, int splitX,
-                        int numJG, int chunksPerSplit, size_t slabElems)
+                        int numJG, int chunksPerSplit, size_t slabElems, int blockChunks)
 {
     constexpr int WAVES = WAVES_;                      // 16; 8 or 4 in the float64 mode on alignments with few column strips (configure)
-    constexpr int JG = WAVES * JW;                     // sites per workgroup
+    constexpr int JG = WAVES * JW;                     // sites (Q = 25: site pairs; L is then their number) per workgroup
+    constexpr int QROWS = Q == kPairQ ? 10 : Q;        // rows of G per unit
     constexpr int CW = kRowBytes / (int)sizeof(T);     // columns per strip
     constexpr int DMA_PER_WAVE = kNC / 2 / WAVES;      // LDS-DMA instructions per wave and tile
     constexpr int TILE = kNC * kRowBytes;
     static_assert(kNC % (2 * WAVES) == 0, "tile rows must divide over the waves");
-    static_assert(JW == 2 && (Q == 21 || Q == 5), "no generated gather block for this shape");
+    static_assert(JW == 2 && (Q == 21 || Q == 5 || (Q == kPairQ && sizeof(T) == 4)), "no generated gather block for this shape");
     static_assert(WAVES == 16 || (sizeof(T) == 8 && (WAVES == 8 || WAVES == 4)), "no generated gather block for this workgroup size");
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
 
@@ -533,45 +629,77 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
 
     if (cBegin < cEnd) stage(cBegin, 0);
     const uint32_t ldsBase = (uint32_t)(uintptr_t)dca_smem + lane * 8;
-    for (int c = cBegin; c < cEnd; ++c) {
-        const int buf = (c - cBegin) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile c have landed
-        if (!(DCA_SCATTER_ABLATE & 1)) __syncthreads();                 // ... everyone's; and tile c-1 is no longer read
-        const uint32_t vbase = ldsBase + buf * TILE;
-        // two sites per wave: the state words come through scalar loads inside the block, which also
-        // issues the wave's four LDS-DMA pieces of tile c+1, one per quarter tile
-        const uint32_t* sp0 = xs[0] + c * (kNC / 2);
-        const uint32_t* sp1 = xs[1] + c * (kNC / 2);
-        const uint32_t npc = __builtin_amdgcn_readfirstlane((c + 1 < cEnd && !(DCA_SCATTER_ABLATE & 8)) ? 1u : 0u);
-        const unsigned char* gbase = tile_src(c + 1);
-        const uint32_t ldst = (uint32_t)(uintptr_t)dca_smem + (buf ^ 1) * TILE + wave * DMA_PER_WAVE * 1024;
-        uint32_t vtmp;
-        [[maybe_unused]] uint32_t vw;       // LDS address / staging registers of the generator's register-staged variant
-        [[maybe_unused]] dca_v4u stg;       // (DCA_GEN_SC_STAGE=vgpr; the shipped LDS-DMA blocks do not use them)
-        if constexpr (Q == 21 && sizeof(T) == 4)
-            DCA_GATHER_Q21_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
-        else if constexpr (Q == 21 && WAVES == 16)
-            DCA_GATHER_Q21_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
-        else if constexpr (Q == 21 && WAVES == 8)
-            DCA_GATHER_Q21_F64_SMEM_W8(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
-        else if constexpr (Q == 21)
-            DCA_GATHER_Q21_F64_SMEM_W4(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
-        else if constexpr (sizeof(T) == 4)
-            DCA_GATHER_Q5_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
-        else if constexpr (WAVES == 16)
-            DCA_GATHER_Q5_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
-        else if constexpr (WAVES == 8)
-            DCA_GATHER_Q5_F64_SMEM_W8(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
-        else
-            DCA_GATHER_Q5_F64_SMEM_W4(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
-    }
-
     T* const Gslab = G + (size_t)split * slabElems;
+    auto run_tiles = [&](int cFrom, int cTo) {
+        for (int c = cFrom; c < cTo; ++c) {
+            const int buf = (c - cBegin) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile c have landed
+            if (!(DCA_SCATTER_ABLATE & 1)) __syncthreads();                 // ... everyone's; and tile c-1 is no longer read
+            const uint32_t vbase = ldsBase + buf * TILE;
+            // two sites per wave: the state words come through scalar loads inside the block, which also
+            // issues the wave's four LDS-DMA pieces of tile c+1, one per quarter tile
+            const uint32_t* sp0 = xs[0] + c * (kNC / 2);
+            const uint32_t* sp1 = xs[1] + c * (kNC / 2);
+            const uint32_t npc = __builtin_amdgcn_readfirstlane((c + 1 < cEnd && !(DCA_SCATTER_ABLATE & 8)) ? 1u : 0u);
+            const unsigned char* gbase = tile_src(c + 1);
+            const uint32_t ldst = (uint32_t)(uintptr_t)dca_smem + (buf ^ 1) * TILE + wave * DMA_PER_WAVE * 1024;
+            uint32_t vtmp;
+            [[maybe_unused]] uint32_t vw;       // LDS address / staging registers of the generator's register-staged variant
+            [[maybe_unused]] dca_v4u stg;       // (DCA_GEN_SC_STAGE=vgpr; the shipped LDS-DMA blocks do not use them)
+            if constexpr (Q == kPairQ)
+                DCA_GATHER_Q25_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+            else if constexpr (Q == 21 && sizeof(T) == 4)
+                DCA_GATHER_Q21_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+            else if constexpr (Q == 21 && WAVES == 16)
+                DCA_GATHER_Q21_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+            else if constexpr (Q == 21 && WAVES == 8)
+                DCA_GATHER_Q21_F64_SMEM_W8(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+            else if constexpr (Q == 21)
+                DCA_GATHER_Q21_F64_SMEM_W4(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[0].c, acc[1].a, acc[1].b, acc[1].c);
+            else if constexpr (sizeof(T) == 4)
+                DCA_GATHER_Q5_F32_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+            else if constexpr (WAVES == 16)
+                DCA_GATHER_Q5_F64_SMEM(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+            else if constexpr (WAVES == 8)
+                DCA_GATHER_Q5_F64_SMEM_W8(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+            else
+                DCA_GATHER_Q5_F64_SMEM_W4(vbase, sp0, sp1, npc, gbase, ginc, voff, ldst, vtmp, stg, vw, acc[0].a, acc[0].b, acc[1].a, acc[1].b);
+        }
+    };
+    auto row_base = [&](int jj, uint32_t laneOff) {
+        return reinterpret_cast<unsigned char*>(Gslab + (size_t)(j0 + jj) * QROWS * Cs + (size_t)ct * CW) + laneOff;
+    };
+    auto row_base_uniform = [&](int jj) { return reinterpret_cast<unsigned char*>(Gslab + (size_t)(j0 + jj) * QROWS * Cs + (size_t)ct * CW); };
+
+    if constexpr (sizeof(T) == 8) {
+        // float64 (parity) mode: the chains run over canonical blocks of blockChunks tiles (kCanonBlock sequences), each
+        // summed from zero; a workgroup with several blocks stores the first block's sums and adds every later block to the
+        // running sum in G: ((B0 + B1) + B2) + ..., the oracle's order (blockChunks = 0: one chain over the whole range)
+        const int blockLen = blockChunks > 0 ? blockChunks : max(1, cEnd - cBegin);
+        for (int cb = cBegin; cb < cEnd || cb == cBegin; cb += blockLen) {
 #pragma unroll
-    for (int jj = 0; jj < JW; ++jj)
-        if (j0 + jj < L)
-            scatter_store_site<Q>(acc[jj], reinterpret_cast<unsigned char*>(Gslab + (size_t)(j0 + jj) * Q * Cs + (size_t)ct * CW) + lane * 8,
-                                  rowStrideBytes);
+            for (int jj = 0; jj < JW; ++jj) acc[jj].zero();
+            run_tiles(cb, min(cEnd, cb + blockLen));
+            // the lane offset is re-made per block: as a loop invariant the 2 Q row addresses of the flush were hoisted out of
+            // the block loop and spilled (142 registers of the 128 this kernel is built for)
+            uint32_t laneOff = lane * 8;
+            asm volatile("" : "+v"(laneOff));
+#pragma unroll
+            for (int jj = 0; jj < JW; ++jj)
+                if (j0 + jj < L) {
+                    if (cb == cBegin) scatter_store_site<Q>(acc[jj], row_base(jj, laneOff), rowStrideBytes);
+                    else scatter_add_site_f64<Q>(acc[jj], row_base_uniform(jj), laneOff, rowStrideBytes);
+                }
+        }
+    } else {
+        run_tiles(cBegin, cEnd);
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj)
+            if (j0 + jj < L) {
+                if constexpr (Q == kPairQ) scatter_store_pair(acc[jj], row_base(jj, lane * 8), rowStrideBytes);
+                else scatter_store_site<Q>(acc[jj], row_base(jj, lane * 8), rowStrideBytes);
+            }
+    }
 }
 
 // G[0] += G[1] + ... + G[nsplit-1], fixed order (deterministic).  Used when there are more than two slabs
@@ -1252,6 +1380,13 @@ struct PlmEngine : PlmEngineBase {
     int numScanChunks = 0, numScatChunks = 0;
     static constexpr int kScatWaves = 16;
     int scatSplit = 1, scatChunksPerSplit = 0, scatJW = 2, scatWaves = kScatWavesC;
+    int scatBlockChunks = 0;           // float64 mode: tiles per canonical block of sequences (0: plain chains)
+    bool scatPerBlock = false;         // ... with one workgroup and one slab of G per block
+    // q = 5 in float32: both gather kernels walk site PAIRS on the 25-state combined alphabet (kPairQ; DCA_PLM_PAIRS=0: the
+    // per-site blocks, for comparisons).  gUnits = what the kernels' "L" counts: pairs then, sites otherwise.
+    bool pairs = false;
+    int gUnits = 0;
+    int logits_q() const { return pairs ? kPairQ : q; }
     int scatRemCT = 0, scatRemSplit = 0, scatRemChunksPerSplit = 0;     // left-over strips (numCT % 8) in their own, finer split launch
 
     T *dx = nullptr, *dg = nullptr, *dxp = nullptr, *dgp = nullptr, *dd = nullptr;
@@ -1388,12 +1523,17 @@ struct PlmEngine : PlmEngineBase {
         const int Lq = L * q;
         const int LqLoc = Lloc * q;
         Cs = (int)round_up(LqLoc, 128);
-        const int JT = jt();
-        Wrows = ceil_div(L, JT) * JT * q + 128;     // + over-read margin of the last LDS-DMA tile
-        scatJW = 2;     // sites per wave of the scatter kernel
+        {
+            const char* pe = getenv("DCA_PLM_PAIRS");
+            pairs = q == 5 && sizeof(T) == 4 && !(pe && atoi(pe) == 0);
+        }
+        gUnits = pairs ? ceil_div(L, 2) : L;
+        const int JT = logits_jt(logits_q());       // units per logits tile
+        Wrows = ceil_div(gUnits, JT) * logits_tile_rows(logits_q()) + 128;     // + over-read margin of the last LDS-DMA tile
+        scatJW = 2;     // units per wave of the scatter kernel
         const int JG = kScatWavesC * scatJW;
-        Grows = ceil_div(L, JG) * JG * q;
-        Npad = (int)round_up(N, logits_seq_per_wg(q));
+        Grows = ceil_div(gUnits, JG) * JG * (pairs ? 2 * q : q);
+        Npad = (int)round_up(N, logits_seq_per_wg(logits_q()));
 
         DCA_TRY(dalloc(&dx, P + kVecPad)); DCA_TRY(dalloc(&dg, P + kVecPad));
         DCA_TRY(dalloc(&dWt, (size_t)Wrows * Cs));
@@ -1412,7 +1552,7 @@ struct PlmEngine : PlmEngineBase {
             // DCA_SCATTER_REM; scatter + fold, ms): D 1 + left-over 7.28 (split 2 without: 7.74), D/8 1.19 (1.34),
             // C 0.376 (0.458 for the best split without a left-over launch), E split 19-32: 0.90 (51: 0.93).
             const int cw = kRowBytes / (int)sizeof(T);
-            const int numCT = ceil_div(Cs, cw), numJGs = ceil_div(L, JG);
+            const int numCT = ceil_div(Cs, cw), numJGs = ceil_div(gUnits, JG);
             const int fullCT = numCT / kNumXcd * kNumXcd, rem = numCT - fullCT;
             const int s0 = std::max(1, std::min({numScatChunks, ceil_div(2048, numCT * numJGs), std::max(1, numScatChunks / 12)}));
             const int cuPerXcd = 256 / kNumXcd;
@@ -1422,18 +1562,39 @@ struct PlmEngine : PlmEngineBase {
             const char* splitEnv = getenv("DCA_SCATTER_SPLIT");    // tuning knob: the split of the main launch
             double bestCost = 1e300;
             scatSplit = 1; scatChunksPerSplit = numScatChunks; scatRemCT = scatRemSplit = scatRemChunksPerSplit = 0;
-            // float64 = parity mode: ONE chain per (site, state, column) over the sequences in ascending order -- the oracle's
-            // (and the reference's one-thread) order of summation, so that the gradient does not depend on the launch
-            // geometry; no tile-range split and no separate launch for the left-over strips unless a test forces them
+            // float64 = parity mode: the oracle's order of summation -- per (site, state, column) the sequences in ascending
+            // order inside blocks of kCanonBlock, the block sums added in ascending block order (oracle/plm_oracle.c,
+            // ORACLE_CANONICAL_BLOCK; round 4: one chain over all N) -- so that the gradient does not depend on the launch
+            // geometry.  Two geometries give exactly that order: ONE workgroup per (strip, site group) that adds its
+            // finished block to the running sum in G and restarts its chains (plm_scatter_kernel, blockChunks), or one
+            // workgroup and one slab PER BLOCK, the slabs summed in ascending order by plm_sum_slabs_kernel.  The second
+            // fills the chip where strips x site groups do not (config E: 12 x 5 = 60 workgroups, 49 blocks), the first
+            // saves the slab traffic where they do (config D: 2656 workgroups, 13 blocks = 11.6 GB of slabs).  No separate
+            // launch for the left-over strips; a test that forces a split or that launch leaves the canonical order.
             const bool canonical = sizeof(T) == 8 && !splitEnv && !remEnv;
-            // ... which leaves (strips x site groups) workgroups: where that does not fill the chip (config E: 12 x 5 = 60),
-            // workgroups of 8 waves (16 sites) spread the same chains over twice the CUs (E: 120; scatter 4.53 -> 3.87 ms).
-            // 4 waves (228 workgroups) measured 7.66 ms: one wave per SIMD cannot cover the M0 -> add chain.  DCA_SCATTER_WAVES forces.
             scatWaves = kScatWavesC;
+            scatBlockChunks = 0;
+            scatPerBlock = false;
             if (canonical) {
-                const char* we = getenv("DCA_SCATTER_WAVES");
-                if (we && (atoi(we) == 16 || atoi(we) == 8 || atoi(we) == 4)) scatWaves = atoi(we);
-                else if ((long long)numCT * ceil_div(L, scatWaves * scatJW) < 192) scatWaves = 8;
+                scatBlockChunks = kCanonBlock / kNC;
+                const int nblocks = ceil_div(numScatChunks, scatBlockChunks);
+                const char* we = getenv("DCA_SCATTER_WAVES");          // tuning knob (one-workgroup geometry)
+                const char* ge = getenv("DCA_SCATTER_CANON");          // tuning / test knob: 1 one workgroup, 2 slab per block
+                auto perXcdOf = [&](int waves, int sp) {
+                    const int njg = ceil_div(gUnits, waves * scatJW);
+                    return fullCT > 0 ? (long long)ceil_div(numCT, kNumXcd) * njg * sp : (long long)ceil_div(numCT * sp, kNumXcd) * njg;
+                };
+                // one workgroup: 16 waves, or 8 where that does not fill the chip (twice the workgroups; 4 waves measured slower)
+                int wavesA = kScatWavesC;
+                if (we && (atoi(we) == 16 || atoi(we) == 8 || atoi(we) == 4)) wavesA = atoi(we);
+                else if ((long long)numCT * ceil_div(gUnits, kScatWavesC * scatJW) < 192) wavesA = 8;
+                // (a tile of an 8-wave workgroup takes 0.85 of a 16-wave one's time: E 3.87 against 4.53 ms on one round each;
+                // the (strip, block) pairs of the second geometry are dealt to the XCDs one by one, see launch_eval)
+                const double costA = rounds(perXcdOf(wavesA, 1)) * (numScatChunks * (wavesA == 8 ? 0.85 : 1.0) + 2.0 + 0.5 * (nblocks - 1));
+                const double costB = rounds((long long)ceil_div(numCT * nblocks, kNumXcd) * numJGs) * (scatBlockChunks + 2.0) + (nblocks - 1) * slabUnits;
+                scatPerBlock = nblocks > 1 && (ge ? atoi(ge) == 2 : costB < costA);
+                if (scatPerBlock) { scatSplit = nblocks; scatChunksPerSplit = scatBlockChunks; }
+                else scatWaves = wavesA;
             }
             for (int sp = 1; sp <= (canonical ? 0 : (splitEnv ? numScatChunks : s0)); ++sp) {
                 if (splitEnv && sp != std::max(1, std::min(numScatChunks, atoi(splitEnv)))) continue;
@@ -1461,9 +1622,9 @@ struct PlmEngine : PlmEngineBase {
         }
         DCA_TRY(dalloc(&dG, (size_t)std::max(scatSplit, scatRemSplit) * Grows * Cs));
         DCA_TRY(dalloc(&dw, N));
-        DCA_TRY(dalloc(&dXL, (size_t)ceil_div(L, JT) * JT * Npad));
+        DCA_TRY(dalloc(&dXL, (size_t)ceil_div(gUnits, JT) * JT * Npad));
         NT = numScatChunks * kNC;
-        DCA_TRY(dalloc(&dXT2, (size_t)L * NT));
+        DCA_TRY(dalloc(&dXT2, (size_t)gUnits * NT));
         const size_t npairs = (size_t)L * (L - 1) / 2;
         DCA_TRY(dalloc(&dPairs, npairs));
         nFxPart = ceil_div(Lloc, 64) * ceil_div(numScanChunks, 4) * 4;
@@ -1535,7 +1696,14 @@ struct PlmEngine : PlmEngineBase {
         }
         HIP_TRY(hipMemcpy(dw, hw.data(), (size_t)N * sizeof(T), hipMemcpyHostToDevice));
 
-        {
+        if (pairs) {
+            hipLaunchKernelGGL(plm_build_pair_states_kernel, dim3(ceil_div(Npad, 256), ceil_div(gUnits, JT) * JT), dim3(256), 0,
+                               ctx->stream, ctx->dX, dXL, N, Npad, L, Ls, 0, 0x2000u);
+            hipLaunchKernelGGL(plm_build_pair_states_kernel, dim3(ceil_div(NT, 256), gUnits), dim3(256), 0, ctx->stream,
+                               ctx->dX, dXT2, N, NT, L, Ls, halo, 0x9000u);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else {
             hipLaunchKernelGGL(plm_build_logit_states_kernel, dim3(ceil_div(Npad, 256), ceil_div(L, JT) * JT), dim3(256), 0,
                                ctx->stream, ctx->dX, dXL, N, Npad, L, Ls);
             hipLaunchKernelGGL(plm_build_states_kernel, dim3(ceil_div(NT, 256), L), dim3(256), 0, ctx->stream,
@@ -1645,13 +1813,20 @@ struct PlmEngine : PlmEngineBase {
         {
             constexpr int CW = 512 / (int)sizeof(T);
             const int numCT = ceil_div(Cs, CW);
-            const int numNB = Npad / logits_seq_per_wg(q);
-            const int blocks = numCT * numNB;
-            const size_t lds = (size_t)2 * 128 * 512 + (size_t)logits_waves(Q) * 256;   // two tiles + prefetch scratch
-            auto kern = plm_logits_kernel<T, Q>;
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            ScopedKernelClock kc(ctx, "plm_logits");
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(logits_waves(Q) * 64), lds, st, dWt, dXL, dSR, N, Npad, L, Cs, numCT, numNB);
+            auto launch = [&](auto kern, int QL) -> int {          // QL: the kernel's alphabet (kPairQ: gUnits site pairs)
+                const int numNB = Npad / logits_seq_per_wg(QL);
+                const int blocks = numCT * numNB;
+                const size_t lds = (size_t)2 * 128 * 512 + (size_t)logits_waves(QL) * 256;   // two tiles + prefetch scratch
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ScopedKernelClock kc(ctx, "plm_logits");
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(logits_waves(QL) * 64), lds, st, dWt, dXL, dSR, N, Npad, gUnits, Cs, numCT, numNB);
+                return DCA_OK;
+            };
+            bool done = false;
+            if constexpr (Q == 5 && sizeof(T) == 4) {
+                if (pairs) { DCA_TRY(launch(plm_logits_kernel<T, kPairQ>, kPairQ)); done = true; }
+            }
+            if (!done) DCA_TRY(launch(plm_logits_kernel<T, Q>, Q));
         }
         DCA_ROUND_STAGE(2, dSR, (size_t)N * Cs);
         {
@@ -1668,23 +1843,23 @@ struct PlmEngine : PlmEngineBase {
         {
             constexpr int CW = kRowBytes / (int)sizeof(T);
             const int numCT = ceil_div(Cs, CW);
-            const int numJG = ceil_div(L, scatWaves * scatJW);
+            const int numJG = ceil_div(gUnits, scatWaves * scatJW);
             const int scatThreads = scatWaves * 64;
             const int mainCT = numCT - scatRemCT;            // strips of the main launch (all of them without a left-over launch)
             const size_t lds = (size_t)2 * kNC * kRowBytes;
             auto launch = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ScopedKernelClock kc(ctx, "plm_scatter");
-                if (numCT < kNumXcd)        // E: 6 strips would leave two XCDs idle: deal the (strip, split) pairs to the XCDs instead
+                if (numCT < kNumXcd || scatPerBlock)        // E: 6 strips would leave two XCDs idle: deal the (strip, split) pairs to the XCDs instead
                     hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(numCT * scatSplit, kNumXcd) * numJG, 1), dim3(scatThreads), lds, st, dR, dXT2, dG,
-                                       N, L, Cs, halo, numScatChunks, NT, 0, numCT * scatSplit, scatSplit, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
+                                       N, gUnits, Cs, halo, numScatChunks, NT, 0, numCT * scatSplit, scatSplit, numJG, scatChunksPerSplit, (size_t)Grows * Cs, scatBlockChunks);
                 else
                     hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(mainCT, kNumXcd) * numJG, scatSplit), dim3(scatThreads), lds, st, dR, dXT2, dG,
-                                       N, L, Cs, halo, numScatChunks, NT, 0, mainCT, 1, numJG, scatChunksPerSplit, (size_t)Grows * Cs);
+                                       N, gUnits, Cs, halo, numScatChunks, NT, 0, mainCT, 1, numJG, scatChunksPerSplit, (size_t)Grows * Cs, scatBlockChunks);
                 if (scatRemCT) {
-                    const int pairs = scatRemCT * scatRemSplit;
-                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(pairs, kNumXcd) * numJG, 1), dim3(scatThreads), lds, st, dR, dXT2, dG,
-                                       N, L, Cs, halo, numScatChunks, NT, mainCT, pairs, scatRemSplit, numJG, scatRemChunksPerSplit, (size_t)Grows * Cs);
+                    const int remPairs = scatRemCT * scatRemSplit;
+                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(remPairs, kNumXcd) * numJG, 1), dim3(scatThreads), lds, st, dR, dXT2, dG,
+                                       N, gUnits, Cs, halo, numScatChunks, NT, mainCT, remPairs, scatRemSplit, numJG, scatRemChunksPerSplit, (size_t)Grows * Cs, 0);
                     const int col0 = mainCT * CW, ncols = Cs - col0;
                     hipLaunchKernelGGL(plm_sum_slabs_cols_kernel<T>, dim3((unsigned)(((size_t)Lq * ncols + 255) / 256)), dim3(256), 0, st, dG,
                                        (size_t)Grows * Cs, Cs, col0, ncols, Lq, scatRemSplit, scatSplit);
@@ -1694,6 +1869,9 @@ struct PlmEngine : PlmEngineBase {
             if constexpr (sizeof(T) == 8) {
                 if (scatWaves == 8) DCA_TRY(launch(plm_scatter_kernel<T, Q, 2, 8>));
                 else if (scatWaves == 4) DCA_TRY(launch(plm_scatter_kernel<T, Q, 2, 4>));
+                else DCA_TRY(launch(plm_scatter_kernel<T, Q, 2, 16>));
+            } else if constexpr (Q == 5) {
+                if (pairs) DCA_TRY(launch(plm_scatter_kernel<T, kPairQ, 2, 16>));
                 else DCA_TRY(launch(plm_scatter_kernel<T, Q, 2, 16>));
             } else {
                 DCA_TRY(launch(plm_scatter_kernel<T, Q, 2, 16>));

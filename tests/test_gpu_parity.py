@@ -147,6 +147,64 @@ def test_gradient_float64_vs_oracle(L_, oracle_plm, tag):
         assert np.array_equal(got[(name, L_.CARRY_CHUNKED)][1], got[(name, L_.CARRY_SERIAL)][1])
 
 
+@pytest.mark.parametrize("q,L,N", [(5, 30, 36000), (21, 20, 50000)])
+def test_float64_canonical_blocks_both_geometries(L_, oracle_plm, monkeypatch, tmp_path, q, L, N):
+    """Round 5: the float64 mode's per-slot chains run over blocks of 16384 sequences whose sums are added in ascending order
+    (the oracle's ORACLE_CANONICAL_BLOCK).  The device has two launch geometries for that order -- one workgroup per (strip,
+    site group) that adds each finished block to the running sum in G, or one workgroup and slab per block with an ordered
+    slab sum -- and picks by a cost model; forced one after the other they give the SAME BITS.  Against the oracle the
+    gradient agrees to the last place or two (the two exp() implementations differ by an ulp, and with chains of thousands
+    of addends most sums see such a term), so the ORDER is pinned by comparison: the device's blocked sums are equal to
+    the blocked oracle's in far more elements than to a single-chain build of the same oracle, and the device forced to
+    round 4's single chain (a forced split of one leaves the canonical order) the other way round."""
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "liboracle_chain.so")
+    subprocess.check_call(["gcc", "-O3", "-fopenmp", "-fno-fast-math", "-ffp-contract=off", "-shared", "-fPIC",
+                           "-DORACLE_CANONICAL_BLOCK=1000000000", "-o", so, os.path.join(here, "oracle", "plm_oracle.c"), "-lm"])
+    chain_f = C.CDLL(so).oracle_gradient_f64
+    chain_f.restype = C.c_double
+    dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    chain_f.argtypes = [np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                        dp, dp, C.c_int, C.c_int]
+    rng = np.random.default_rng(50 + q)
+    X = np.ascontiguousarray(rng.integers(0, q, size=(N, L), dtype=np.uint8))          # three / four canonical blocks
+    w64 = np.ascontiguousarray(rng.uniform(0.05, 1.0, size=N))
+    x = perturbed(oracle_plm.init_x(X, w64, q), L, q)
+    fx_o, g_o = oracle_plm.gradient(X, w64, q, 0.7, 3.0, x, carry=True)
+    g_c = np.zeros_like(x)
+    chain_f(X, w64, N, L, q, 0.7, 3.0, x, g_c, 1, os.cpu_count())
+    got = {}
+    for name, env in (("one_workgroup", {"DCA_SCATTER_CANON": "1"}), ("slab_per_block", {"DCA_SCATTER_CANON": "2"}), ("picked", {}),
+                      ("single_chain", {"DCA_SCATTER_SPLIT": "1"})):
+        for k in ("DCA_SCATTER_CANON", "DCA_SCATTER_SPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = L_.Context(0, L_.DCA_F64)
+        ctx.set_msa(X, q)
+        ctx.set_weights(w64)
+        ctx.plm_configure(0.7, 3.0, L_.CARRY_CHUNKED)
+        ctx.plm_set_x(x)
+        fx = ctx.plm_gradient()
+        got[name] = (fx, ctx.plm_get_g(np.float64))
+        ctx.close()
+    pairs_part = slice(L * q, None)                      # the coupling gradient: the sums whose order is at stake
+    for name in ("one_workgroup", "slab_per_block", "picked"):
+        fx, g = got[name]
+        assert abs(fx - fx_o) <= 4e-16 * abs(fx_o), (name, fx, fx_o)
+        assert rel_err(g, g_o) < 5e-15, (name, rel_err(g, g_o))
+        assert np.array_equal(g, got["one_workgroup"][1]), name
+        same, other = float(np.mean(g[pairs_part] != g_o[pairs_part])), float(np.mean(g[pairs_part] != g_c[pairs_part]))
+        print("float64 canonical blocks q=%d %s: %.3f of the coupling gradient differs from the blocked oracle, %.3f from the single-chain oracle"
+              % (q, name, same, other))
+        assert same + 0.15 < other, (name, same, other)
+    chain = got["single_chain"][1]
+    assert rel_err(chain, g_o) < 1e-12
+    same, other = float(np.mean(chain[pairs_part] != g_c[pairs_part])), float(np.mean(chain[pairs_part] != g_o[pairs_part]))
+    assert same + 0.15 < other, ("single_chain", same, other)
+
+
 def test_chunked_scan_equals_serial_chain(L_, oracle_plm):
     """The chunk-parallel scan with 40 warm-up steps must reproduce the strictly serial
     carry chain (start-up error <= 2^-40)."""
@@ -605,12 +663,15 @@ def test_scores_order_matches_stable_argsort(L_, oracle_mf):
 
 @pytest.mark.parametrize("N,L,q", [(1, 2, 5), (3, 2, 21), (7, 5, 21), (33, 7, 5), (129, 13, 21), (130, 33, 5),
                                     (513, 6, 21), (640, 25, 5), (257, 31, 21),
-                                    (96, 6, 21), (97, 7, 21), (768, 5, 21), (769, 8, 21), (49, 26, 5), (769, 27, 5)])
+                                    (96, 6, 21), (97, 7, 21), (768, 5, 21), (769, 8, 21), (49, 26, 5), (769, 27, 5),
+                                    (2, 3, 5), (80, 23, 5), (81, 24, 5), (641, 25, 5), (300, 63, 5), (131, 64, 5), (90, 65, 5), (1281, 49, 5)])
 def test_gradient_edge_shapes(L_, oracle_plm, N, L, q):
     """Shapes at and across the tile boundaries of the two gather kernels: fewer sequences than one wave's block of
     the logits kernel (96 for q = 21, 48 for q = 5; 32 earlier) / one 128-row tile / one workgroup's 768 sequences
     (512 earlier), each + 1; fewer sites than one LDS tile of W (6 resp. 25 sites) or one 32-site scatter group (+1), a
-    single sequence, the minimum L = 2."""
+    single sequence, the minimum L = 2.  Round 5 (q = 5, float32: site pairs on the 25-state alphabet): odd L (the last
+    site pairs with a padding site), one wave's 80 sequences and one workgroup's 640 (+1), 12-pair tiles of W (23 / 24 / 25 /
+    49 sites), the scatter kernel's 64-site groups (63 / 64 / 65)."""
     rng = np.random.default_rng(1000 * N + 10 * L + q)
     X = rng.integers(0, q, size=(N, L), dtype=np.uint8)
     X = np.unique(X, axis=0)                      # the library expects de-duplicated rows like the reader yields
@@ -627,6 +688,40 @@ def test_gradient_edge_shapes(L_, oracle_plm, N, L, q):
         assert abs(fx - fx_o) <= tol * abs(fx_o), (prec, fx, fx_o)
         assert rel_err(g, g_o) < tol, (prec, rel_err(g, g_o))
         ctx.close()
+
+
+@pytest.mark.parametrize("tag", ["toy_rna", "rf71", "rf00167"])
+def test_site_pair_alphabet_against_per_site_blocks(L_, oracle_plm, monkeypatch, tag):
+    """q = 5, float32 (round 5): both gather kernels walk PAIRS of sites on the combined 25-state alphabet -- the logits kernel
+    adds W[(j1, b1)] + W[(j2, b2)] formed once per wave and pair, the scatter kernel sums into 25 accumulators per pair and
+    marginalises them when it stores.  Same sums, re-associated: against the per-site blocks (DCA_PLM_PAIRS=0) the objective
+    and the gradient agree to float32 rounding (and are not the same bits), and both stay within the bound the per-site
+    path has against the compiled reference's own (fx, g) (test_gradient_float32_vs_reference: 1e-5)."""
+    G = golden("plm_" + tag)
+    L, q = int(G["L"]), int(G["q"])
+    assert q == 5
+    lh, lJ = float(G["lambda_h"]), float(G["lambda_J"])
+    w = oracle_plm.weights(G["X"], 0.8, np.float32)
+    x = perturbed(oracle_plm.init_x(G["X"], w, q), L, q)
+    out = {}
+    for name, env in (("pairs", None), ("sites", "0")):
+        if env is None:
+            monkeypatch.delenv("DCA_PLM_PAIRS", raising=False)
+        else:
+            monkeypatch.setenv("DCA_PLM_PAIRS", env)
+        ctx = make_ctx(L_, G["X"], q, L_.DCA_F32, 0.8, L_.DCA_F32)
+        ctx.plm_configure(lh, lJ)
+        ctx.plm_set_x(x)
+        fx = ctx.plm_gradient()
+        out[name] = (fx, ctx.plm_get_g(np.float64))
+        ctx.close()
+    fx_o, g_o = oracle_plm.gradient(G["X"], w.astype(np.float64), q, lh, lJ, x.astype(np.float64), carry=True)
+    assert abs(out["pairs"][0] - out["sites"][0]) <= 2e-6 * abs(fx_o)
+    assert rel_err(out["pairs"][1], out["sites"][1]) < 5e-6
+    assert not np.array_equal(out["pairs"][1], out["sites"][1])
+    for name in out:
+        assert abs(out[name][0] - fx_o) <= 1e-5 * abs(fx_o), name
+        assert rel_err(out[name][1], g_o) < 1e-5, (name, rel_err(out[name][1], g_o))
 
 
 def test_device_block_cache_reuse_and_release(L_):

@@ -111,6 +111,44 @@ def test_canonical_float64_order_is_a_reordering_only(oracle_plm, tmp_path):
             assert not np.array_equal(g_c, g_p)            # it IS another order
 
 
+def test_canonical_float64_blocks_are_a_reordering_only(oracle_plm, tmp_path):
+    """Round 5: the float64 oracle's per-slot chains run over blocks of 16384 sequences whose sums are added in ascending
+    order (ORACLE_CANONICAL_BLOCK).  Against a build with one block for everything (round 4's single chain) and against the
+    reference's literal order (-DORACLE_PLAIN_F64): same objective bits, gradient equal up to float64 rounding -- and really
+    another order once the alignment is deeper than one block; identical bits when it is not."""
+    import ctypes as C
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libs = {}
+    for name, flag in (("chain", "-DORACLE_CANONICAL_BLOCK=1000000000"), ("plain", "-DORACLE_PLAIN_F64")):
+        so = str(tmp_path / ("liboracle_%s.so" % name))
+        subprocess.check_call(["gcc", "-O3", "-fopenmp", "-fno-fast-math", "-ffp-contract=off", "-shared", "-fPIC", flag,
+                               "-o", so, os.path.join(here, "oracle", "plm_oracle.c"), "-lm"])
+        f = C.CDLL(so).oracle_gradient_f64
+        f.restype = C.c_double
+        dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+        f.argtypes = [np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), dp, C.c_int, C.c_int, C.c_int, C.c_double,
+                      C.c_double, dp, dp, C.c_int, C.c_int]
+        libs[name] = f
+    rng = np.random.default_rng(5)
+    L, q = 9, 5
+    for N, differs in ((36000, True), (16384, False), (18000, True)):
+        X = np.ascontiguousarray(rng.integers(0, q, size=(N, L), dtype=np.uint8))
+        w = np.ascontiguousarray(rng.uniform(0.1, 1.0, size=N))
+        x = perturbed(oracle_plm.init_x(X, w, q), L, q)
+        for carry in (1, 0):
+            fx_b, g_b = oracle_plm.gradient(X, w, q, 0.3, 2.0, x, carry=bool(carry), threads=3)
+            for name in ("chain", "plain"):
+                g_o = np.zeros_like(x)
+                fx_o = libs[name](X, w, N, L, q, 0.3, 2.0, x, g_o, carry, 3)
+                assert abs(fx_b - fx_o) <= 1e-13 * abs(fx_o), (N, name, carry)
+                assert rel_err(g_b, g_o) < 1e-12, (N, name, carry, rel_err(g_b, g_o))
+                if name == "chain":
+                    assert np.array_equal(g_b, g_o) == (not differs), (N, carry)
+                    assert fx_b == fx_o
+
+
 def test_carry_over_is_what_the_reference_does(oracle_plm):
     """without the carried-over probabilities the result is far off."""
     G = golden("plm_toy_rna")

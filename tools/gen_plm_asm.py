@@ -49,7 +49,7 @@ S0, T0 = 40, 72
 
 def tuples(q):
     """legal VGPR tuple sizes covering 2q registers"""
-    return {21: [32, 8, 2], 5: [8, 2]}[q]
+    return {21: [32, 8, 2], 5: [8, 2], 25: [32, 16, 2]}[q]
 
 
 def plan(q, jw):
@@ -290,7 +290,7 @@ def macro(q, f64, jw=JW):
 
 
 def logits_jt(q):
-    return {21: 6, 5: 25}[q]
+    return {21: 6, 5: 25, 25: 12}[q]          # q = 25: PAIRS of q = 5 sites per tile (24 sites, 120 rows)
 
 
 # (waves per workgroup, sequences per wave) of plm_logits_kernel.  Per site a wave spends a fixed ~490 clk fetching
@@ -301,12 +301,17 @@ def logits_jt(q):
 # isolation with L2-hot state words (tools/experiments/gen_logits8b.py): 1.66 clk per (sequence, site) per CU against
 # 1.88 for 12 waves x 56 sequences with two ping-pong sets (round 1's shape; 16 x 32: 2.25).
 # q=5: 16 waves x 48 sequences, two sets.
-LOGITS_CFG = {21: (8, 96), 5: (16, 48)}
+# "q = 25" is the site-pair alphabet of q = 5 in float32 (round 5, logits_body): a unit of the block is a PAIR of sites, its
+# 25 "rows" are the sums W[(j1, b1)] + W[(j2, b2)] formed once per wave and pair in registers (10 row reads + 25 packed adds),
+# and a sequence then costs ONE M0 write and ONE indexed add per pair of sites: (25 + nseq) adds instead of 2 nseq.
+# 8 waves x 80 sequences on 256 VGPRs: 160 accumulator + 50 table + 20 row registers.
+LOGITS_CFG = {21: (8, 96), 5: (16, 48), 25: (8, 80)}
+LOGITS_PAIR_Q = 5              # states per site of the pair variant
 # Row registers double-buffered (round 4): the q rows of site j+1 are requested WHILE site j's adds issue (one ds_read every
 # few adds, into a second set of q register pairs), so a wave no longer stops for an LDS round trip (~490 clk) in front of
 # every site -- with two waves per SIMD that bubble is what kept the adds at ~57 % of the VALU.  The second set costs 2q
 # registers, i.e. q = 21 runs 80 instead of 96 sequences per wave; only the first site of a tile still waits.
-LOGITS_DBUF = {21: False, 5: False}
+LOGITS_DBUF = {21: False, 5: False, 25: False}
 if os.environ.get("DCA_GEN_LG21"):             # experiments: "waves,nseq,dbuf"
     _w, _n, _d = (int(v) for v in os.environ["DCA_GEN_LG21"].split(","))
     LOGITS_CFG[21] = (_w, _n)
@@ -346,8 +351,13 @@ def logits_plan(q):
     tb = LS0 + (1 if logits_single_set(q) else 2) * nw
     assert tb + 7 <= 96 and nseq % 8 == 0
     w0 = acc0 - 2 * q * (2 if LOGITS_DBUF[q] else 1)
-    assert w0 >= 8, "no VGPRs left for the compiler"
+    assert logits_temp0(q, w0) >= 8, "no VGPRs left for the compiler"
     return waves, nseq, w0, acc0, nw, tb
+
+
+def logits_temp0(q, w0):
+    """first register the block clobbers: the pair variant keeps the 2 x 5 rows it builds its table from below the table"""
+    return w0 - (4 * LOGITS_PAIR_Q if q == 25 else 0)
 
 
 def logits_chunk_load(q, c):
@@ -409,8 +419,17 @@ def logits_body(q, f64):
     advance = ["s_add_u32 s%d, s%d, %%[stride]" % (tb + 2, tb + 2), "s_addc_u32 s%d, s%d, 0" % (tb + 3, tb + 3)]
     rowsets = [w0, w0 + 2 * q] if dbuf else [w0, w0]
 
+    pq = LOGITS_PAIR_Q
+    rt = logits_temp0(q, w0)
+
     def row_reads(jj, rb):
+        if q == 25:          # the 5 + 5 rows of the pair's two sites (tile rows 10 jj ..), into the registers below the table
+            return ["ds_read_b64 v[%d:%d], %%[vbase] offset:%d" % (rt + 2 * k, rt + 2 * k + 1, (jj * 2 * pq + k) * ROWBYTES) for k in range(2 * pq)]
         return ["ds_read_b64 v[%d:%d], %%[vbase] offset:%d" % (rb + 2 * b, rb + 2 * b + 1, (jj * q + b) * ROWBYTES) for b in range(q)]
+
+    def table_build(rb):     # "row" 5 b1 + b2 of the pair = row b1 of its first site + row b2 of its second
+        return ["%s v[%d:%d], v[%d:%d], v[%d:%d]" % (add, rb + 2 * (pq * b1 + b2), rb + 2 * (pq * b1 + b2) + 1, rt + 2 * b1, rt + 2 * b1 + 1,
+                                                    rt + 2 * (pq + b2), rt + 2 * (pq + b2) + 1) for b1 in range(pq) for b2 in range(pq)]
 
     o = ["s_mov_b32 s%d, m0" % (tb + 1),
          "s_mov_b64 s[%d:%d], %%[sptr]" % (tb + 2, tb + 3),
@@ -418,7 +437,10 @@ def logits_body(q, f64):
          "s_mov_b32 s%d, %%[ldst]" % ld,
          "s_mov_b32 s%d, 0" % tb]
     o += [logits_chunk_load(q, c) for c in range(nchunks - 1)] if single else logits_state_loads(q, 0)
-    if dbuf:
+    # pair variant: the 10 rows are consumed by the table build, so the NEXT pair's rows are requested right behind it, into
+    # the same registers, and arrive under this pair's adds -- only the first pair of a tile waits for its LDS round trip
+    rows_ahead = q == 25
+    if dbuf or rows_ahead:
         o += row_reads(0, rowsets[0])
     for jj in range(jt):
         cur = LS0 if single else LS0 + (jj % 2) * nw
@@ -436,13 +458,17 @@ def logits_body(q, f64):
                       "s_addc_u32 s%d, s%d, 0" % (gb + 1, gb + 1),
                       "s_add_u32 s%d, s%d, %d" % (ld, ld, waves * 1024),
                       ".Ldca_lg_skip%d_%%=:" % i]
-        if not dbuf:
+        if not dbuf and not rows_ahead:
             o += row_reads(jj, rb)
         o.append("s_waitcnt lgkmcnt(0)")          # this site's rows (and the state words requested during the previous site) have landed
         if single:
             o.append(logits_chunk_load(q, nchunks - 1))
         elif jj + 1 < jt:
             o += logits_state_loads(q, (jj + 1) % 2)
+        if q == 25:
+            o += table_build(rb)
+            if jj + 1 < jt:
+                o += row_reads(jj + 1, rb)
         o.append("s_set_gpr_idx_on s%d, 0x2" % tb)
         # double-buffered rows: the next site's row reads are dealt over this site's adds (DS instructions are not indexed)
         pending = row_reads(jj + 1, rowsets[(jj + 1) % 2]) if dbuf and jj + 1 < jt else []
@@ -480,7 +506,8 @@ def logits_macro(q, f64):
     lines.append("        : %s \\" % ", ".join(ops))
     lines.append('        : [vbase] "v"(VBASE), [sptr] "s"(SPTR), [stride] "s"(STRIDE), [npc] "s"(NPC), [gbase] "s"(GBASE), '
                  '[ginc] "s"(GINC), [voff] "v"(VOFF), [ldst] "s"(LDST) \\')
-    clob = ['"memory"', '"scc"'] + ['"v%d"' % (w0 + i) for i in range(acc0 - w0)] + ['"s%d"' % i for i in range(LS0, tb + 7)]
+    t0 = logits_temp0(q, w0)
+    clob = ['"memory"', '"scc"'] + ['"v%d"' % (t0 + i) for i in range(acc0 - t0)] + ['"s%d"' % i for i in range(LS0, tb + 7)]
     lines.append("        : %s)" % ", ".join(clob))
     return "\n".join(lines)
 
@@ -489,10 +516,10 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     lout = ["// GENERATED by tools/gen_plm_asm.py -- do not edit by hand.",
             "// Inline-asm inner blocks of plm_logits_kernel; see the generator for the register plan.", ""]
-    for q in (21, 5):
+    for q in (21, 5, 25):
         lout.append("#define DCA_LOGITS_WAVES_Q%d %d" % (q, LOGITS_CFG[q][0]))
         lout.append("#define DCA_LOGITS_NSEQ_Q%d %d" % (q, LOGITS_CFG[q][1]))
-        for f64 in (0, 1):
+        for f64 in ((0, 1) if q != 25 else (0,)):          # the pair alphabet is a float32 formulation (it re-associates the sums)
             lout.append(logits_macro(q, f64))
             lout.append("")
     lpath = os.path.join(here, "..", "pydca_amd", "csrc", "logits_gather_asm.inc")
@@ -512,6 +539,9 @@ def main():
         for waves in (8, 4):
             out.append(macro_smem(q, 1, waves))
             out.append("")
+    # q = 5 in float32 on the site-pair alphabet: the block with 25 "states" per unit, a unit being a pair of sites (round 5)
+    out.append(macro_smem(25, 0))
+    out.append("")
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pydca_amd", "csrc", "scatter_gather_asm.inc")
     with open(path, "w") as fh:
         fh.write("\n".join(out))
