@@ -536,7 +536,7 @@ __device__ __forceinline__ void scatter_store_site(const SiteAcc<Q>& acc, unsign
 }
 
 // float64 mode, end of a canonical block that is not the workgroup's first: G = G + (the block's sums) -- the running sum
-// of the finished blocks on the left, as the oracle adds them (oracle/plm_oracle.c, ORACLE_CANONICAL_BLOCK).  A lane's 8
+// of the finished blocks on the left, as the float64 oracle of the test suite adds them (its ORACLE_CANONICAL_BLOCK).  A lane's 8
 // bytes are one double; every address is read and written by this lane only.
 template <int Q, int S, int GROUP, int K = 0>
 __device__ __forceinline__ void scatter_add_rows_f64(const SiteAcc<Q>& acc, const double (&v)[GROUP], unsigned char* rowBase, uint32_t laneOff,
@@ -1563,13 +1563,15 @@ struct PlmEngine : PlmEngineBase {
             double bestCost = 1e300;
             scatSplit = 1; scatChunksPerSplit = numScatChunks; scatRemCT = scatRemSplit = scatRemChunksPerSplit = 0;
             // float64 = parity mode: the oracle's order of summation -- per (site, state, column) the sequences in ascending
-            // order inside blocks of kCanonBlock, the block sums added in ascending block order (oracle/plm_oracle.c,
+            // order inside blocks of kCanonBlock, the block sums added in ascending block order (the test oracle's
             // ORACLE_CANONICAL_BLOCK; round 4: one chain over all N) -- so that the gradient does not depend on the launch
             // geometry.  Two geometries give exactly that order: ONE workgroup per (strip, site group) that adds its
             // finished block to the running sum in G and restarts its chains (plm_scatter_kernel, blockChunks), or one
             // workgroup and one slab PER BLOCK, the slabs summed in ascending order by plm_sum_slabs_kernel.  The second
-            // fills the chip where strips x site groups do not (config E: 12 x 5 = 60 workgroups, 49 blocks), the first
-            // saves the slab traffic where they do (config D: 2656 workgroups, 13 blocks = 11.6 GB of slabs).  No separate
+            // fills the chip where strips x site groups do not (config E: 12 x 5 = 60 workgroups, 13 blocks: scatter 4.03 ->
+            // 1.39 ms), the first saves the slab traffic where they do (config D: 2656 workgroups, 4 blocks: 14.4 ms against
+            // 16.6 + 0.9 in the fold; round 4's single chain 13.3 -- each of the three read-modify-write passes over G stalls
+            // the lock-stepped workgroups for 0.35 ms, which is why the blocks are 16384 and not 4096 sequences).  No separate
             // launch for the left-over strips; a test that forces a split or that launch leaves the canonical order.
             const bool canonical = sizeof(T) == 8 && !splitEnv && !remEnv;
             scatWaves = kScatWavesC;
