@@ -1430,18 +1430,23 @@ int launch_gemm_splitk_capped(hipStream_t stream, const double* A, int lda, cons
     return DCA_OK;
 }
 
-struct BlockedCfg { int W, cap, overlap, minN, splitMinK, roundK; };
+struct BlockedCfg { int W, cap, overlap, minN, splitMinK, roundK, trsmSplit; };
 static const BlockedCfg& blocked_cfg()
 {
     static const BlockedCfg c = [] {
         // measured (tools/experiments/inv_sizes.sh; fused walk -> blocked, ms): n = 4032 3.75 -> 3.83, 5056 5.33 -> 5.24, 6016 8.00 -> 7.53,
         // 8000 14.36 -> 12.62, 10 048 23.48 -> 21.83; panels of 256 / 1024 columns lose 0.1 - 0.8 ms at every size
-        BlockedCfg v{512, 248, 1, 5000, 512, 300};
+        // trsmSplit (DCA_CHOLINV_TRSM_SPLIT=1; round 5, measured, NOT adopted): only the next diagonal block's rows of a panel of
+        // the factor on the chain, the rows below on the bulk stream -- 22.7 against 21.7 ms at n = 10 048 (13.0 / 12.6 at 8000,
+        // 7.50 / 7.58 at 6016): the bulk stream is the longer of the two, and every cap from 248 to 2000 workgroups gives
+        // 21.7 - 22.9 ms (160: 24.4), with the eight-wave bulk kernel 21.9 - 23.7 (profiles/r05_inverse_sweeps.txt)
+        BlockedCfg v{512, 248, 1, 5000, 512, 300, 0};
         if (const char* e = getenv("DCA_CHOLINV_PANEL")) v.W = std::max(128, atoi(e) / 128 * 128);   // 0 / unparsable -> 128; DCA_CHOLINV_BLOCKED=0 selects the fused walk
         if (const char* e = getenv("DCA_CHOLINV_SIDE_CAP")) v.cap = std::max(1, atoi(e));
         if (const char* e = getenv("DCA_CHOLINV_OVERLAP")) v.overlap = atoi(e);
         if (const char* e = getenv("DCA_CHOLINV_BLOCKED_MIN")) v.minN = atoi(e);
         if (const char* e = getenv("DCA_CHOLINV_ROUNDK")) v.roundK = atoi(e);
+        if (const char* e = getenv("DCA_CHOLINV_TRSM_SPLIT")) v.trsmSplit = atoi(e);
         if (const char* e = getenv("DCA_CHOLINV_SPLITK_MIN")) v.splitMinK = atoi(e);       // k per slice at least this (0: never split)
         if (const char* e = getenv("DCA_CHOLINV_BLOCKED")) if (atoi(e) == 0) v.minN = INT_MAX;
         return v;
@@ -1506,12 +1511,20 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
         // ---- chain: the panel of the factor below the block
         if (twoStreams && j > 0) HIP_TRY(hipStreamWaitEvent(ctx->stream, ev(1, j), 0));
         double* Lj = Lm + (size_t)(c + w) * ld + c;
-        if ((rc = launch_gemm(ctx, GemmArgs{A + (size_t)(c + w) * ld + c, ld, MASK_NONE, D, ld, MASK_LOWER, Lj, ld, nullptr, 0, m, w, w, 1.0, 0.0, 0, WALK_COLUMNS_REVERSED})) != DCA_OK) break;
+        const int w1 = b[j + 2] - b[j + 1];
+        // the chain needs only the rows of the NEXT diagonal block from this panel of the factor; with two streams the rows
+        // below them are the bulk's (cfg.trsmSplit)
+        const int mTop = (twoStreams && cfg.trsmSplit && m - w1 > 0) ? w1 : m;
+        if ((rc = launch_gemm(ctx, GemmArgs{A + (size_t)(c + w) * ld + c, ld, MASK_NONE, D, ld, MASK_LOWER, Lj, ld, nullptr, 0, mTop, w, w, 1.0, 0.0, 0, WALK_COLUMNS_REVERSED})) != DCA_OK) break;
         if (twoStreams) {
             HIP_TRY(hipEventRecord(ev(0, j), ctx->stream));
             HIP_TRY(hipStreamWaitEvent(bulk, ev(0, j), 0));
         }
-        const int w1 = b[j + 2] - b[j + 1];
+        if (mTop < m) {
+            if ((rc = launch_gemm_capped(bulk, GemmArgs{A + (size_t)(c + w + mTop) * ld + c, ld, MASK_NONE, D, ld, MASK_LOWER, Lj + (size_t)mTop * ld, ld, nullptr, 0,
+                                                         m - mTop, w, w, 1.0, 0.0, 0}, cfg.cap)) != DCA_OK) break;
+            bulkInFlight = true;
+        }
         // ---- bulk: rows of panel j + 1 under its diagonal block, from L_j
         if (m - w1 > 0) {
             if ((rc = launch_gemm_capped(bulk, GemmArgs{Lj + (size_t)w1 * ld, ld, MASK_NONE, Lj, ld, MASK_NONE, A + (size_t)(c + w + w1) * ld + c + w, ld, nullptr, 0,
