@@ -118,6 +118,10 @@ int dca_compute_weights(dca_ctx* ctx, double seqid, int compare_precision);
 int dca_set_weights(dca_ctx* ctx, const double* w);           /* externally computed weights */
 int dca_get_weights(dca_ctx* ctx, double* w_out);             /* N values: 1/count */
 int dca_get_weight_counts(dca_ctx* ctx, uint32_t* counts_out);/* N values (after dca_compute_weights) */
+/* Measurement aid (bench.py's roofline of the weights kernel): the integer work the last dca_compute_weights launch really
+ * issued -- out[0] = wave x 32-site groups compared (each 16 pairs per lane x (planes xor/or + 1 popcount-add) VALU
+ * instructions), out[1] = the same count without the exact early exit, out[2] = bit planes per group (5 or 3). */
+int dca_weights_work(dca_ctx* ctx, uint64_t* out3);
 int dca_get_meff(dca_ctx* ctx, double* meff_out);
 
 /* ------------------------------------------------------------------ plmDCA

@@ -74,6 +74,7 @@ def lib():
         "dca_destroy": (None, [vp]),
         "dca_set_msa": (i, [vp, vp, i, i, i]),
         "dca_compute_weights": (i, [vp, d, i]),
+        "dca_weights_work": (i, [vp, vp]),
         "dca_compute_weights_sharded": (i, [vp, d, i]),
         "dca_weights_partial_counts": (i, [vp, d, i, i, i, vp]),
         "dca_set_weight_counts": (i, [vp, vp]),
@@ -138,7 +139,7 @@ def lib():
     return L
 
 
-EXPORTS = ["dca_compute_weights_sharded", "dca_weights_partial_counts", "dca_set_weight_counts", "dca_comm_unique_id",
+EXPORTS = ["dca_weights_work", "dca_compute_weights_sharded", "dca_weights_partial_counts", "dca_set_weight_counts", "dca_comm_unique_id",
            "dca_comm_init", "dca_comm_destroy", "dca_comm_info", "dca_plm_set_native_comm", "dca_mf_set_native_comm",
            "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_read_msa_alloc", "dca_mf_set_row_window", "dca_comm_allgather_host", "dca_fasta_shape", "dca_read_fasta", "dca_read_fasta_alloc", "dca_host_free", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
@@ -254,6 +255,12 @@ class Context:
     def compute_weights(self, seqid, compare_precision=DCA_F32):
         check(self._l.dca_compute_weights(self._h, float(seqid), int(compare_precision)))
         return self.weights()
+
+    def weights_work(self):
+        """(wave x 32-site groups the last compute_weights launch compared, the same without the early exit, bit planes per group)"""
+        out = np.zeros(3, dtype=np.uint64)
+        check(self._l.dca_weights_work(self._h, _ptr(out)))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def set_weights(self, w):
         w = np.ascontiguousarray(w, dtype=np.float64)

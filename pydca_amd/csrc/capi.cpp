@@ -396,6 +396,13 @@ int dca_get_weights(dca_ctx* ctx, double* w_out)
     return DCA_OK;
 }
 
+int dca_weights_work(dca_ctx* ctx, uint64_t* out3)
+{
+    if (!ctx || !out3) return DCA_ERR_ARG;
+    out3[0] = ctx->weightsWork[0]; out3[1] = ctx->weightsWork[1]; out3[2] = (uint64_t)ctx->weightsPlanes;
+    return DCA_OK;
+}
+
 int dca_get_weight_counts(dca_ctx* ctx, uint32_t* counts_out)
 {
     CHECK_CTX(ctx);

@@ -73,6 +73,8 @@ struct dca_ctx {
     uint32_t* dCounts = nullptr;
     double* dWd = nullptr;     // N doubles
     double meff = 0.0;
+    unsigned long long weightsWork[2] = {0, 0};     // last weights launch: wave x 32-site groups compared / without the early exit
+    int weightsPlanes = 0;                          // ... bit planes per group (5: q <= 32, 3: q <= 8)
 
     // scratch scalars: device slots + pinned host mirror
     double* dScal = nullptr;

@@ -89,7 +89,7 @@ __global__ void weights_bitplanes_kernel(const uint8_t* __restrict__ X, const in
 template <int PL>
 __global__ __launch_bounds__(256)
 void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__ counts, int N, int L, int G, int thresh,
-                          int tilesPerSide, int part, int parts)
+                          int tilesPerSide, int part, int parts, unsigned long long* __restrict__ work)
 {
     constexpr int PLP = (PL + 1) & ~1;
     constexpr int ROWDW = kKG * PLP;
@@ -135,6 +135,7 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
     // and short alignments (config E: 150 sites, passed after ~64) are over before the first stage of 128 sites ends.
     const unsigned maxMism = (unsigned)(L - thresh);
     bool waveDone = false;       // wave-uniform
+    unsigned groupsDone = 0;     // wave-uniform: 32-site groups this wave really compared (what the early exit leaves of G)
     auto all_passed = [&]() {          // smallest of the 16 counts against the bound: 8 x v_min3 instead of 16 compares and ands
         unsigned mn = mism[0][0];
 #pragma unroll
@@ -164,6 +165,7 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
         for (int gg = 0; gg < kKG; ++gg) {
             if (g0 + gg > 0 && !waveDone) waveDone = __all(all_passed());
             if (waveDone) continue;
+            ++groupsDone;
             uint32_t a[4][PLP], b[4][PLP];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -190,6 +192,12 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
                 }
         }
         if (!waveDone) waveDone = __all(all_passed());
+    }
+    // work[0]: wave x 32-site groups compared (each = 16 pairs per lane x (PL xor/or + 1 popcount-add) VALU instructions):
+    // the issued integer work that bench.py prices against the integer-VALU rate; work[1]: the same without any early exit
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&work[0], (unsigned long long)groupsDone);
+        atomicAdd(&work[1], (unsigned long long)G);
     }
     // ident = L - mismatches (padding sites are state 0 in every row and never mismatch).  A wave whose pairs have all
     // passed the bound has nothing to count (ident >= thresh <=> mismatches <= L - thresh): most waves skip the epilogue.
@@ -262,14 +270,17 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int p
         const bool ranked = wantRanked && (size_t)L * sizeof(unsigned long long) <= 60000;
         uint32_t *dP = nullptr, *dHist = nullptr;
         int* dPerm = nullptr;
+        unsigned long long* dWork = nullptr;
         hipError_t ea = dca_dev_malloc(reinterpret_cast<void**>(&dP), (size_t)N * G * PLP * sizeof(uint32_t));
         if (ea == hipSuccess) ea = dca_dev_malloc(reinterpret_cast<void**>(&dPerm), (size_t)ctx->Ls * sizeof(int));
+        if (ea == hipSuccess) ea = dca_dev_malloc(reinterpret_cast<void**>(&dWork), 2 * sizeof(unsigned long long));
+        if (ea == hipSuccess) ea = hipMemsetAsync(dWork, 0, 2 * sizeof(unsigned long long), ctx->stream);
         if (ea == hipSuccess && ranked) {            // the site histogram only exists for the ranked order
             ea = dca_dev_malloc(reinterpret_cast<void**>(&dHist), (size_t)L * 32 * sizeof(uint32_t));
             if (ea == hipSuccess) ea = hipMemsetAsync(dHist, 0, (size_t)L * 32 * sizeof(uint32_t), ctx->stream);
         }
         if (ea != hipSuccess) {                      // nothing of the scratch is left behind
-            dca_dev_free(dP); dca_dev_free(dHist); dca_dev_free(dPerm);
+            dca_dev_free(dP); dca_dev_free(dHist); dca_dev_free(dPerm); dca_dev_free(dWork);
             dca_set_error("weights scratch: %s", hipGetErrorString(ea));
             return DCA_ERR_HIP;
         }
@@ -284,12 +295,15 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int p
         dim3 grid((unsigned)ceil_div(superPerSide * superPerSide * 32 * 32, parts));
         if (small) {
             hipLaunchKernelGGL(weights_bitplanes_kernel<3>, dim3(tb), dim3(256), 0, ctx->stream, ctx->dX, dPerm, dP, N, ctx->Ls);
-            hipLaunchKernelGGL(weights_count_kernel<3>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide, part, parts);
+            hipLaunchKernelGGL(weights_count_kernel<3>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide, part, parts, dWork);
         } else {
             hipLaunchKernelGGL(weights_bitplanes_kernel<5>, dim3(tb), dim3(256), 0, ctx->stream, ctx->dX, dPerm, dP, N, ctx->Ls);
-            hipLaunchKernelGGL(weights_count_kernel<5>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide, part, parts);
+            hipLaunchKernelGGL(weights_count_kernel<5>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide, part, parts, dWork);
         }
         hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(ctx->weightsWork, dWork, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        ctx->weightsPlanes = small ? 3 : 5;
+        dca_dev_free(dWork);
         dca_dev_free(dP);
         dca_dev_free(dHist);
         dca_dev_free(dPerm);

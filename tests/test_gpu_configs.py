@@ -227,7 +227,13 @@ def test_config_C_lbfgs_P3_chunked_float64(L_, oracle_plm, oracle_mf, msa_C, ora
 
 
 def _write_report(name, obj):
+    """gpurun_out/<name>; stamped with the fingerprint of the kernel sources the figures were measured on, so that bench.py,
+    which quotes the committed copy under profiles/, can tell when the tree has moved on (`parity_report_is_stale`)."""
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    if isinstance(obj, dict):
+        sys.path.insert(0, ROOT)
+        from bench import kernel_sources_fingerprint
+        obj = dict(obj, kernel_sources_sha256=kernel_sources_fingerprint())
     with open(os.path.join(ROOT, "gpurun_out", name), "w") as fh:
         json.dump(obj, fh, indent=1)
 
