@@ -538,14 +538,40 @@ def main():
     st = ctx.plm_lbfgs_iterate(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = None
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        tall = [torch.zeros(1, dtype=torch.float64, device=tdev) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([dt], dtype=torch.float64, device=tdev))
+        per_rank_ms = [float(t.item()) / max(args.steps, 1) * 1e3 for t in tall]       # every rank's own clock around the same K iterations
+        dt = max(float(t.item()) for t in tall)
     steps_done = st.iterations - it0
     evals = st.evaluations - ev0
     ktimes = {tag: ctx.kernel_time(tag) for tag in ("plm_expand", "plm_logits", "plm_softmax", "plm_scatter", "plm_fold", "lbfgs_vec")}
     ctx.set_profiling(False)
+
+    # The N = 1 point of the same run: rank 0 times the same K iterations on its GPU alone, in this
+    # process group, while the other ranks wait -- the scaling curve's first point can be checked against BENCH without a
+    # second launch.  After the timed region; not part of `value`.
+    single_gpu_same_run = None
+    if world > 1 and os.environ.get("DCA_BENCH_NO_SINGLE") != "1":
+        if rank == 0:
+            c1 = _lib.Context(local_rank, _lib.DCA_F64 if args.precision == 64 else _lib.DCA_F32)
+            c1.set_msa(X, q)
+            c1.set_weight_counts(counts)
+            c1.plm_configure(lh, lJ, _lib.CARRY_CHUNKED)
+            c1.plm_init_x()
+            c1.plm_lbfgs_begin(total_cap + 1000)
+            s1 = c1.plm_lbfgs_iterate(args.warmup) if args.warmup > 0 else None
+            i1 = s1.iterations if s1 else 0
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            s1 = c1.plm_lbfgs_iterate(args.steps)
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            single_gpu_same_run = {"iterations_per_s": (s1.iterations - i1) / d1, "ms_per_step": d1 / max(s1.iterations - i1, 1) * 1e3,
+                                   "steps": s1.iterations - i1, "what": "rank 0 alone on its GPU, same alignment / K / W, after the timed region"}
+            c1.close()
+        barrier()
 
     if rank != 0:
         if dist is not None:
@@ -630,7 +656,21 @@ def main():
         "kernels": kernels_ms, "roofline": roofline,
         "host_cores": os.cpu_count(),
     }
+    if world > 1:
+        out["per_rank_ms_per_step"] = per_rank_ms
+        if single_gpu_same_run is not None:
+            out["single_gpu_same_run"] = single_gpu_same_run
+            out["speedup_vs_single_gpu_same_run"] = out["value"] / single_gpu_same_run["iterations_per_s"]
     if world > 1 and comm_selection is not None:
+        # bytes a rank puts on the wires per evaluation under each scheme (arithmetic from the layout; ring
+        # all-reduce counted as reduce-scatter + all-gather)
+        pb = float(P) * esz
+        f = (world - 1) / float(world)
+        comm_selection["wire_bytes_per_rank_per_evaluation"] = {
+            "1": 2.0 * f * pb, "2": 2.0 * f * pb, "3": 2.0 * f * pb,
+            "4": 2.0 * (float(Lq) * Lq / 2.0) * f * esz / world,
+            "note": "sent per rank and evaluation; 1-3: reduce-scatter(g) + all-gather(x) of the P-vector (1: as one all-reduce); "
+                    "4: couplings up + gradient-table rows down, (L q)^2 / 2 (1 - 1/world) elements each way over the node, averaged over the ranks"}
         out["comm_selection"] = comm_selection
 
     if world == 1 and not args.no_mfdca:
@@ -695,10 +735,14 @@ def main():
         if t_cnt > 0:
             upd = N * L * (L - 1) / 2.0
             cnt_bytes = N * L + 8.0 * N + 8.0 * Lq * Lq
-            more["pair_counts_M2"] = {"bound": "lds atomics", "achieved": upd / t_cnt / 1e12, "peak": 256 * 16 * 2.4e9 / 1e12, "unit": "T weighted updates/s",
-                                      "frac": upd / t_cnt / (256 * 16 * 2.4e9), "avg_kernel_ms": t_cnt * 1e3,
+            # peak: what a loop of nothing but ds_add_f64 on this histogram shape sustains on this chip (tools/experiments/
+            # lds_atomic_rate.hip, profiles/r05_lds_atomic_rate.txt: 8.1 lane updates per clock and CU = 4.4 T updates/s; round 4
+            # assumed 16 per clock at 2.4 GHz without measuring it)
+            lds_peak = 4.4e12
+            more["pair_counts_M2"] = {"bound": "lds atomics", "achieved": upd / t_cnt / 1e12, "peak": lds_peak / 1e12, "unit": "T weighted updates/s",
+                                      "frac": upd / t_cnt / lds_peak, "avg_kernel_ms": t_cnt * 1e3,
                                       "hbm": {"achieved": cnt_bytes / t_cnt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cnt_bytes / t_cnt / 1e9 / HBM_PEAK_GBS},
-                                      "note": "histogram formulation (N L^2 / 2 ds_add_f64), not the 21 x larger one-hot GEMM; peak = 16 64-bit LDS atomics per clock and CU"}
+                                      "note": "histogram formulation (N L^2 / 2 ds_add_f64), not the 21 x larger one-hot GEMM; peak = the measured rate of a bare ds_add_f64 loop on the same histogram shape"}
         out["roofline_more"] = more
         mctx.close()
 

@@ -14,6 +14,8 @@
 // 64x64 sequence tiles (upper triangle of tile pairs only), a 4x4 register block per thread,
 // plane rows staged in LDS and read with 8-byte loads (row stride 26 / 18 dwords: conflict free).
 // A tile whose pairs can all no longer reach the threshold skips its remaining sites.
+#include <vector>
+
 #include "dca_internal.h"
 
 namespace {
@@ -85,6 +87,8 @@ __global__ void weights_bitplanes_kernel(const uint8_t* __restrict__ X, const in
 #pragma unroll
     for (int p = 0; p < PLP; ++p) P[idx * PLP + p] = p < PL ? planes[p] : 0u;
 }
+
+constexpr unsigned kWorkSlots = 4096;
 
 template <int PL>
 __global__ __launch_bounds__(256)
@@ -193,12 +197,11 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
         }
         if (!waveDone) waveDone = __all(all_passed());
     }
-    // work[0]: wave x 32-site groups compared (each = 16 pairs per lane x (PL xor/or + 1 popcount-add) VALU instructions):
-    // the issued integer work that bench.py prices against the integer-VALU rate; work[1]: the same without any early exit
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&work[0], (unsigned long long)groupsDone);
-        atomicAdd(&work[1], (unsigned long long)G);
-    }
+    // work[]: wave x 32-site groups compared (each = 16 pairs per lane x (PL xor/or + 1 popcount-add) VALU instructions):
+    // the issued integer work that bench.py prices against the integer-VALU rate
+    // (kWorkSlots counters, summed on the host: one address for the 1.2 million waves of config D serialised their atomics
+    // into 27 ms)
+    if ((threadIdx.x & 63) == 0 && groupsDone) atomicAdd(&work[(blockIdx.x * 4u + (threadIdx.x >> 6)) % kWorkSlots], (unsigned long long)groupsDone);
     // ident = L - mismatches (padding sites are state 0 in every row and never mismatch).  A wave whose pairs have all
     // passed the bound has nothing to count (ident >= thresh <=> mismatches <= L - thresh): most waves skip the epilogue.
     if (!waveDone) {
@@ -273,8 +276,8 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int p
         unsigned long long* dWork = nullptr;
         hipError_t ea = dca_dev_malloc(reinterpret_cast<void**>(&dP), (size_t)N * G * PLP * sizeof(uint32_t));
         if (ea == hipSuccess) ea = dca_dev_malloc(reinterpret_cast<void**>(&dPerm), (size_t)ctx->Ls * sizeof(int));
-        if (ea == hipSuccess) ea = dca_dev_malloc(reinterpret_cast<void**>(&dWork), 2 * sizeof(unsigned long long));
-        if (ea == hipSuccess) ea = hipMemsetAsync(dWork, 0, 2 * sizeof(unsigned long long), ctx->stream);
+        if (ea == hipSuccess) ea = dca_dev_malloc(reinterpret_cast<void**>(&dWork), kWorkSlots * sizeof(unsigned long long));
+        if (ea == hipSuccess) ea = hipMemsetAsync(dWork, 0, kWorkSlots * sizeof(unsigned long long), ctx->stream);
         if (ea == hipSuccess && ranked) {            // the site histogram only exists for the ranked order
             ea = dca_dev_malloc(reinterpret_cast<void**>(&dHist), (size_t)L * 32 * sizeof(uint32_t));
             if (ea == hipSuccess) ea = hipMemsetAsync(dHist, 0, (size_t)L * 32 * sizeof(uint32_t), ctx->stream);
@@ -301,8 +304,17 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int p
             hipLaunchKernelGGL(weights_count_kernel<5>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide, part, parts, dWork);
         }
         hipError_t e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) e = hipMemcpy(ctx->weightsWork, dWork, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        ctx->weightsPlanes = small ? 3 : 5;
+        if (e == hipSuccess) {
+            std::vector<unsigned long long> slots(kWorkSlots);
+            e = hipMemcpy(slots.data(), dWork, kWorkSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            unsigned long long done = 0;
+            for (unsigned long long v : slots) done += v;
+            // without the early exit every wave of this part's tile pairs (upper triangle, diagonal included) compares all G groups
+            const unsigned long long tp = (unsigned long long)tilesPerSide * (tilesPerSide + 1) / 2;
+            ctx->weightsWork[0] = done;
+            ctx->weightsWork[1] = (tp + parts - 1 - part) / parts * 4ull * (unsigned long long)G;
+            ctx->weightsPlanes = small ? 3 : 5;
+        }
         dca_dev_free(dWork);
         dca_dev_free(dP);
         dca_dev_free(dHist);

@@ -713,6 +713,15 @@ def test_bench_native_path_two_processes(scheme):
     if sel["chosen_mode"] == 4:
         assert "column strips" in d2["config"]["parallelism"]
     assert abs(d2["fx"] - d1["fx"]) <= 1e-6 * abs(d1["fx"]), (d2["fx"], d1["fx"])
+    # round 5: every rank's own time around the K iterations, the bytes each scheme puts on the wires, and the N = 1 point of the
+    # same run (rank 0 alone after the timed region)
+    assert len(d2["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d2["per_rank_ms_per_step"])
+    assert abs(max(d2["per_rank_ms_per_step"]) - d2["ms_per_step"]) <= 1e-6 * d2["ms_per_step"]
+    wb = sel["wire_bytes_per_rank_per_evaluation"]
+    assert wb["1"] == wb["2"] == wb["3"] > wb["4"] > 0
+    one_gpu = d2["single_gpu_same_run"]
+    assert one_gpu["steps"] == d2["steps"] and one_gpu["iterations_per_s"] > 0
+    assert abs(d2["speedup_vs_single_gpu_same_run"] - d2["value"] / one_gpu["iterations_per_s"]) < 1e-9
 
 
 def test_msa_numerics_direct_information_functions():
