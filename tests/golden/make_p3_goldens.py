@@ -38,7 +38,7 @@ CHECKPOINTS = (10, 25, 50, 75)
 X_SAMPLE = 65521          # about this many elements of the final x are kept (every stride-th)
 
 
-def make(cfg, cap, out_dir, threads):
+def make(cfg, cap, out_dir, threads, prefix="p3"):
     L, N, q, lh, lJ = FULL_SIZE[cfg]
     t0 = time.time()
     X = dedup(generate(L, N, q, SEEDS[cfg]))
@@ -46,7 +46,7 @@ def make(cfg, cap, out_dir, threads):
     x0 = oracle_plm.init_x(X, w, q)
     t_setup = time.time() - t0
     os.makedirs(out_dir, exist_ok=True)
-    prog = os.path.join(out_dir, "p3_config_%s_cap%d.progress.txt" % (cfg, cap))
+    prog = os.path.join(out_dir, "%s_config_%s_cap%d.progress.txt" % (prefix, cfg, cap))
     if os.path.exists(prog):
         os.remove(prog)
     os.environ["ORACLE_PROGRESS_FILE"] = prog
@@ -74,11 +74,11 @@ def make(cfg, cap, out_dir, threads):
     for k, xk in sorted(run.get("snapshots", {}).items()):
         out["fn_apc_it%d" % k] = oracle_mf.plm_fn(xk, L, q, apc_correct=True)
         out["fn_it%d" % k] = oracle_mf.plm_fn(xk, L, q, apc_correct=False)
-    path = os.path.join(out_dir, "p3_config_%s_cap%d.npz" % (cfg, cap))
+    path = os.path.join(out_dir, "%s_config_%s_cap%d.npz" % (prefix, cfg, cap))
     np.savez_compressed(path, **out)
     summary = {k: (v if not isinstance(v, np.ndarray) else "array%r" % (v.shape,)) for k, v in out.items()}
     summary["setup_seconds"] = t_setup
-    with open(os.path.join(out_dir, "p3_config_%s_cap%d.summary.json" % (cfg, cap)), "w") as fh:
+    with open(os.path.join(out_dir, "%s_config_%s_cap%d.summary.json" % (prefix, cfg, cap)), "w") as fh:
         json.dump(summary, fh, indent=1, default=str)
     print("config %s: status %d, %d iterations, %d evaluations, fx %.12g, %.1f s (%.2f s / evaluation, %d threads) -> %s" % (
         cfg, run["status"], run["iterations"], run["evaluations"], run["fx"], t_run, t_run / max(1, run["evaluations"]), threads, path), flush=True)
@@ -90,7 +90,21 @@ if __name__ == "__main__":
     ap.add_argument("--cap", type=int, default=100)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "p3"))
     ap.add_argument("--threads", type=int, default=os.cpu_count())
+    ap.add_argument("--plain", action="store_true",
+                    help="the same runs with the oracle built -DORACLE_PLAIN_F64: the reference's LITERAL order of operations in float64 "
+                         "(no canonical order, no blocks) -> plain_f64_config_<id>_cap<cap>.npz, what "
+                         "tests/test_gpu_configs.py::test_float64_device_vs_reference_order_at_cap bounds the device against")
     a = ap.parse_args()
     oracle_plm.build(ref=False)
+    prefix = "p3"
+    if a.plain:
+        import subprocess
+        os.makedirs(a.out, exist_ok=True)
+        so = os.path.join(a.out, "liboracle_plain_f64.so")
+        subprocess.check_call(["gcc", "-O3", "-fopenmp", "-fno-fast-math", "-ffp-contract=off", "-shared", "-fPIC", "-DORACLE_PLAIN_F64",
+                               "-o", so, os.path.join(ROOT, "oracle", "plm_oracle.c"), "-lm"])
+        oracle_plm._LIB_PATH = so          # the module loads its library on first use
+        oracle_plm._lib = None
+        prefix = "plain_f64"
     for cfg in a.config:
-        make(cfg, a.cap, a.out, a.threads)
+        make(cfg, a.cap, a.out, a.threads, prefix)
