@@ -19,6 +19,8 @@
 #include <mutex>
 #include <atomic>
 
+#include <string>
+
 #include "dca_internal.h"
 
 namespace {
@@ -574,6 +576,179 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
             }
 }
 
+// ------------------------------------------------------------------ stream-K form of the bulk products (round 5)
+// The look-ahead factorisation's bulk products (C -= A B^T, no triangular operand, 128 x 128 tiles) have FEW output tiles and
+// a DEEP k range -- the deep update of a 512-column panel is (rows / 128) x 4 tiles, e.g. 172 at the middle of n = 10 048 --
+// and ran as one workgroup per tile: 172 of 256 CUs busy for the whole k walk (41 TF), or, split along k into equal
+// slices, tile x slice counts that again do not divide by the CU count.  Here the ITERATION space (tiles x k-tiles of 16)
+// is cut into equal contiguous pieces: every workgroup does the same number of k-tiles (+-1), a piece that covers a whole
+// tile is finished in place, the at most two partial pieces of a workgroup (the tail of one tile at its start, the head of
+// another at its end) go to two slots of a scratch array, and gemm_streamk_fixup_kernel adds the pieces of every split tile
+// in ascending k order before it applies alpha / beta -- a fixed order, so the result does not depend on timing.
+// Operand reuse: the gx column tiles of one tile row read the same rows of A.  The iteration space is therefore
+// (tile rows x k-tiles), cut into W pieces, and piece q is walked by a GROUP of gx workgroups, one per column tile, with
+// ids that put them on the same XCD (id % 8) -- they start together and run the same loop, so A's k-tiles are fetched
+// once per group and hit that XCD's L2 for the others.  (The first version cut tiles x k-tiles per workgroup: neighbouring
+// workgroups then stand at different k of the same rows, every operand tile comes from the fabric -- 1.4 GB per deep
+// update instead of 0.2 -- and the deep updates got slower, 8.8 against 6.9 ms at n = 10 048.)
+struct StreamKArgs {
+    const double* A; int lda;
+    const double* B; int ldb; int maskB;     // MASK_LOWER: B is lower triangular (k <= row); the k range is NOT shortened
+    double* C; int ldc;
+    int M, N, K;
+    double alpha, beta;
+    double* P;                               // 2 W gx slots of 128 x 128 doubles: slot ((2 q + s) gx + tj)
+    int gx, KT, W;                           // tile columns, k-tiles per tile, groups (pieces)
+    long long I;                             // iterations = tile rows x KT
+};
+__host__ __device__ __forceinline__ long long streamk_first(const StreamKArgs& g, int q) { return g.I * q / g.W; }
+__host__ __device__ __forceinline__ int streamk_owner(const StreamKArgs& g, long long it)      // the q with first(q) <= it < first(q + 1)
+{
+    return (int)(((it + 1) * g.W + g.I - 1) / g.I) - 1;
+}
+
+__global__ __launch_bounds__(256, 1)
+void gemm_nt_f64_streamk_kernel(StreamKArgs g)
+{
+    constexpr int BK = 16, TW = 4;
+    constexpr int BM = 128, BN = 128;
+    constexpr int PW = BM / 8 / 4;                                  // 1 KiB DMA pieces (8 tile rows) per wave and operand
+    constexpr int OP = BM * BK * (int)sizeof(double);
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];   // [3][A | B]
+    unsigned char* const smem = dca_gemm_smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4, swz = (fr >> 1) & 7;
+    // id -> (group q, column tile tj): the gx workgroups of a group have the same id % 8, i.e. the same XCD
+    const int per = 8 * g.gx;
+    const int w = ((int)blockIdx.x / per) * 8 + ((int)blockIdx.x % 8);
+    const int tj = ((int)blockIdx.x % per) / 8;
+    if (w >= g.W) return;
+    const long long itBeg = streamk_first(g, w), itEnd = streamk_first(g, w + 1);
+
+    for (long long it = itBeg; it < itEnd;) {
+        const int ti = (int)(it / g.KT), kt0 = (int)(it % g.KT);
+        const int kt1 = (int)min((long long)g.KT, kt0 + (itEnd - it));
+        const int nk = kt1 - kt0, kLo = kt0 * BK;
+        double4_t acc[TW][TW];
+#pragma unroll
+        for (int m = 0; m < TW; ++m)
+#pragma unroll
+            for (int n = 0; n < TW; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        const double* srcA[PW];
+        const double* srcB[PW];
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int R = 8 * (PW * wave + i) + (lane >> 3);
+            const int piece = (lane & 7) ^ ((R >> 1) & 7);
+            srcA[i] = g.A + (size_t)min(ti * BM + R, g.M - 1) * g.lda + 2 * piece;
+            srcB[i] = g.B + (size_t)min(tj * BN + R, g.N - 1) * g.ldb + 2 * piece;
+        }
+        auto issue = [&](int buf, int k0) {
+#pragma unroll
+            for (int i = 0; i < PW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * 2 * OP + (PW * wave + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < PW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * 2 * OP + OP + (PW * wave + i) * 1024), 16, 0, 0);
+        };
+        auto mma_tile = [&](int buf, int k0) {
+            const unsigned char* as = smem + buf * 2 * OP;
+            const unsigned char* bs = as + OP;
+            const bool diagB = g.maskB != MASK_NONE && k0 + BK > tj * BN && k0 < (tj + 1) * BN;    // wave-uniform
+            const bool zeroB = g.maskB == MASK_LOWER && k0 >= (tj + 1) * BN;                         // the whole k-tile lies above B's diagonal
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                const int slot = (4 * kk + fg) ^ swz;
+                double2_t a[TW], b[TW];
+#pragma unroll
+                for (int m = 0; m < TW; ++m) a[m] = *reinterpret_cast<const double2_t*>(as + (wm * 16 * TW + 16 * m + fr) * 128 + slot * 16);
+#pragma unroll
+                for (int m = 0; m < TW; ++m) b[m] = *reinterpret_cast<const double2_t*>(bs + (wn * 16 * TW + 16 * m + fr) * 128 + slot * 16);
+                if (diagB || zeroB) {
+                    const int kmin = k0 + 8 * kk;
+#pragma unroll
+                    for (int m = 0; m < TW; ++m) {
+                        const int bRow = tj * BN + wn * 16 * TW + 16 * m + fr;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) b[m][h] = (kmin + 2 * fg + h > bRow) ? 0.0 : b[m][h];
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int m = 0; m < TW; ++m)
+#pragma unroll
+                        for (int n = 0; n < TW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][h], b[n][h], acc[m][n], 0, 0, 0);
+            }
+        };
+        // three operand buffers, two k-tiles of loads in flight: one workgroup per CU has nothing else to cover a fetch
+        // that misses the L2 (the operands of a piece come from the fabric once per group), and a k-tile of MFMAs is 1.95 us
+        issue(0, kLo);
+        if (nk > 1) issue(1, kLo + BK);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 0, buf = 0; t < nk; ++t) {
+            const int nxt2 = buf == 0 ? 2 : buf - 1;                  // the buffer of tile t + 2 = the one tile t - 1 used
+            if (t + 2 < nk) issue(nxt2, kLo + (t + 2) * BK);
+            mma_tile(buf, kLo + t * BK);
+            if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW) : "memory");     // tile t + 1 has landed (t + 2 may be in flight)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        const bool whole = kt0 == 0 && kt1 == g.KT;
+        double* const slot = g.P + ((size_t)(2 * w + (it == itBeg ? 0 : 1)) * g.gx + tj) * (BM * BN);
+#pragma unroll
+        for (int m = 0; m < TW; ++m)
+#pragma unroll
+            for (int n = 0; n < TW; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ii = wm * 16 * TW + m * 16 + (lane >> 4) + 4 * r, jj = wn * 16 * TW + n * 16 + (lane & 15);
+                    if (!whole) { slot[ii * BN + jj] = acc[m][n][r]; continue; }
+                    const int i = ti * BM + ii, j = tj * BN + jj;
+                    if (i >= g.M || j >= g.N) continue;
+                    double* cp = g.C + (size_t)i * g.ldc + j;
+                    double v = g.alpha * acc[m][n][r];
+                    if (g.beta != 0.0) v += g.beta * (*cp);
+                    *cp = v;
+                }
+        it += nk;
+    }
+}
+
+// one workgroup per output tile: nothing to do where one stream-K workgroup walked the whole tile; otherwise the pieces in ascending w
+__global__ __launch_bounds__(256)
+void gemm_streamk_fixup_kernel(StreamKArgs g)
+{
+    constexpr int BM = 128, BN = 128;
+    const int tile = (int)blockIdx.x;
+    const int ti = tile / g.gx, tj = tile % g.gx;
+    const long long t0 = (long long)ti * g.KT, t1 = t0 + g.KT;
+    const int wa = streamk_owner(g, t0), wb = streamk_owner(g, t1 - 1);
+    if (wa == wb) return;
+    for (int e = threadIdx.x; e < BM * BN; e += 256) {
+        const int ii = e / BN, jj = e % BN;
+        const int i = ti * BM + ii, j = tj * BN + jj;
+        if (i >= g.M || j >= g.N) continue;
+        double sum = 0.0;
+        for (int w = wa; w <= wb; ++w) {
+            const long long first = streamk_first(g, w);
+            sum += g.P[((size_t)(2 * w + (first >= t0 ? 0 : 1)) * g.gx + tj) * (BM * BN) + e];      // the piece starts with w's range, or behind a piece of an earlier tile row
+        }
+        double* cp = g.C + (size_t)i * g.ldc + j;
+        double v = g.alpha * sum;
+        if (g.beta != 0.0) v += g.beta * (*cp);
+        *cp = v;
+    }
+}
+
 // 64x64 leaf: A (lower triangle valid) -> X = inv(chol(A)), written lower + mirrored upper.
 // One workgroup of 16 x 16 threads; thread (ty, tx) keeps ONE 4 x 4 register block c.  The factorisation and the
 // triangular inverse advance together, one 4-wide block column per step, 16 steps of two barriers: the time of a
@@ -1057,6 +1232,7 @@ int gemm_kernels_prepare(int device)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 16 * 8));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 16 * 8));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_dma_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 16 * 8));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_streamk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 16 * 8));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, small));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, small));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<64>()));
@@ -1076,7 +1252,7 @@ int launch_gemm_banded(dca_ctx* ctx, hipStream_t stream, GemmArgs g, int maxWGs)
     const int band = std::max(1, maxWGs / gx);
     for (int r = 0; r < gy; r += band) {
         g.row0 = r;
-        hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<4>, dim3(gx, std::min(band, gy - r)), dim3(256), (size_t)4 * 128 * 16 * sizeof(double), stream, g);
+        hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<4>, dim3(gx, std::min(band, gy - r)), dim3(256), (size_t)6 * 128 * 16 * sizeof(double), stream, g);
     }
     HIP_TRY(hipGetLastError());
     return DCA_OK;
@@ -1363,7 +1539,7 @@ static int bulk_kw()
 void bulk_kernel_launch(hipStream_t stream, dim3 grid, const GemmArgs& g)
 {
     if (bulk_kw() == 2) hipLaunchKernelGGL((gemm_nt_f64_dma_kernel<4, 4, 2>), grid, dim3(512), (size_t)8 * 128 * 16 * sizeof(double), stream, g);
-    else hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<4>, grid, dim3(256), (size_t)4 * 128 * 16 * sizeof(double), stream, g);
+    else hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<4>, grid, dim3(256), (size_t)6 * 128 * 16 * sizeof(double), stream, g);
 }
 
 int launch_gemm_capped(hipStream_t stream, GemmArgs g, int maxWGs)
@@ -1430,7 +1606,26 @@ int launch_gemm_splitk_capped(hipStream_t stream, const double* A, int lda, cons
     return DCA_OK;
 }
 
-struct BlockedCfg { int W, cap, overlap, minN, splitMinK, roundK, trsmSplit; };
+// C = alpha A B^T + beta C on `stream` in the stream-K form (gemm_nt_f64_streamk_kernel): W workgroups, at most `maxW`, as many as
+// the scratch P (Pcap doubles) has slot pairs for and as there are iterations
+int launch_gemm_streamk(hipStream_t stream, const double* A, int lda, const double* B, int ldb, int maskB, double* C, int ldc, int M, int N, int K,
+                        double alpha, double beta, double* P, size_t Pcap, int maxW)
+{
+    if (K % 16 != 0) { dca_set_error("stream-K product: k range must be a multiple of 16"); return DCA_ERR_ARG; }
+    StreamKArgs g{A, lda, B, ldb, maskB, C, ldc, M, N, K, alpha, beta, P, (N + 127) / 128, K / 16, 0, 0};
+    const int gy = (M + 127) / 128, tiles = g.gx * gy;
+    g.I = (long long)gy * g.KT;
+    // groups: as many as the cap allows workgroups for, as the scratch has slots for, and no more than leave every piece
+    // a few dozen k-tiles (a piece pays a pipeline start and a 128 KB store)
+    g.W = (int)std::min<long long>({(long long)std::max(1, maxW / g.gx), (long long)(Pcap / ((size_t)2 * g.gx * 128 * 128)), std::max<long long>(1, g.I / 48)});
+    if (g.W < 1) { dca_set_error("stream-K product: no scratch"); return DCA_ERR_NOMEM; }
+    hipLaunchKernelGGL(gemm_nt_f64_streamk_kernel, dim3((unsigned)((g.W + 7) / 8 * 8 * g.gx)), dim3(256), (size_t)6 * 128 * 16 * sizeof(double), stream, g);
+    hipLaunchKernelGGL(gemm_streamk_fixup_kernel, dim3(tiles), dim3(256), 0, stream, g);
+    HIP_TRY(hipGetLastError());
+    return DCA_OK;
+}
+
+struct BlockedCfg { int W, cap, overlap, minN, splitMinK, roundK, trsmSplit, streamK; };
 static const BlockedCfg& blocked_cfg()
 {
     static const BlockedCfg c = [] {
@@ -1440,13 +1635,19 @@ static const BlockedCfg& blocked_cfg()
         // the factor on the chain, the rows below on the bulk stream -- 22.7 against 21.7 ms at n = 10 048 (13.0 / 12.6 at 8000,
         // 7.50 / 7.58 at 6016): the bulk stream is the longer of the two, and every cap from 248 to 2000 workgroups gives
         // 21.7 - 22.9 ms (160: 24.4), with the eight-wave bulk kernel 21.9 - 23.7 (profiles/r05_inverse_sweeps.txt)
-        BlockedCfg v{512, 248, 1, 5000, 512, 300, 0};
+        // streamK (DCA_CHOLINV_STREAMK=1; round 5, measured, NOT adopted): the bulk products in the stream-K form above -- 24.7 - 26.5 ms
+        // against 21.6: equal k-tile counts per workgroup, but the pieces stand at different k of the operands, so the
+        // 512 x K operand that the one-workgroup-per-tile form keeps in the L2 (all its workgroups walk k together) comes
+        // from the fabric for every piece: 58 % of the matrix-core rate per CU against 91 % (tools/experiments/streamk_bench.hip,
+        // profiles/r05_streamk_bench.txt: 40 TF on 256 CUs against 42 on 172)
+        BlockedCfg v{512, 248, 1, 5000, 512, 300, 0, 0};
         if (const char* e = getenv("DCA_CHOLINV_PANEL")) v.W = std::max(128, atoi(e) / 128 * 128);   // 0 / unparsable -> 128; DCA_CHOLINV_BLOCKED=0 selects the fused walk
         if (const char* e = getenv("DCA_CHOLINV_SIDE_CAP")) v.cap = std::max(1, atoi(e));
         if (const char* e = getenv("DCA_CHOLINV_OVERLAP")) v.overlap = atoi(e);
         if (const char* e = getenv("DCA_CHOLINV_BLOCKED_MIN")) v.minN = atoi(e);
         if (const char* e = getenv("DCA_CHOLINV_ROUNDK")) v.roundK = atoi(e);
         if (const char* e = getenv("DCA_CHOLINV_TRSM_SPLIT")) v.trsmSplit = atoi(e);
+        if (const char* e = getenv("DCA_CHOLINV_STREAMK")) v.streamK = atoi(e);
         if (const char* e = getenv("DCA_CHOLINV_SPLITK_MIN")) v.splitMinK = atoi(e);       // k per slice at least this (0: never split)
         if (const char* e = getenv("DCA_CHOLINV_BLOCKED")) if (atoi(e) == 0) v.minN = INT_MAX;
         return v;
@@ -1479,9 +1680,39 @@ int trtri_tree(dca_ctx* ctx, double* A, const double* Lm, int ld, const std::vec
     return DCA_OK;
 }
 
+// DCA_CHOLINV_TRACE=1 (measurement aid): timing events on both streams of the blocked inverse -- the kernel trace of the
+// profiler serialises the two queues, these do not.  Printed to stderr when the inverse has finished.
+struct StepTrace {
+    bool on = false;
+    std::vector<std::pair<std::string, hipEvent_t>> marks;
+    void mark(hipStream_t st, const char* what, int j)
+    {
+        if (!on) return;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        hipEventRecord(e, st);
+        marks.emplace_back(std::string(what) + " " + std::to_string(j), e);
+    }
+    void dump()
+    {
+        if (!on || marks.empty()) return;
+        hipDeviceSynchronize();
+        for (size_t i = 0; i < marks.size(); ++i) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, marks[0].second, marks[i].second);
+            fprintf(stderr, "cholinv trace %9.1f us  %s\n", ms * 1e3, marks[i].first.c_str());
+        }
+        for (auto& m : marks) hipEventDestroy(m.second);
+        marks.clear();
+    }
+};
+
 int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* dInfo, SideSet* side)
 {
     const BlockedCfg& cfg = blocked_cfg();
+    static const bool traceOn = getenv("DCA_CHOLINV_TRACE") && atoi(getenv("DCA_CHOLINV_TRACE")) != 0;
+    StepTrace tr;
+    tr.on = traceOn;
     const int ld = n, W = cfg.W;
     std::vector<int> b;
     for (int c = 0; c < n; c += W) b.push_back(c);
@@ -1506,7 +1737,9 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
     for (int j = 0; j < nb && rc == DCA_OK; ++j) {
         const int c = b[j], w = b[j + 1] - c, m = n - c - w;
         double* D = A + (size_t)c * ld + c;
+        tr.mark(ctx->stream, "chain: block begins", j);
         if ((rc = cholinv_rec(ctx, D, ld, w, c, chainWs, dInfo, nullptr)) != DCA_OK) break;
+        tr.mark(ctx->stream, "chain: block factored", j);
         if (m == 0) break;
         // ---- chain: the panel of the factor below the block
         if (twoStreams && j > 0) HIP_TRY(hipStreamWaitEvent(ctx->stream, ev(1, j), 0));
@@ -1516,21 +1749,30 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
         // below them are the bulk's (cfg.trsmSplit)
         const int mTop = (twoStreams && cfg.trsmSplit && m - w1 > 0) ? w1 : m;
         if ((rc = launch_gemm(ctx, GemmArgs{A + (size_t)(c + w) * ld + c, ld, MASK_NONE, D, ld, MASK_LOWER, Lj, ld, nullptr, 0, mTop, w, w, 1.0, 0.0, 0, WALK_COLUMNS_REVERSED})) != DCA_OK) break;
+        tr.mark(ctx->stream, "chain: panel of the factor done", j);
         if (twoStreams) {
             HIP_TRY(hipEventRecord(ev(0, j), ctx->stream));
             HIP_TRY(hipStreamWaitEvent(bulk, ev(0, j), 0));
         }
+        tr.mark(bulk, "bulk: begins step", j);
         if (mTop < m) {
-            if ((rc = launch_gemm_capped(bulk, GemmArgs{A + (size_t)(c + w + mTop) * ld + c, ld, MASK_NONE, D, ld, MASK_LOWER, Lj + (size_t)mTop * ld, ld, nullptr, 0,
-                                                         m - mTop, w, w, 1.0, 0.0, 0}, cfg.cap)) != DCA_OK) break;
+            if (cfg.streamK) rc = launch_gemm_streamk(bulk, A + (size_t)(c + w + mTop) * ld + c, ld, D, ld, MASK_LOWER, Lj + (size_t)mTop * ld, ld, m - mTop, w, w, 1.0, 0.0,
+                                                      sidePartials, sidePartialsCap, cfg.cap);
+            else rc = launch_gemm_capped(bulk, GemmArgs{A + (size_t)(c + w + mTop) * ld + c, ld, MASK_NONE, D, ld, MASK_LOWER, Lj + (size_t)mTop * ld, ld, nullptr, 0,
+                                                        m - mTop, w, w, 1.0, 0.0, 0}, cfg.cap);
+            if (rc != DCA_OK) break;
             bulkInFlight = true;
         }
         // ---- bulk: rows of panel j + 1 under its diagonal block, from L_j
         if (m - w1 > 0) {
-            if ((rc = launch_gemm_capped(bulk, GemmArgs{Lj + (size_t)w1 * ld, ld, MASK_NONE, Lj, ld, MASK_NONE, A + (size_t)(c + w + w1) * ld + c + w, ld, nullptr, 0,
-                                                         m - w1, w1, w, -1.0, 1.0, 0}, cfg.cap)) != DCA_OK) break;
+            if (cfg.streamK) rc = launch_gemm_streamk(bulk, Lj + (size_t)w1 * ld, ld, Lj, ld, MASK_NONE, A + (size_t)(c + w + w1) * ld + c + w, ld, m - w1, w1, w, -1.0, 1.0,
+                                                      sidePartials, sidePartialsCap, cfg.cap);
+            else rc = launch_gemm_capped(bulk, GemmArgs{Lj + (size_t)w1 * ld, ld, MASK_NONE, Lj, ld, MASK_NONE, A + (size_t)(c + w + w1) * ld + c + w, ld, nullptr, 0,
+                                                        m - w1, w1, w, -1.0, 1.0, 0}, cfg.cap);
+            if (rc != DCA_OK) break;
             bulkInFlight = true;
             if (twoStreams) HIP_TRY(hipEventRecord(ev(1, j + 1), bulk));
+            tr.mark(bulk, "bulk: rows of the next panel done", j);
             // ---- bulk: panel j + 2 from all the panels up to j at once
             const int c2 = b[j + 2], w2 = b[j + 3 <= nb ? j + 3 : nb] - c2;
             if (w2 > 0) {
@@ -1550,11 +1792,13 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
                         if (cost < best) { best = cost; slices = sl; }
                     }
                 }
-                if (slices > 1) rc = launch_gemm_splitk_capped(bulk, Lrows, ld, Lrows, ld, A + (size_t)c2 * ld + c2, ld, n - c2, w2, K, slices, sidePartials, cfg.cap);
+                if (cfg.streamK) rc = launch_gemm_streamk(bulk, Lrows, ld, Lrows, ld, MASK_NONE, A + (size_t)c2 * ld + c2, ld, n - c2, w2, K, -1.0, 1.0, sidePartials, sidePartialsCap, cfg.cap);
+                else if (slices > 1) rc = launch_gemm_splitk_capped(bulk, Lrows, ld, Lrows, ld, A + (size_t)c2 * ld + c2, ld, n - c2, w2, K, slices, sidePartials, cfg.cap);
                 else rc = launch_gemm_capped(bulk, GemmArgs{Lrows, ld, MASK_NONE, Lrows, ld, MASK_NONE, A + (size_t)c2 * ld + c2, ld, nullptr, 0,
                                                             n - c2, w2, K, -1.0, 1.0, 1}, cfg.cap);
                 if (rc != DCA_OK) break;
                 if (twoStreams) HIP_TRY(hipEventRecord(ev(2, j + 2), bulk));
+                tr.mark(bulk, "bulk: deep update of panel j + 2 done", j);
             }
         }
         // ---- chain: the next diagonal block from L_j (after the deep-K update of the same block)
@@ -1566,7 +1810,11 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
         HIP_TRY(hipEventRecord(ev(0, nb), bulk));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ev(0, nb), 0));
     }
-    return trtri_tree(ctx, A, Lm, ld, b, 0, nb, ws);
+    tr.mark(ctx->stream, "factorisation done", nb);
+    rc = trtri_tree(ctx, A, Lm, ld, b, 0, nb, ws);
+    tr.mark(ctx->stream, "triangular inverse done", nb);
+    tr.dump();
+    return rc;
 }
 
 }  // namespace
