@@ -151,13 +151,26 @@ def cpu_baseline(X, q, lh, lJ, evals_per_iter, sample_rows):
     return out
 
 
+def gather_issue_model(q, precision):
+    """What the two gather kernels ISSUE per (sequence, site, 512-byte strip) unit: packed adds and LDS row bytes.  q = 21 and
+    the float64 mode: one indexed add per unit, the per-site blocks of tools/gen_plm_asm.py.  q = 5 in float32 (round 5) walks
+    site PAIRS on the 25-state alphabet: the logits kernel (25 + 80) adds and 10 row reads per 160 units, the scatter
+    kernel one add per two units and one row read per four."""
+    from tools.gen_plm_asm import LOGITS_CFG
+    if q == 5 and precision == 32 and os.environ.get("DCA_PLM_PAIRS") != "0":
+        nseq = LOGITS_CFG[25][1]
+        return {"plm_logits": {"adds": (25.0 + nseq) / (2.0 * nseq), "lds_bytes": 10 * 512.0 / (2.0 * nseq)},
+                "plm_scatter": {"adds": 0.5, "lds_bytes": 512.0 / 4}, "formulation": "site-pair alphabet (25 combined states)"}
+    return {"plm_logits": {"adds": 1.0, "lds_bytes": q * 512.0 / LOGITS_CFG[q][1]}, "plm_scatter": {"adds": 1.0, "lds_bytes": 512.0 / 2},
+            "formulation": "per-site blocks"}
+
+
 def rna_workload_block(device, steps=10, warmup=3):
     """Config E (plmdca rna, L=150 N=200k q=5: BASELINE.json's "bandwidth-bound regime" case) on this GPU, beside the headline
     configuration: iterations/s and what its two gather kernels reach of the same roofs.  q = 5 runs other kernel
     variants than q = 21 (logits: 16 waves x 48 sequences, scatter: strips dealt to the XCDs by (strip, split))."""
     from pydca_amd import _lib
     from tools.gen_msa import dedup, generate
-    from tools.gen_plm_asm import LOGITS_CFG
     L, N, q, seed, lh, lJ = WORKLOADS["E"]
     X = dedup(generate(L, N, q, seed))
     N = X.shape[0]
@@ -184,12 +197,17 @@ def rna_workload_block(device, steps=10, warmup=3):
            "weights_kernel_ms": t_w, "kernels": {k: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in kt.items()}, "roofline": {}}
     alg = {"plm_logits": Lq * Lq * esz + N * L + N * Lq * esz, "plm_scatter": N * Lq * esz + Lq * Lq * esz + N * L * 2,
            "plm_softmax": 2 * N * Lq * esz + N * L + 4 * N}
-    lds = {"plm_logits": units * q * 512.0 / LOGITS_CFG[q][1], "plm_scatter": units * 512.0 / 2}
+    model = gather_issue_model(q, 32)
+    out["gather_formulation"] = model["formulation"]
+    lds = {k: units * model[k]["lds_bytes"] for k in ("plm_logits", "plm_scatter")}
     for k in ("plm_logits", "plm_scatter", "plm_softmax"):
         avg_s = kt[k][0] / max(kt[k][1], 1) / 1e3
         r = {"avg_kernel_ms": avg_s * 1e3, "hbm": {"achieved": alg[k] / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg[k] / avg_s / 1e9 / HBM_PEAK_GBS}}
         if k in lds:
-            r["valu"] = {"achieved": N * L * Lq / avg_s / 1e12, "peak": 78.6, "unit": "Tadd/s", "frac": N * L * Lq / avg_s / 1e12 / 78.6}
+            issued = N * L * Lq * model[k]["adds"]          # packed-add lanes the kernel really issues (the pair alphabet needs fewer than one per unit)
+            r["valu"] = {"achieved": issued / avg_s / 1e12, "peak": 78.6, "unit": "Tadd/s", "frac": issued / avg_s / 1e12 / 78.6,
+                         "issued_adds_per_sequence_site_column": model[k]["adds"],
+                         "sequence_site_column_sums_per_s": N * L * Lq / avg_s / 1e12}
             r["onchip"] = {"achieved": lds[k] / avg_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": lds[k] / avg_s / 1e9 / LDS_PEAK_GBS}
         out["roofline"][k] = r
     ctx.close()
@@ -592,9 +610,9 @@ def main():
     # on-chip view.  One unit = one 512-byte row piece added to a running sum; N*L*(Lq*esz/512) units per launch.
     # LDS bytes actually read per unit: logits fetches the q rows of a site once per wave for its nseq sequences,
     # scatter reads every row once per wave for its two sites.
-    from tools.gen_plm_asm import LOGITS_CFG
     units = n_local * L * (Lq * esz / 512.0)
-    lds_bytes = {"plm_logits": units * q * 512.0 / LOGITS_CFG[q][1], "plm_scatter": units * 512.0 / 2}
+    model = gather_issue_model(q, args.precision)
+    lds_bytes = {k: units * model[k]["lds_bytes"] for k in ("plm_logits", "plm_scatter")}
     dom = max(alg_bytes, key=lambda k: ktimes[k][0])
     ms, launches = ktimes[dom]
     avg_s = ms / max(launches, 1) / 1e3
@@ -611,7 +629,8 @@ def main():
             traffic_stale = tj.get("kernel_sources_sha256") != kernel_sources_fingerprint()
         except Exception:
             traffic = None
-    adds = n_local * L * Lq                       # indexed adds per launch: one per (sequence, site, column)
+    sums = n_local * L * Lq                       # (sequence, site, column) sums per launch
+    adds = sums * model[dom]["adds"]              # packed-add lanes issued for them (one each, except on the q = 5 site-pair alphabet)
     valu_peak = 78.6 if args.precision == 32 else 39.3     # 157.3 TFLOP/s fp32 vector = 78.6e12 FMA slots/s; fp64 half of that
     hbm_view = {"bound": "hbm", "achieved": alg_bytes[dom] / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg_bytes[dom] / avg_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes[dom]}
@@ -628,6 +647,7 @@ def main():
                 "stage_kernels": {"plm_logits": ["plm_logits_kernel"],
                                   "plm_scatter": ["plm_scatter_kernel (main)", "plm_scatter_kernel (left-over strips)",
                                                   "plm_sum_slabs_cols_kernel"]}[dom],
+                "gather_formulation": model["formulation"], "issued_adds_per_sequence_site_column": model[dom]["adds"],
                 "note": "gather kernel: bound on chip by the issue of the indexed packed adds (1 SALU + 1 VALU per 512-byte row piece), not by HBM; "
                         "peak = fp%d vector peak counted in adds" % (32 if args.precision == 32 else 64),
                 "hbm": hbm_view,
@@ -638,7 +658,7 @@ def main():
     for k in alg_bytes:
         k_s = ktimes[k][0] / max(ktimes[k][1], 1) / 1e3
         if k_s > 0:
-            roofline["per_kernel"][k] = {"avg_ms": k_s * 1e3, "valu_frac": adds / k_s / 1e12 / valu_peak,
+            roofline["per_kernel"][k] = {"avg_ms": k_s * 1e3, "valu_frac": sums * model[k]["adds"] / k_s / 1e12 / valu_peak,
                                          "hbm_frac": alg_bytes[k] / k_s / 1e9 / HBM_PEAK_GBS}
     kernels_ms = {k: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in ktimes.items()}
 

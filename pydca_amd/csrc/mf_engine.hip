@@ -46,7 +46,7 @@ constexpr int kSortThreads = 256;
 
 __global__ __launch_bounds__(kSortThreads)
 void mf_site_sort_kernel(const uint8_t* __restrict__ XT, const double* __restrict__ w, uint32_t* __restrict__ perm,
-                         double* __restrict__ wperm, int* __restrict__ off, uint8_t* __restrict__ dom, double* __restrict__ cnt1,
+                         int* __restrict__ off, uint8_t* __restrict__ dom, double* __restrict__ cnt1,
                          int N, int Nt, int q)
 {
     __shared__ int cnts[32][kSortThreads + 1];
@@ -78,17 +78,12 @@ void mf_site_sort_kernel(const uint8_t* __restrict__ XT, const double* __restric
         dom[i] = (uint8_t)best;
     }
     __syncthreads();
-    // wperm: the weights in list order beside the list (round 5) -- the counts kernel then reads a batch's weights as
-    // one contiguous run instead of 32 gathered scalar loads, each a round trip of its own behind the list entries
     uint32_t* p = perm + (size_t)i * N;
-    double* wp = wperm + (size_t)i * N;
     for (int b = 0; b < q; ++b) local[b] = base[b] + cnts[b][t];
     for (int n = nb; n < ne; ++n) {
         const int b = col[n];
-        const double wn = w[n];
-        wp[local[b]] = wn;
         p[local[b]++] = (uint32_t)n;
-        wsum[b][t] += wn;                           // ascending n inside the segment
+        wsum[b][t] += w[n];                         // ascending n inside the segment
     }
     __syncthreads();
     if (t < q) {              // weighted count of state t: segments in ascending order (deterministic)
@@ -116,8 +111,8 @@ __device__ __forceinline__ void lds_add(double* p, double v)
 // sum_a Craw[(i,a)][(j,b)] = cnt1[j][b].
 template <bool PREFETCH>
 __global__ __launch_bounds__(kCountThreads)
-void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ w, const double* __restrict__ wperm,
-                      const uint32_t* __restrict__ perm, const int* __restrict__ off, const uint8_t* __restrict__ dom, double* __restrict__ Craw,
+void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ w, const uint32_t* __restrict__ perm,
+                      const int* __restrict__ off, const uint8_t* __restrict__ dom, double* __restrict__ Craw,
                       int N, int L, int Ls, int q, int ldc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
@@ -126,7 +121,6 @@ void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ 
     if (a == dom[i] || i == L - 1) return;
     const int k0 = off[i * (q + 1) + a], k1 = off[i * (q + 1) + a + 1];
     const uint32_t* p = perm + (size_t)i * N;
-    const double* wp = wperm + (size_t)i * N;       // the weights of the list's sequences, in list order
     const int t = threadIdx.x;
 #ifndef DCA_COUNTS_U
 #define DCA_COUNTS_U 32
@@ -161,16 +155,16 @@ void mf_counts_kernel(const uint8_t* __restrict__ X, const double* __restrict__ 
                     for (int u = 0; u < U; ++u) nn[u] = p[k + U + u];
                 }
 #pragma unroll
-                // weights: in list order from the permuted copy where the list entries are scalar loads (one contiguous run
-                // instead of U gathered round trips: D 4.1 -> 3.86 ms); gathered per lane beside the prefetched entries (with
-                // scalar loads there the s_waitcnt that covers them also drains the LDS adds: E 4.1 -> 6.1 ms)
-                for (int u = 0; u < U; ++u) { wv[u] = PREFETCH ? w[n[u]] : wp[k + u]; bb[u] = Xj[(size_t)n[u] * Ls]; }
+                // (round 5, measured, not kept: the weights in list order beside the lists, written by the sort kernel -- one
+                // contiguous run per batch instead of U gathered loads: counts 4.1 -> 3.8 ms at D, but the sort kernel's
+                // scattered 8-byte stores cost the same 0.3 ms, and for q = 5 the scalar run's s_waitcnt drains the LDS adds)
+                for (int u = 0; u < U; ++u) { wv[u] = w[n[u]]; bb[u] = Xj[(size_t)n[u] * Ls]; }
 #pragma unroll
                 for (int u = 0; u < U; ++u) lds_add(&hist[bb[u] * kCountThreads + t], wv[u]);     // list order: ascending n
             }
             for (; k < k1; ++k) {
                 const uint32_t n = p[k];
-                lds_add(&hist[Xj[(size_t)n * Ls] * kCountThreads + t], wp[k]);
+                lds_add(&hist[Xj[(size_t)n * Ls] * kCountThreads + t], w[n]);
             }
         }
         // the block's part of row (i,a) is one contiguous run of (sites in the block) x q doubles: store it in that
@@ -313,7 +307,6 @@ struct MfEngine {
     dca_ctx* ctx;
     int N, L, q, Ls, Lq, n, np;
     uint32_t* dPerm = nullptr;
-    double* dWperm = nullptr;         // the weights in the order of the per-site lists
     int* dOff = nullptr;
     uint8_t *dXT = nullptr, *dDom = nullptr;
     double* dCnt1 = nullptr;
@@ -332,7 +325,7 @@ struct MfEngine {
     bool counts_global = false;       // the cached counts are the sum over all ranks' windows (= the whole alignment's)
     double meff = 0.0;                // Meff the frequencies are normalised by: ctx->meff (this context's weights) summed over
                                       // the shards when a hook / the native reduction is set; ctx->meff itself stays local
-    ~MfEngine() { dca_dev_free(dRegFi); dca_dev_free(dPerm); dca_dev_free(dWperm); dca_dev_free(dOff); dca_dev_free(dXT); dca_dev_free(dDom); dca_dev_free(dCnt1); dca_dev_free(dCraw); dca_dev_free(dFi); dca_dev_free(dC); dca_dev_free(dWork); }
+    ~MfEngine() { dca_dev_free(dRegFi); dca_dev_free(dPerm); dca_dev_free(dOff); dca_dev_free(dXT); dca_dev_free(dDom); dca_dev_free(dCnt1); dca_dev_free(dCraw); dca_dev_free(dFi); dca_dev_free(dC); dca_dev_free(dWork); }
 };
 
 MfEngine* dca_make_mf_engine(dca_ctx* ctx)
@@ -359,7 +352,6 @@ static int mf_counts(MfEngine* m)
     const double* Ww = ctx->dWd + rowFirst;
     if (!m->dPerm) {
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dPerm), (size_t)m->L * m->N * sizeof(uint32_t), false));
-        HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dWperm), (size_t)m->L * m->N * sizeof(double), false));
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dOff), (size_t)m->L * (m->q + 1) * sizeof(int)));
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dCraw), (size_t)m->Lq * m->Lq * sizeof(double), false));
         HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&m->dFi), (size_t)m->Lq * sizeof(double)));
@@ -371,17 +363,17 @@ static int mf_counts(MfEngine* m)
         ScopedKernelClock kc(ctx, "mf_sort");
         hipLaunchKernelGGL(mf_transpose_kernel, dim3(std::max(1, ceil_div(Nw, 64)), ceil_div(m->L, 64)), dim3(256), 0, ctx->stream,
                            Xw, m->dXT, Nw, m->L, m->Ls, Nt);
-        hipLaunchKernelGGL(mf_site_sort_kernel, dim3(m->L), dim3(kSortThreads), 0, ctx->stream, m->dXT, Ww, m->dPerm, m->dWperm,
+        hipLaunchKernelGGL(mf_site_sort_kernel, dim3(m->L), dim3(kSortThreads), 0, ctx->stream, m->dXT, Ww, m->dPerm,
                            m->dOff, m->dDom, m->dCnt1, Nw, Nt, m->q);
     }
     {
         ScopedKernelClock kc(ctx, "mf_counts");
         const size_t lds = (size_t)m->q * kCountThreads * sizeof(double);
         if (m->q <= 8)
-            hipLaunchKernelGGL(mf_counts_kernel<true>, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, Xw, Ww, m->dWperm,
+            hipLaunchKernelGGL(mf_counts_kernel<true>, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, Xw, Ww,
                                m->dPerm, m->dOff, m->dDom, m->dCraw, Nw, m->L, m->Ls, m->q, m->Lq);
         else
-            hipLaunchKernelGGL(mf_counts_kernel<false>, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, Xw, Ww, m->dWperm,
+            hipLaunchKernelGGL(mf_counts_kernel<false>, dim3(m->L * m->q), dim3(kCountThreads), lds, ctx->stream, Xw, Ww,
                                m->dPerm, m->dOff, m->dDom, m->dCraw, Nw, m->L, m->Ls, m->q, m->Lq);
         hipLaunchKernelGGL(mf_complete_kernel, dim3(m->L, m->L), dim3(64), 0, ctx->stream, m->dCraw, m->dCnt1, m->dDom,
                            m->L, m->q, m->Lq);

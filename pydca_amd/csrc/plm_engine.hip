@@ -328,7 +328,7 @@ template <typename T, int Q>
 __global__ __launch_bounds__(256)
 void plm_softmax_kernel(const T* __restrict__ SR, T* __restrict__ Rout, const T* __restrict__ x, const uint8_t* __restrict__ X,
                         const T* __restrict__ w, double* __restrict__ fxPart,
-                        int N, int L, int Ls, int Cs, int halo, int chunk, int warm, int carry, int numChunks)
+                        int N, int L, int Ls, int Cs, int halo, int chunk, int warm, int carry, int numChunks, double* __restrict__ colPart)
 {
     constexpr int ROWB = 64 * Q * (int)sizeof(T);        // bytes of a wave's span of one row
     constexpr int NP = (ROWB + 1023) / 1024;             // 16-byte pieces per lane
@@ -347,6 +347,15 @@ void plm_softmax_kernel(const T* __restrict__ SR, T* __restrict__ Rout, const T*
     unsigned char* sOut = sIn + NP * 1024;
     const int rowBytes = (min(64, L - i0) * Q * (int)sizeof(T) + 15) & ~15;
     double facc = 0.0, flo = 0.0;
+    // float64, q = 5 (round 5): the double-double column sums of R (the field gradients, plm_colsum_*) are taken here, where
+    // R is made, instead of in one more pass over it -- five more double-double accumulators per lane (for q = 21 the 42
+    // registers do not fit beside the row buffers).  One partial per (chunk, site, state); colPart == nullptr: not wanted.
+    constexpr bool COLSUM = sizeof(T) == 8 && Q == 5;
+    [[maybe_unused]] double chi[COLSUM ? Q : 1], clo[COLSUM ? Q : 1];
+    if constexpr (COLSUM) {
+#pragma unroll
+        for (int a = 0; a < Q; ++a) chi[a] = clo[a] = 0.0;
+    }
     if (chunkId < numChunks) {
         const int s = halo + chunkId * chunk;
         const int e = min(s + chunk, N);
@@ -408,6 +417,7 @@ void plm_softmax_kernel(const T* __restrict__ SR, T* __restrict__ Rout, const T*
                             T r = wn * p[a];
                             if (a == xi) r -= wn;
                             reinterpret_cast<T*>(sOut)[lane * Q + a] = r;
+                            if constexpr (COLSUM) dd_add(chi[a], clo[a], (double)r);
                         }
                         __builtin_amdgcn_wave_barrier();
                         unsigned char* row = reinterpret_cast<unsigned char*>(Rout + (size_t)n * Cs + (size_t)i0 * Q);
@@ -419,6 +429,16 @@ void plm_softmax_kernel(const T* __restrict__ SR, T* __restrict__ Rout, const T*
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
+            }
+        }
+    }
+    if constexpr (COLSUM) {
+        if (colPart && chunkId < numChunks && i < L) {
+#pragma unroll
+            for (int a = 0; a < Q; ++a) {
+                const size_t o = 2 * ((size_t)chunkId * L * Q + (size_t)i * Q + a);
+                colPart[o] = chi[a];
+                colPart[o + 1] = clo[a];
             }
         }
     }
@@ -752,6 +772,17 @@ void plm_colsum_parts_kernel(const T* __restrict__ R, int N, int Cs, int Lq, dou
         parts[2 * ((size_t)blockIdx.y * Lq + c)] = hi;
         parts[2 * ((size_t)blockIdx.y * Lq + c) + 1] = lo;
     }
+}
+// the softmax kernel's per-chunk partials (q = 5): row block b of the output = the chunks b, b + gridDim.y, ... in that order
+__global__ __launch_bounds__(256)
+void plm_colsum_chunks_kernel(const double* __restrict__ chunkParts, int numChunks, int Lq, double* __restrict__ parts)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Lq) return;
+    double hi = 0.0, lo = 0.0;
+    for (int k = blockIdx.y; k < numChunks; k += gridDim.y) dd_add2(hi, lo, chunkParts[2 * ((size_t)k * Lq + c)], chunkParts[2 * ((size_t)k * Lq + c) + 1]);
+    parts[2 * ((size_t)blockIdx.y * Lq + c)] = hi;
+    parts[2 * ((size_t)blockIdx.y * Lq + c) + 1] = lo;
 }
 __global__ void plm_colsum_final_kernel(const double* __restrict__ parts, int nblocks, int Lq, double* __restrict__ colSum)
 {
@@ -1400,6 +1431,7 @@ struct PlmEngine : PlmEngineBase {
     PairIJ* dPairs = nullptr;
     double *dFxPart = nullptr, *dRegPart = nullptr, *dVecPart = nullptr;
     double *dColPart = nullptr, *dColSum = nullptr;      // float64 mode: column sums of R in double-double
+    double* dColChunk = nullptr;                         // ... q = 5: per scan chunk, from the softmax kernel
     // Column-strip decomposition (native_mode 4, configure_strips): this rank holds the COLUMNS of sites [cS0, cS1) of W, S, R
     // and G (re-based to column 0; Cs is the window's stride), walks all sequences, and owns the packed parameters
     // [oLo, oHi): the pairs (i, j) whose first site it holds (rank 0 the fields too).  Without it the window is everything.
@@ -1447,7 +1479,7 @@ struct PlmEngine : PlmEngineBase {
         for (int i = 0; i < 5; ++i) { dca_dev_free(dS[i]); dca_dev_free(dY[i]); }
         dca_dev_free(dLb); dLb = nullptr; dca_dev_free(dWt); dca_dev_free(dSR); dca_dev_free(dR); dca_dev_free(dG); dca_dev_free(dw); dca_dev_free(dXL); dca_dev_free(dXT2);
         dca_dev_free(dPairs); dca_dev_free(dFxPart); dca_dev_free(dRegPart); dca_dev_free(dVecPart);
-        dca_dev_free(dColPart); dca_dev_free(dColSum);
+        dca_dev_free(dColPart); dca_dev_free(dColSum); dca_dev_free(dColChunk);
         dca_dev_free(dGrecv); dca_dev_free(dXsend); dca_dev_free(dXrecv);
     }
     ~PlmEngine() override { freeall(); }
@@ -1514,7 +1546,7 @@ struct PlmEngine : PlmEngineBase {
         for (int i = 0; i < 5; ++i) dS[i] = dY[i] = nullptr;
         dWt = dSR = dR = dG = dw = nullptr; dXL = nullptr; dXT2 = nullptr; dPairs = nullptr;
         dFxPart = dRegPart = dVecPart = nullptr;
-        dColPart = dColSum = nullptr;
+        dColPart = dColSum = dColChunk = nullptr;
         dGrecv = dXsend = dXrecv = nullptr;
         lbfgs_alloc = false;
         o = decltype(o)();
@@ -1639,6 +1671,7 @@ struct PlmEngine : PlmEngineBase {
         HIP_TRY(hipMemsetAsync(dFxPart, 0, 2 * (size_t)nFxPart * sizeof(double), ctx->stream));
         if (sizeof(T) == 8) {
             DCA_TRY(dalloc(&dColPart, 2 * (size_t)kColSumRowBlocks * Lq));
+            if (q == 5) DCA_TRY(dalloc(&dColChunk, 2 * (size_t)numScanChunks * Lq));      // the softmax kernel's per-chunk column sums
             DCA_TRY(dalloc(&dColSum, (size_t)Lq));
         }
         grecvOff.assign(sWorld + 1, 0); xsendOff.assign(sWorld + 1, 0); xrecvOff.assign(sWorld + 1, 0);
@@ -1839,7 +1872,7 @@ struct PlmEngine : PlmEngineBase {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plm_softmax_kernel<T, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)softLds));
             // the window's sites: their fields, their alignment column, their columns of S / R
             hipLaunchKernelGGL((plm_softmax_kernel<T, Q>), grid, dim3(256), softLds, st, dSR, dR, dx + (size_t)cS0 * q, ctx->dX + cS0, dw, dFxPart,
-                               N, Lloc, Ls, Cs, halo, chunk, warm, carry_mode != DCA_CARRY_EXACT ? 1 : 0, numScanChunks);
+                               N, Lloc, Ls, Cs, halo, chunk, warm, carry_mode != DCA_CARRY_EXACT ? 1 : 0, numScanChunks, dColChunk);
         }
         DCA_ROUND_STAGE(4, dR, (size_t)N * Cs);
         {
@@ -1889,7 +1922,10 @@ struct PlmEngine : PlmEngineBase {
                 foldSlabs = 1;
             }
             if (dColSum) {
-                hipLaunchKernelGGL(plm_colsum_parts_kernel<T>, dim3(ceil_div(LqLoc, 64), kColSumRowBlocks), dim3(256), 0, st, dR, N, Cs, LqLoc, dColPart);
+                if (dColChunk)
+                    hipLaunchKernelGGL(plm_colsum_chunks_kernel, dim3(ceil_div(LqLoc, 256), kColSumRowBlocks), dim3(256), 0, st, dColChunk, numScanChunks, LqLoc, dColPart);
+                else
+                    hipLaunchKernelGGL(plm_colsum_parts_kernel<T>, dim3(ceil_div(LqLoc, 64), kColSumRowBlocks), dim3(256), 0, st, dR, N, Cs, LqLoc, dColPart);
                 hipLaunchKernelGGL(plm_colsum_final_kernel, dim3(ceil_div(LqLoc, 256)), dim3(256), 0, st, dColPart, kColSumRowBlocks, LqLoc, dColSum);
             }
             hipLaunchKernelGGL(plm_fold_fields_kernel<T>, dim3(ceil_div(LqLoc, 256)), dim3(256), 0, st, dx + (size_t)cS0 * q, dG, dg + (size_t)cS0 * q,
