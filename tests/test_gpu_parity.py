@@ -388,12 +388,15 @@ def test_spd_inverse_alternative_leaves(env):
 
 
 @pytest.mark.parametrize("env", [{"DCA_CHOLINV_PANEL": "128"}, {"DCA_CHOLINV_PANEL": "128", "DCA_CHOLINV_OVERLAP": "0"},
-                                 {"DCA_CHOLINV_PANEL": "256", "DCA_CHOLINV_SIDE_CAP": "7"}, {"DCA_CHOLINV_PANEL": "128", "DCA_CHOLINV_BULK_KW": "2"}])
+                                 {"DCA_CHOLINV_PANEL": "256", "DCA_CHOLINV_SIDE_CAP": "7"}, {"DCA_CHOLINV_PANEL": "128", "DCA_CHOLINV_BULK_KW": "2"},
+                                 {"DCA_CHOLINV_PANEL": "128", "DCA_CHOLINV_STREAMK": "1", "DCA_CHOLINV_TRSM_SPLIT": "1"},
+                                 {"DCA_CHOLINV_PANEL": "256", "DCA_CHOLINV_STREAMK": "1", "DCA_CHOLINV_SIDE_CAP": "12"}])
 def test_spd_inverse_blocked_form_at_small_sizes(env):
     """Round 5: the look-ahead factorisation + separate triangular-inverse tree (cholinv_blocked) is what runs for n >= 5000;
     forced here onto small matrices (panels of 128 / 256 columns, split-k from 128 columns on, one stream, tiny launch caps,
-    the eight-wave bulk kernel) so that every branch of it -- ragged last panel, split-k with its reduction, band
-    splitting, the event chain -- is compared with LAPACK."""
+    the eight-wave bulk kernel, and the two opt-in forms that were measured slower and stay off: the stream-K bulk products
+    with their ordered fix-up, the panel's lower rows on the bulk stream) so that every branch of it -- ragged last panel,
+    split-k with its reduction, band splitting, the event chain -- is compared with LAPACK."""
     import subprocess
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
