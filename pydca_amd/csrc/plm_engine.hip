@@ -169,15 +169,17 @@ __device__ __forceinline__ void logits_store(const LogitsAcc<NSEQ / 8>& acc, uns
 #define DCA_SCATTER_ABLATE 0
 #endif
 
-template <typename T, int Q>
+// JTV (site-pair alphabet only): site pairs per LDS tile, 12 (0), 11 or 10 -- the engine takes the count that pads ceil(L / 2) least
+template <typename T, int Q, int JTV = 0>
 __global__ __launch_bounds__(logits_waves(Q) * 64)
 void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL, T* __restrict__ S,
                        int N, int Npad, int L, int Cs, int numColTiles, int numNBlocks)
 {
     constexpr int WAVES = logits_waves(Q);
     constexpr int NSEQ = logits_nseq(Q);
-    constexpr int JT = logits_jt(Q);
-    constexpr int TROWS = logits_tile_rows(Q);      // rows of W per tile (Q = 25: 12 site pairs = 24 sites of 5 rows)
+    constexpr int JT = JTV ? JTV : logits_jt(Q);
+    constexpr int TROWS = JTV ? JTV * 2 * 5 : logits_tile_rows(Q);      // rows of W per tile (Q = 25: site pairs = 2 sites of 5 rows)
+    static_assert(JTV == 0 || (Q == kPairQ && (JTV == 11 || JTV == 10)), "tile variants exist for the site-pair alphabet only");
     constexpr int CW = 512 / (int)sizeof(T);
     constexpr int TILE = 128 * 512;                 // bytes of one LDS buffer (TROWS <= 128 rows)
     static_assert(Q != kPairQ || sizeof(T) == 4, "the site-pair alphabet is a float32 formulation");
@@ -261,7 +263,9 @@ void plm_logits_kernel(const T* __restrict__ W, const uint16_t* __restrict__ XL,
         const uint32_t npc = __builtin_amdgcn_readfirstlane((jt + 1 < numJT && !(DCA_LOGITS_ABLATE & 2)) ? (uint32_t)((PIECES - wave + WAVES - 1) / WAVES) : 0u);
         const unsigned char* gbase = Wbytes + (size_t)((jt + 1) * TROWS + wave * 2) * rowStrideBytes;     // wave-uniform
         const uint32_t ldst = (uint32_t)(uintptr_t)dca_smem + (buf ^ 1) * TILE + wave * 1024;
-        if constexpr (Q == kPairQ) DCA_LOGITS_Q25_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
+        if constexpr (Q == kPairQ && JTV == 11) DCA_LOGITS_Q25J11_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
+        else if constexpr (Q == kPairQ && JTV == 10) DCA_LOGITS_Q25J10_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
+        else if constexpr (Q == kPairQ) DCA_LOGITS_Q25_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
         else if constexpr (Q == 21 && sizeof(T) == 4) DCA_LOGITS_Q21_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
         else if constexpr (Q == 21) DCA_LOGITS_Q21_F64(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
         else if constexpr (sizeof(T) == 4) DCA_LOGITS_Q5_F32(vbase, sp, strideBytes, npc, gbase, ginc, voff, ldst, acc);
@@ -1417,6 +1421,7 @@ struct PlmEngine : PlmEngineBase {
     // per-site blocks, for comparisons).  gUnits = what the kernels' "L" counts: pairs then, sites otherwise.
     bool pairs = false;
     int gUnits = 0;
+    int pairJT = 12;                   // site pairs per LDS tile of the logits kernel: of 12 / 11 / 10 the count that pads gUnits least
     int logits_q() const { return pairs ? kPairQ : q; }
     int scatRemCT = 0, scatRemSplit = 0, scatRemChunksPerSplit = 0;     // left-over strips (numCT % 8) in their own, finer split launch
 
@@ -1560,8 +1565,12 @@ struct PlmEngine : PlmEngineBase {
             pairs = q == 5 && sizeof(T) == 4 && !(pe && atoi(pe) == 0);
         }
         gUnits = pairs ? ceil_div(L, 2) : L;
-        const int JT = logits_jt(logits_q());       // units per logits tile
-        Wrows = ceil_div(gUnits, JT) * logits_tile_rows(logits_q()) + 128;     // + over-read margin of the last LDS-DMA tile
+        pairJT = 12;
+        if (pairs)
+            for (int jt : {11, 10})
+                if (ceil_div(gUnits, jt) * jt < ceil_div(gUnits, pairJT) * pairJT) pairJT = jt;      // L = 150: 75 pairs = 7 x 11 (77) rather than 7 x 12 (84)
+        const int JT = pairs ? pairJT : logits_jt(q);       // units per logits tile
+        Wrows = ceil_div(gUnits, JT) * (pairs ? JT * 2 * q : JT * q) + 128;     // + over-read margin of the last LDS-DMA tile
         scatJW = 2;     // units per wave of the scatter kernel
         const int JG = kScatWavesC * scatJW;
         Grows = ceil_div(gUnits, JG) * JG * (pairs ? 2 * q : q);
@@ -1859,7 +1868,12 @@ struct PlmEngine : PlmEngineBase {
             };
             bool done = false;
             if constexpr (Q == 5 && sizeof(T) == 4) {
-                if (pairs) { DCA_TRY(launch(plm_logits_kernel<T, kPairQ>, kPairQ)); done = true; }
+                if (pairs) {
+                    if (pairJT == 11) DCA_TRY(launch(plm_logits_kernel<T, kPairQ, 11>, kPairQ));
+                    else if (pairJT == 10) DCA_TRY(launch(plm_logits_kernel<T, kPairQ, 10>, kPairQ));
+                    else DCA_TRY(launch(plm_logits_kernel<T, kPairQ>, kPairQ));
+                    done = true;
+                }
             }
             if (!done) DCA_TRY(launch(plm_logits_kernel<T, Q>, Q));
         }

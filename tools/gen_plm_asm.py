@@ -289,8 +289,11 @@ def macro(q, f64, jw=JW):
 # LDS destination.
 
 
+PAIR_JT = 12                   # pair variant: site pairs per LDS tile of the macro being generated (main() also emits 11 and 10)
+
+
 def logits_jt(q):
-    return {21: 6, 5: 25, 25: 12}[q]          # q = 25: PAIRS of q = 5 sites per tile (24 sites, 120 rows)
+    return {21: 6, 5: 25, 25: PAIR_JT}[q]     # q = 25: PAIRS of q = 5 sites per tile (24 sites, 120 rows)
 
 
 # (waves per workgroup, sequences per wave) of plm_logits_kernel.  Per site a wave spends a fixed ~490 clk fetching
@@ -498,7 +501,8 @@ def logits_macro(q, f64):
     site / bytes between sites.  Staging of the next tile: NPC pieces (0: none), piece i copies 1 KiB from
     GBASE + i * GINC + VOFF (per lane) to LDS address LDST + i * waves * 1024."""
     waves, nseq, w0, acc0, nw, tb = logits_plan(q)
-    lines = ["#define DCA_LOGITS_Q%d_%s(VBASE, SPTR, STRIDE, NPC, GBASE, GINC, VOFF, LDST, ACC) \\" % (q, "F64" if f64 else "F32"),
+    jsfx = "J%d" % PAIR_JT if q == 25 and PAIR_JT != 12 else ""
+    lines = ["#define DCA_LOGITS_Q%d%s_%s(VBASE, SPTR, STRIDE, NPC, GBASE, GINC, VOFF, LDST, ACC) \\" % (q, jsfx, "F64" if f64 else "F32"),
              "    asm volatile( \\"]
     for ln in logits_body(q, f64):
         lines.append('        "%s\\n" \\' % ln)
@@ -522,6 +526,13 @@ def main():
         for f64 in ((0, 1) if q != 25 else (0,)):          # the pair alphabet is a float32 formulation (it re-associates the sums)
             lout.append(logits_macro(q, f64))
             lout.append("")
+    # the pair variant again with 11 and 10 pairs per tile: the engine takes the one that pads ceil(L / 2) least
+    # (L = 150: 75 pairs are 7 tiles of 12 = 84 pair steps, or 7 of 11 = 77)
+    global PAIR_JT
+    for PAIR_JT in (11, 10):
+        lout.append(logits_macro(25, 0))
+        lout.append("")
+    PAIR_JT = 12
     lpath = os.path.join(here, "..", "pydca_amd", "csrc", "logits_gather_asm.inc")
     with open(lpath, "w") as fh:
         fh.write("\n".join(lout))
