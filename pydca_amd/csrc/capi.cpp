@@ -617,7 +617,12 @@ int dca_spd_inverse(dca_ctx* ctx, const double* A, int n, double* Ainv_out)
     if (!A || !Ainv_out || n <= 0) return DCA_ERR_ARG;
     const int np = (int)round_up((size_t)n, 64);
     std::vector<double> padded((size_t)np * np, 0.0);
-    for (int r = 0; r < n; ++r) memcpy(padded.data() + (size_t)r * np, A + (size_t)r * n, (size_t)n * sizeof(double));
+    // the LOWER triangle of A is what is inverted (as LAPACK's 'L' routines read it): mirrored here, because the device
+    // path reads both halves of the matrix
+    for (int r = 0; r < n; ++r) {
+        memcpy(padded.data() + (size_t)r * np, A + (size_t)r * n, (size_t)(r + 1) * sizeof(double));
+        for (int c = 0; c < r; ++c) padded[(size_t)c * np + r] = A[(size_t)r * n + c];
+    }
     for (int r = n; r < np; ++r) padded[(size_t)r * np + r] = 1.0;
     double *dA = nullptr, *dWork = nullptr;
     HIP_TRY(dca_dev_malloc(reinterpret_cast<void**>(&dA), padded.size() * sizeof(double)));

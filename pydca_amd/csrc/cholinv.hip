@@ -1277,7 +1277,7 @@ bool launch_gemm_small_pair(dca_ctx* ctx, const GemmArgs& a, const GemmArgs& b)
     return true;
 }
 
-int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
+int launch_gemm_on(hipStream_t stream, const GemmArgs& g)
 {
     dim3 grid(g.N / BN, g.M / BM);
     if (g.walk == WALK_COLUMNS_REVERSED) grid = dim3(g.M / BM, g.N / BN);
@@ -1287,11 +1287,11 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
     if ((long long)grid.x * grid.y <= small32Max) {          // far fewer tiles than CUs: 32 x 32 tiles on four times as many CUs
         dim3 g32(grid.x * 2, grid.y * 2);
         const size_t lds = (size_t)2 * (32 + 32) * (64 + 2) * sizeof(double);
-        hipLaunchKernelGGL(gemm_nt_f64_small_kernel, g32, dim3(256), lds, ctx->stream, g);
+        hipLaunchKernelGGL(gemm_nt_f64_small_kernel, g32, dim3(256), lds, stream, g);
         return DCA_OK;
     }
     if ((long long)grid.x * grid.y <= deepMaxTiles) {       // under two workgroups per CU: latency bound (measured: 0 -> 37.7, 128 -> 37.0, 400 -> 36.4, 1600 -> 36.9 ms)
-        hipLaunchKernelGGL(gemm_nt_f64_kernel<64>, grid, dim3(256), gemm_lds_bytes<64>(), ctx->stream, g);
+        hipLaunchKernelGGL(gemm_nt_f64_kernel<64>, grid, dim3(256), gemm_lds_bytes<64>(), stream, g);
     } else {
         static const bool ahead2 = getenv("DCA_GEMM_AHEAD2") && atoi(getenv("DCA_GEMM_AHEAD2")) != 0;
         static const bool dma = !(getenv("DCA_GEMM_DMA") && atoi(getenv("DCA_GEMM_DMA")) == 0);
@@ -1315,20 +1315,21 @@ int launch_gemm(dca_ctx* ctx, const GemmArgs& g)
             const bool walkOk = g.walk != WALK_COLUMNS_REVERSED;
             if (!use128 && walkOk && rect && (masks == 2 || (rect == 2 && masks == 1)) && (long long)grid.x * grid.y >= 2048) {
                 // 128 x 64 tiles: grid.y counts 128-row tiles
-                hipLaunchKernelGGL((gemm_nt_f64_dma_kernel<4, 2>), dim3(grid.x, gy), dim3(256), (size_t)2 * (128 + 64) * 16 * sizeof(double), ctx->stream, g);
+                hipLaunchKernelGGL((gemm_nt_f64_dma_kernel<4, 2>), dim3(grid.x, gy), dim3(256), (size_t)2 * (128 + 64) * 16 * sizeof(double), stream, g);
             } else if (use128) {
                 dim3 grid128(gx, gy);
                 if (g.walk == WALK_COLUMNS_REVERSED) grid128 = dim3((g.M + 127) / 128, (g.N + 127) / 128);
-                hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<4>, grid128, dim3(256), (size_t)4 * 128 * 16 * sizeof(double), ctx->stream, g);
+                hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<4>, grid128, dim3(256), (size_t)4 * 128 * 16 * sizeof(double), stream, g);
             } else {
-                hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<2>, grid, dim3(256), (size_t)4 * 64 * 16 * sizeof(double), ctx->stream, g);
+                hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<2>, grid, dim3(256), (size_t)4 * 64 * 16 * sizeof(double), stream, g);
             }
         }
-        else if (ahead2) hipLaunchKernelGGL((gemm_nt_f64_kernel<16, true>), grid, dim3(256), gemm_lds_bytes<16>(), ctx->stream, g);
-        else hipLaunchKernelGGL(gemm_nt_f64_kernel<16>, grid, dim3(256), gemm_lds_bytes<16>(), ctx->stream, g);
+        else if (ahead2) hipLaunchKernelGGL((gemm_nt_f64_kernel<16, true>), grid, dim3(256), gemm_lds_bytes<16>(), stream, g);
+        else hipLaunchKernelGGL(gemm_nt_f64_kernel<16>, grid, dim3(256), gemm_lds_bytes<16>(), stream, g);
     }
     return DCA_OK;
 }
+int launch_gemm(dca_ctx* ctx, const GemmArgs& g) { return launch_gemm_on(ctx->stream, g); }
 
 // Side streams of the recursion, one per depth (a node's background product must not queue behind its ancestors'); the
 // context's own stream carries the critical path.
@@ -1817,6 +1818,465 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
     return rc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the inverse as a symmetric BLOCK SWEEP (block Gauss-Jordan on an SPD matrix).
+//
+// The three-phase form above (factorisation, triangular inverse, X^T X) is three serial phases of which the first and
+// the second run out of parallel work at their ends (a deep update of the look-ahead factorisation is 100 - 250 tiles)
+// -- 33 / 53 / 58 TF at n = 10 048 where the GEMM alone sustains 69.  The sweep does the same n^3 flop in ONE phase whose
+// every step is the same rank-w update of the WHOLE matrix.  With M symmetric (both halves stored), J the next w pivot
+// columns and P = inv(M_JJ):
+//     W      = M[:, J] P                       n x w x w
+//     M[i,j] -= W[i, :] M[j, J]^T              every tile with i, j outside J  (lower tiles, mirrored: (n - w)^2 w flop)
+//     M[:, J] = W,  M[J, :] = W^T,  M[J, J] = -P
+// and after the last panel M = -inv(A) -- the couplings themselves.  M_JJ at the time its panel is swept is the Schur
+// complement of the panels before it, so the pivots met are EXACTLY the pivots of the Cholesky factorisation of A: P comes
+// from the same leaves (X = inv(chol(M_JJ)) by the fused recursion on the w x w block, P = X^T X) and a matrix that is not
+// positive definite is reported with the same pivot index as before.
+// Two streams.  The CHAIN (context stream) owns the diagonal: from P_p it forms the next pivot block itself,
+//     S' = M[J', J'] - (M[J', J] P_p) M[J', J]^T   (three few-tile products), then X', P' ...
+// and never waits for the bulk of its own step.  The BULK stream does W, then the tiles that the chain of the NEXT steps
+// reads (column panel J' and the diagonal block after it: `prio`), then the rest, as PERSISTENT launches of at most `cap`
+// workgroups of 128 x 128 tiles (one per CU, whole CUs stay free for the chain's kernels), every workgroup walking the
+// tile list with stride `cap`; the list is ordered in bands of four tile rows so that the 31 workgroups that share an
+// XCD's L2 work on a 4 x 8 block of tiles at a time (12 operand panels instead of 62).
+enum { SWEEP_REST = 0, SWEEP_PRIO = 1 };
+struct SweepArgs {
+    const double* W; int ldw;      // n x w: the scaled panel
+    double* M; int ld;             // n x n, symmetric, both halves
+    int n, c, w;                   // pivot columns [c, c + w)
+    int nt;                        // tile rows of M (128 rows each, the last one may be short)
+    int skip0, skipN;              // tile rows left out: the pivot panel and the panel after it
+    int mode;
+    int pr0, prN;                  // SWEEP_PRIO: tile rows of the next panel
+    int dg0, dgN;                  // diagonal block of the panel after the next: its lower tiles belong to PRIO, not to REST
+    int nTiles;                    // length of the tile list (entries that decode to no tile are passed over)
+    int* ctr;                      // 8 zeroed counters: the list is cut into 8 chunks, chunk x is handed out to the workgroups of XCD x first
+};
+
+// tile list entry t -> tile (ti, tj), tj <= ti
+__device__ __forceinline__ bool sweep_tile_of(const SweepArgs& g, int t, int& ti, int& tj)
+{
+    const int nR = g.nt - g.skipN;
+    if (g.mode == SWEEP_REST) {
+        // lower triangle over the nR remaining tile rows in bands of 4 rows, column by column inside a band; band k starts at 8 k^2 + 2 k
+        int k = (int)((sqrtf(4.f + 32.f * (float)t) - 2.f) * (1.f / 16.f));
+        while (8 * (k + 1) * (k + 1) + 2 * (k + 1) <= t) ++k;
+        while (8 * k * k + 2 * k > t) --k;
+        const int u = t - (8 * k * k + 2 * k);
+        int a, b;
+        if (u < 16 * k) { b = u >> 2; a = 4 * k + (u & 3); }
+        else {
+            const int v = u - 16 * k;                          // the band's own 4 x 4 triangle, column by column
+            const int col = v < 4 ? 0 : v < 7 ? 1 : v < 9 ? 2 : 3;
+            const int row = v < 4 ? v : v < 7 ? v - 3 : v < 9 ? v - 5 : 3;
+            a = 4 * k + row; b = 4 * k + col;
+        }
+        if (a >= nR) return false;
+        ti = a < g.skip0 ? a : a + g.skipN;
+        tj = b < g.skip0 ? b : b + g.skipN;
+        if (g.dgN > 0 && tj >= g.dg0 && ti < g.dg0 + g.dgN) return false;      // tj <= ti: both inside the block
+        return true;
+    }
+    const int rect = g.prN * nR;
+    if (t < rect) {
+        const int cc = g.pr0 + t % g.prN;
+        int r = t / g.prN;
+        r = r < g.skip0 ? r : r + g.skipN;
+        ti = max(r, cc); tj = min(r, cc);
+        return true;
+    }
+    const int u = t - rect;
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= u) ++a;
+    ti = g.dg0 + a; tj = g.dg0 + u - a * (a + 1) / 2;
+    return true;
+}
+
+// 128 x 128 tiles, operands by LDS-DMA as in gemm_nt_f64_dma_kernel<4>; no triangular operand.  The accumulators START as
+// -M[tile] (fetched while the first operand tiles are on their way) and the tile is stored as -acc: the read half of the
+// read-modify-write costs no registers and no pass of its own.
+// NST operand stages in LDS (32 KB each), NST - 1 of them in flight: every k-tile of 16 is a NEW 128-byte line of every
+// operand row, so each step waits for a fetch that nobody has made before (the workgroups of an XCD walk k together, the
+// first to ask misses the L2), and one workgroup per CU has nothing else to run meanwhile: with two stages the step took
+// 2.5 us against 0.85 us of matrix-core time (round 6, first measurement: 82 us per K = 512 tile).
+#ifndef DCA_SWEEP_ABLATE
+#define DCA_SWEEP_ABLATE 0        // tools/experiments/sweep_bench.hip, timing only: 1 no load of the tile, 4 no store
+#endif
+template <int NST>
+__global__ __launch_bounds__(256, 2)
+void sweep_update_kernel(SweepArgs g)
+{
+    constexpr int BK = 16, TW = 4, BM = 128, BN = 128;
+    constexpr int PW = BM / 8 / 4;
+    constexpr int OP = BM * BK * (int)sizeof(double);
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];   // [NST][A | B]
+    unsigned char* const smem = dca_gemm_smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4, swz = (fr >> 1) & 7;
+    const int nk = g.w / BK;
+    __shared__ int s_tile;
+    int q = (int)blockIdx.x % 8, tries = 0;                         // thread 0: the chunk it draws from, chunks found empty
+
+    for (;;) {
+        if (tid == 0) {
+            int t = -1;
+            while (tries < 8) {
+                const int lo = (int)((long long)g.nTiles * q / 8), hi = (int)((long long)g.nTiles * (q + 1) / 8);
+                const int v = lo + atomicAdd(&g.ctr[q], 1);
+                if (v < hi) { t = v; break; }
+                q = (q + 1) & 7; ++tries;                           // own chunk done: help the next XCD's
+            }
+            s_tile = t;
+        }
+        __syncthreads();
+        const int t = s_tile;
+        __syncthreads();
+        if (t < 0) break;
+        int ti, tj;
+        if (!sweep_tile_of(g, t, ti, tj)) continue;                 // the same for the whole workgroup
+        // the tile itself first (oldest in the memory queue: landed when the first operand stage has)
+        double4_t acc[TW][TW];
+        const int iBase = ti * BM + wm * 64 + (lane >> 4), jBase = tj * BN + wn * 64 + (lane & 15);
+#pragma unroll
+        for (int m = 0; m < TW; ++m)
+#pragma unroll
+            for (int n = 0; n < TW; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = min(iBase + m * 16 + 4 * r, g.n - 1), j = min(jBase + n * 16, g.n - 1);
+                    acc[m][n][r] = (DCA_SWEEP_ABLATE & 1) ? 0.0 : -g.M[(size_t)i * g.ld + j];
+                }
+        const double* srcA[PW];
+        const double* srcB[PW];
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int R = 8 * (PW * wave + i) + (lane >> 3);
+            const int piece = (lane & 7) ^ ((R >> 1) & 7);
+            srcA[i] = g.W + (size_t)min(ti * BM + R, g.n - 1) * g.ldw + 2 * piece;
+            srcB[i] = g.M + (size_t)min(tj * BN + R, g.n - 1) * g.ld + g.c + 2 * piece;
+        }
+        auto issue = [&](int st, int k0) {
+#pragma unroll
+            for (int i = 0; i < PW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(smem + st * 2 * OP + (PW * wave + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < PW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(smem + st * 2 * OP + OP + (PW * wave + i) * 1024), 16, 0, 0);
+        };
+        // wait until at most `tiles` operand stages of this wave are still in flight (2 PW loads each)
+        auto wait_stages = [&](int tiles) {
+            if (tiles >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * PW) : "memory");
+            else if (tiles == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * PW) : "memory");
+            else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        auto mma_tile = [&](int st) {
+            const unsigned char* as = smem + st * 2 * OP;
+            const unsigned char* bs = as + OP;
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                const int slot = (4 * kk + fg) ^ swz;
+                double2_t a[TW], b[TW];
+#pragma unroll
+                for (int m = 0; m < TW; ++m) a[m] = *reinterpret_cast<const double2_t*>(as + (wm * 64 + 16 * m + fr) * 128 + slot * 16);
+#pragma unroll
+                for (int m = 0; m < TW; ++m) b[m] = *reinterpret_cast<const double2_t*>(bs + (wn * 64 + 16 * m + fr) * 128 + slot * 16);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int m = 0; m < TW; ++m)
+#pragma unroll
+                        for (int n = 0; n < TW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][h], b[n][h], acc[m][n], 0, 0, 0);
+            }
+        };
+        const int ahead = min(NST - 1, nk);
+        for (int s = 0; s < ahead; ++s) issue(s, s * BK);
+        wait_stages(ahead - 1);
+        __syncthreads();
+        for (int kt = 0, st = 0; kt < nk; ++kt) {
+            const int nxt = kt + NST - 1;                             // its stage is the one tile kt - 1 used
+            if (nxt < nk) issue(st == 0 ? NST - 1 : st - 1, nxt * BK);
+            mma_tile(st);
+            wait_stages(min(NST - 2, nk - kt - 2));                   // tile kt + 1 has landed
+            __syncthreads();
+            st = st == NST - 1 ? 0 : st + 1;
+        }
+        const bool diag = ti == tj;
+        if (!(DCA_SWEEP_ABLATE & 4)) {
+#pragma unroll
+            for (int m = 0; m < TW; ++m)
+#pragma unroll
+                for (int n = 0; n < TW; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = iBase + m * 16 + 4 * r, j = jBase + n * 16;
+                        if (i >= g.n || j >= g.n) continue;
+                        if (diag && j > i) continue;
+                        const double v = -acc[m][n][r];
+                        g.M[(size_t)i * g.ld + j] = v;
+                    }
+        } else if (acc[0][0][0] == 1.2345e-300) g.M[0] = 0.0;
+    }
+}
+
+// M[:, c .. c + w) <- W and M[c .. c + w, :) <- W^T outside the pivot block, the pivot block itself <- -P (32 x 32 pieces)
+__global__ __launch_bounds__(256)
+void sweep_finalize_kernel(double* __restrict__ M, int ld, int c, int w, const double* __restrict__ W, int ldw, const double* __restrict__ P, int ldp)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int k0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    if (r0 >= c && r0 < c + w) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = r0 + ty + 8 * s;
+            M[(size_t)r * ld + c + k0 + tx] = -P[(size_t)(r - c) * ldp + k0 + tx];
+        }
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int r = r0 + ty + 8 * s;
+        const double v = W[(size_t)r * ldw + k0 + tx];
+        M[(size_t)r * ld + c + k0 + tx] = v;
+        tile[ty + 8 * s][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) M[(size_t)(c + k0 + ty + 8 * s) * ld + r0 + tx] = tile[tx][ty + 8 * s];
+}
+
+// dst[j][c + k] = src[c + k][j] for the rows [c, c + w) and the columns j < cols: the part of a column panel that lies ABOVE
+// the diagonal, from the row panel left of it (the sweep keeps the lower triangle up to date; the operand loads of a
+// step read whole columns of the pivot panel)
+__global__ __launch_bounds__(256)
+void mirror_row_panel_kernel(double* __restrict__ M, int ld, int c, int w, int cols)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int k0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) tile[ty + 8 * s][tx] = M[(size_t)(c + k0 + ty + 8 * s) * ld + j0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) M[(size_t)(j0 + ty + 8 * s) * ld + c + k0 + tx] = tile[tx][ty + 8 * s];
+}
+
+// upper triangle <- transposed lower triangle, 32 x 32 pieces (the sweep's last pass: the result is bit-symmetric)
+__global__ __launch_bounds__(256)
+void symmetrize_kernel(double* __restrict__ M, int ld, int nb)
+{
+    __shared__ double tile[32][33];
+    // piece (bi, bj), bj < bi, from the linear index of the strict lower triangle of pieces
+    const int t = blockIdx.x;
+    int bi = (int)((sqrtf(8.f * (float)t + 1.f) + 1.f) * 0.5f);
+    while (bi * (bi - 1) / 2 > t) --bi;
+    while ((bi + 1) * bi / 2 <= t) ++bi;
+    const int bj = t - bi * (bi - 1) / 2;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) tile[ty + 8 * s][tx] = M[(size_t)(32 * bi + ty + 8 * s) * ld + 32 * bj + tx];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) M[(size_t)(32 * bj + ty + 8 * s) * ld + 32 * bi + tx] = tile[tx][ty + 8 * s];
+}
+// ... and inside the diagonal pieces
+__global__ __launch_bounds__(256)
+void symmetrize_diag_kernel(double* __restrict__ M, int ld)
+{
+    const int b = blockIdx.x;
+    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+        const int r = e >> 5, cc = e & 31;
+        if (cc > r) M[(size_t)(32 * b + r) * ld + 32 * b + cc] = M[(size_t)(32 * b + cc) * ld + 32 * b + r];
+    }
+}
+
+__global__ __launch_bounds__(256)
+void copy_block_kernel(double* __restrict__ dst, int ldd, const double* __restrict__ src, int lds, int rows, int cols)
+{
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    const int perRow = cols / 2;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows * perRow; e += gridDim.x * blockDim.x) {
+        const int r = e / perRow, k = 2 * (e % perRow);
+        *reinterpret_cast<double2_t*>(dst + (size_t)r * ldd + k) = *reinterpret_cast<const double2_t*>(src + (size_t)r * lds + k);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void scale_matrix_kernel(double* __restrict__ M, size_t count, double f)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) M[e] *= f;
+}
+
+struct SweepCfg { int minN, wide, narrow, wideMinN, cap, stages, perCu; };
+void sweep_update_launch(hipStream_t stream, int G, int stages, int perCu, const SweepArgs& g)
+{
+    // dynamic LDS: what the stages need; with perCu == 1 never less than 96 KB, so that a CU takes ONE of these workgroups
+    const size_t stage = (size_t)2 * 128 * 16 * sizeof(double);
+    const size_t lds = perCu >= 2 ? stages * stage : std::max<size_t>(stages, 3) * stage;
+    if (stages >= 4) hipLaunchKernelGGL(sweep_update_kernel<4>, dim3(G), dim3(256), lds, stream, g);
+    else if (stages == 3) hipLaunchKernelGGL(sweep_update_kernel<3>, dim3(G), dim3(256), lds, stream, g);
+    else hipLaunchKernelGGL(sweep_update_kernel<2>, dim3(G), dim3(256), lds, stream, g);
+}
+static const SweepCfg& sweep_cfg()
+{
+    static const SweepCfg c = [] {
+        SweepCfg v{1024, 512, 256, 6000, 496, 2, 2};
+        if (const char* e = getenv("DCA_SWEEP_MIN")) v.minN = atoi(e);
+        if (const char* e = getenv("DCA_SWEEP")) if (atoi(e) == 0) v.minN = INT_MAX;
+        if (const char* e = getenv("DCA_SWEEP_PANEL")) v.wide = v.narrow = std::max(128, atoi(e) / 128 * 128);
+        if (const char* e = getenv("DCA_SWEEP_CAP")) v.cap = std::max(8, atoi(e) / 8 * 8);
+        if (const char* e = getenv("DCA_SWEEP_STAGES")) v.stages = std::max(2, std::min(4, atoi(e)));
+        if (const char* e = getenv("DCA_SWEEP_PER_CU")) v.perCu = atoi(e);
+        return v;
+    }();
+    return c;
+}
+
+int sweep_kernels_prepare(int device)
+{
+    static std::mutex mu;
+    static std::vector<int> done;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int d : done) if (d == device) return DCA_OK;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_update_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 16 * 8));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_update_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 16 * 8));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_update_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 16 * 8));
+    done.push_back(device);
+    return DCA_OK;
+}
+
+int cholinv_sweep(dca_ctx* ctx, double* A, int n, double* work, int* dInfo, SideSet* side)
+{
+    const SweepCfg& cfg = sweep_cfg();
+    DCA_TRY(sweep_kernels_prepare(ctx->device));
+    static const bool traceOn = getenv("DCA_CHOLINV_TRACE") && atoi(getenv("DCA_CHOLINV_TRACE")) != 0;
+    StepTrace tr;
+    tr.on = traceOn;
+    const int ld = n;
+    const int B = n >= cfg.wideMinN ? cfg.wide : cfg.narrow;
+    std::vector<int> b;
+    for (int c = 0; c < n; c += B) b.push_back(c);
+    b.push_back(n);
+    const int np = (int)b.size() - 1;
+    const int nt = (n + 127) / 128;
+    EventPool* pool = event_pool_of(side);
+    hipStream_t chain = ctx->stream, bulk = side->s[0], prio = side->s[1];
+    // events of step p: 0 the inverse of the pivot block is there (chain), 1 the tiles the chain reads next are updated (prio),
+    // 2 the chain has read the pivot panel -- it may be overwritten (chain), 3 the scaled panel W is there (bulk), 4 the next
+    // pivot panel's rows are mirrored into its columns above the diagonal (prio)
+    constexpr int EV = 5;
+    auto ev = [&](int kind, int p) { return pool->get((size_t)EV * p + kind); };
+    if (!ev(EV - 1, np)) { dca_set_error("cholinv: event creation failed"); return DCA_ERR_HIP; }
+    // workspace: W | P[2] | S[2] | Wn | arena of the recursion on a pivot block | tile counters
+    const size_t BB = (size_t)B * B;
+    double* W = work;
+    double* P[2] = {W + (size_t)n * B, W + (size_t)n * B + BB};
+    double* S[2] = {P[1] + BB, P[1] + 2 * BB};
+    double* Wn = S[1] + BB;
+    Arena chainWs{Wn + BB, 2 * BB};
+    int* ctr = reinterpret_cast<int*>(Wn + 3 * BB);                 // [np][2][8]
+    if ((size_t)n * B + 7 * BB + (size_t)np * 8 + 8 > (size_t)2 * n * n) { dca_set_error("cholinv sweep: workspace too small"); return DCA_ERR_NOMEM; }
+    HIP_TRY(hipMemsetAsync(ctr, 0, (size_t)np * 16 * sizeof(int), chain));
+    bool sideInFlight = false;
+    int rc = DCA_OK;
+    auto copy_block = [&](double* dst, int ldd, const double* src, int rows, int cols) {
+        hipLaunchKernelGGL(copy_block_kernel, dim3(std::min(256, (rows * cols / 2 + 255) / 256)), dim3(256), 0, chain, dst, ldd, src, ld, rows, cols);
+    };
+#define SWEEP_HIP(expr) if ((expr) != hipSuccess) { dca_set_error("cholinv sweep: %s failed", #expr); rc = DCA_ERR_HIP; break; }
+    copy_block(S[0], B, A, b[1], b[1]);
+    for (int p = 0; p < np && rc == DCA_OK; ++p) {
+        const int c = b[p], w = b[p + 1] - c;
+        const bool last = p + 1 == np;
+        const int c1 = last ? n : b[p + 1], w1 = last ? 0 : b[p + 2] - c1;
+        const int c2 = c1 + w1, w2 = (last || p + 2 == np) ? 0 : b[p + 3] - c2;
+        double* Sp = S[p & 1];
+        double* Pp = P[p & 1];
+        // ---- chain: X = inv(chol(S)), P = X^T X
+        tr.mark(chain, "chain: pivot block begins", p);
+        if ((rc = cholinv_rec(ctx, Sp, B, w, c, chainWs, dInfo, nullptr)) != DCA_OK) break;
+        if ((rc = launch_gemm(ctx, GemmArgs{Sp, B, MASK_UPPER, Sp, B, MASK_UPPER, Pp, B, Pp, B, w, w, w, 1.0, 0.0, 1})) != DCA_OK) break;
+        tr.mark(chain, "chain: P done", p);
+        SWEEP_HIP(hipEventRecord(ev(0, p), chain));
+        if (!last) {
+            // the next pivot block from this one: S' = M[J', J'] - (M[J', J] P) M[J', J]^T
+            if (p >= 1) SWEEP_HIP(hipStreamWaitEvent(chain, ev(1, p - 1), 0));
+            const double* MnJ = A + (size_t)c1 * ld + c;
+            if ((rc = launch_gemm(ctx, GemmArgs{MnJ, ld, MASK_NONE, Pp, B, MASK_NONE, Wn, B, nullptr, 0, w1, w, w, 1.0, 0.0, 0})) != DCA_OK) break;
+            copy_block(S[(p + 1) & 1], B, A + (size_t)c1 * ld + c1, w1, w1);
+            if ((rc = launch_gemm(ctx, GemmArgs{Wn, B, MASK_NONE, MnJ, ld, MASK_NONE, S[(p + 1) & 1], B, nullptr, 0, w1, w1, w, -1.0, 1.0, 1})) != DCA_OK) break;
+            SWEEP_HIP(hipEventRecord(ev(2, p), chain));
+            tr.mark(chain, "chain: next pivot block formed", p);
+        }
+        // ---- bulk: W, then the tiles outside the next panel
+        SWEEP_HIP(hipStreamWaitEvent(bulk, ev(0, p), 0));
+        if (p >= 1) SWEEP_HIP(hipStreamWaitEvent(bulk, ev(4, p - 1), 0));     // the pivot panel's columns above the diagonal
+        sideInFlight = true;
+        tr.mark(bulk, "bulk: step begins", p);
+        if ((rc = launch_gemm_on(bulk, GemmArgs{A + c, ld, MASK_NONE, Pp, B, MASK_NONE, W, B, nullptr, 0, n, w, w, 1.0, 0.0, 0})) != DCA_OK) break;
+        SWEEP_HIP(hipEventRecord(ev(3, p), bulk));
+        tr.mark(bulk, "bulk: W done", p);
+        SweepArgs g{W, B, A, ld, n, c, w, nt, c / 128, (c1 + w1 + 127) / 128 - c / 128, SWEEP_REST, c1 / 128, (c1 + w1 + 127) / 128 - c1 / 128,
+                    c2 / 128, w2 > 0 ? (c2 + w2 + 127) / 128 - c2 / 128 : 0, 0, nullptr};
+        if (w1 == 0) { g.prN = 0; g.skipN = nt - g.skip0; }
+        const int nR = nt - g.skipN;
+        if (!last) {
+            // ---- prio (its own stream, next to the rest): the next panel's tiles and the diagonal block after it, then the mirror
+            SWEEP_HIP(hipStreamWaitEvent(prio, ev(3, p), 0));
+            tr.mark(prio, "prio: begins", p);
+            SweepArgs gp = g;
+            gp.mode = SWEEP_PRIO;
+            gp.nTiles = g.prN * nR + g.dgN * (g.dgN + 1) / 2;
+            gp.ctr = ctr + (size_t)p * 16 + 8;
+            if (gp.nTiles > 0) sweep_update_launch(prio, std::min(cfg.cap, (gp.nTiles + 7) / 8 * 8), cfg.stages, cfg.perCu, gp);
+            SWEEP_HIP(hipEventRecord(ev(1, p), prio));
+            tr.mark(prio, "prio: tiles done", p);
+            if (c > 0) hipLaunchKernelGGL(mirror_row_panel_kernel, dim3(w1 / 32, c / 32), dim3(256), 0, prio, A, ld, c1, w1, c);
+            SWEEP_HIP(hipEventRecord(ev(4, p), prio));
+        }
+        if (nR > 0) {
+            g.mode = SWEEP_REST;
+            const int bands = (nR + 3) / 4;
+            g.nTiles = 8 * bands * bands + 2 * bands;
+            g.ctr = ctr + (size_t)p * 16;
+            sweep_update_launch(bulk, std::min(cfg.cap, (g.nTiles + 7) / 8 * 8), cfg.stages, cfg.perCu, g);
+            tr.mark(bulk, "bulk: rest done", p);
+        }
+        if (!last) {
+            SWEEP_HIP(hipStreamWaitEvent(bulk, ev(1, p), 0));       // prio reads the pivot panel and W too
+            SWEEP_HIP(hipStreamWaitEvent(bulk, ev(2, p), 0));
+        }
+        hipLaunchKernelGGL(sweep_finalize_kernel, dim3(w / 32, n / 32), dim3(256), 0, bulk, A, ld, c, w, W, B, Pp, B);
+        tr.mark(bulk, "bulk: panel written", p);
+        if (hipGetLastError() != hipSuccess) { dca_set_error("cholinv sweep: launch failed"); rc = DCA_ERR_HIP; }
+    }
+#undef SWEEP_HIP
+    if (rc != DCA_OK) {
+        if (sideInFlight) { hipStreamSynchronize(bulk); hipStreamSynchronize(prio); }   // they write A and read the workspace: drain them before the caller may free either
+        tr.dump();
+        return rc;
+    }
+    // the lower triangle is the result: mirror it (everything the prio stream did was joined into the bulk stream before the last panel was written)
+    const int nb32 = n / 32;
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb32 * (nb32 - 1) / 2), dim3(256), 0, bulk, A, ld, nb32);
+    hipLaunchKernelGGL(symmetrize_diag_kernel, dim3(nb32), dim3(256), 0, bulk, A, ld);
+    if (hipEventRecord(ev(0, np), bulk) != hipSuccess || hipStreamWaitEvent(chain, ev(0, np), 0) != hipSuccess) {
+        hipStreamSynchronize(bulk);
+        dca_set_error("cholinv sweep: join of the bulk stream failed");
+        return DCA_ERR_HIP;
+    }
+    tr.mark(chain, "sweep done", np);
+    tr.dump();
+    return DCA_OK;
+}
+
 }  // namespace
 
 int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* info_out, double scale, double** result)
@@ -1829,17 +2289,30 @@ int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* 
     HIP_TRY(hipMemsetAsync(dInfo, 0, sizeof(int), ctx->stream));
     Arena ws{dWork, (size_t)n * n};
     int rc;
+    bool swept = false;
     {
         ScopedKernelClock kr(ctx, "mf_inverse_recursion");
         // a set of side streams only where the recursion will use one (see cholinv_rec); everything they run is joined
         // into ctx->stream before the recursion returns, so the set can go back as soon as the launches are enqueued
-        SideSet* side = n >= 2048 ? side_set_acquire(ctx->device) : nullptr;
+        const bool wantSweep = n >= sweep_cfg().minN;
+        SideSet* side = (n >= 2048 || wantSweep) ? side_set_acquire(ctx->device) : nullptr;
+        if (wantSweep && side) {
+            // the block sweep (round 6): -inv(A) in place
+            rc = cholinv_sweep(ctx, dA, n, dWork, dInfo, side);
+            swept = true;
+        }
         // the blocked form keeps the factor's panels in the second half of the workspace, which X^T X overwrites at the end
-        if (n >= blocked_cfg().minN && n > 2 * blocked_cfg().W) rc = cholinv_blocked(ctx, dA, n, ws, dWork + (size_t)n * n, dInfo, side);
+        else if (n >= blocked_cfg().minN && n > 2 * blocked_cfg().W) rc = cholinv_blocked(ctx, dA, n, ws, dWork + (size_t)n * n, dInfo, side);
         else rc = cholinv_rec(ctx, dA, n, n, 0, ws, dInfo, side);
         side_set_release(side);
     }
-    if (rc == DCA_OK) {
+    if (rc == DCA_OK && swept) {
+        if (scale != -1.0) {
+            hipLaunchKernelGGL(scale_matrix_kernel, dim3(2048), dim3(256), 0, ctx->stream, dA, (size_t)n * n, -scale);
+            HIP_TRY(hipGetLastError());
+        }
+        *result = dA;
+    } else if (rc == DCA_OK) {
         double* out = dWork + (size_t)n * n;
         // scale * inv(A)[i][j] = scale * sum_{k >= max(i,j)} X[k][i] X[k][j] = scale * sum_k Xt[i][k] Xt[j][k]
         ScopedKernelClock kx(ctx, "mf_inverse_xtx");

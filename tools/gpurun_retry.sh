@@ -1,0 +1,10 @@
+#!/bin/bash
+# usage: tools/gpurun_retry.sh <timeout-seconds> '<command>'   -- retries while the pool is busy (exit code 3)
+T=$1; shift
+for i in $(seq 1 30); do
+  /usr/local/graft/bin/gpurun --timeout "$T" -- "$@"
+  rc=$?
+  if [ $rc -ne 3 ]; then exit $rc; fi
+  sleep 90
+done
+exit 3
