@@ -1213,6 +1213,228 @@ void cholinv_leaf_mfma_kernel(double* __restrict__ M, int ld, int pivotBase, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the leaf in steps of SIXTEEN columns (NB = 64 ... 256).
+// The leaf above advances four columns per step: two workgroup barriers, three LDS round trips and the 4 x 4 diagonal block
+// factored by ONE lane (600 ns) for every four columns -- 1.44 us per step, 46 us per 128 columns, and with 8 x 189 registers
+// it needs a CU of its own.  Here a step is one 16-column tile column T:
+//   1. [D16 = inv(chol(C(T,T))) is in LDS]  L(i,T) = C(i,T) D16^T for the tile rows below (4 MFMAs per tile, operands through
+//      LDS), X(T,j) = D16 B(T,j) for the tiles left of the diagonal (4 MFMAs on the owner's own accumulators -- the
+//      accumulator layout IS the B-operand layout), X(T,T) = D16; X rows go to memory, all of it to the `panel` buffer;
+//   2. the tiles of column T+1 take their rank-16 update first and publish themselves (next diagonal tile, next column);
+//   3. wave 0 factors and inverts the next diagonal tile WHILE the other waves update the remaining tiles.
+// The 16 x 16 diagonal tile is done by one WAVE with one matrix row per lane (registers, v_readlane broadcasts of the pivot
+// row, no LDS, no barrier): Gaussian elimination of [S | I] with the multipliers s_rk / p_k (reciprocal: one seed + one
+// cubic correction, 4 dependent operations) leaves the inverse of the unit factor in the right half, scaled at the end by
+// 1 / sqrt(p_r).  Per column the dependent chain is 7 operations instead of ~11 per column of the one-lane 4 x 4 form.
+// Seven worker waves + the chain wave; NB <= 128 fits in 128 registers per lane (a CU that runs one of the sweep's update
+// workgroups still has room for it), NB = 256 (136 tiles) needs 256.
+__device__ __forceinline__ double lane_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rcp_cubic(double a)
+{
+    // v_rcp_f64 is good to ~2^-23; y (1 + e + e^2), e = 1 - a y, leaves e^3 ~ 2^-69
+    const double y = __builtin_amdgcn_rcp(a);
+    const double e = __builtin_fma(-a, y, 1.0);
+    const double t = __builtin_fma(e, e, e);
+    return __builtin_fma(y, t, y);
+}
+// S: 16 x 16 symmetric tile in LDS (row-major, both halves); D <- inv(chol(S)) (lower, zeros above).  One whole wave.
+// One COLUMN of [S | I] per lane (lanes 0 .. 15 the columns of S, 16 .. 31 those of the right half): eliminating column k
+// is  v[r] -= m_r v[k]  in every lane, with the multipliers m_r = S[r][k] / p_k formed in lane k and broadcast -- 15 - k
+// broadcasts per column serve both halves (one matrix ROW per lane needed 16: the pivot row of both halves).
+__device__ __forceinline__ void factor16(const double* __restrict__ S, double* __restrict__ D, int lane, int* __restrict__ info, int pivot0)
+{
+    const int c = lane & 15;
+    const bool right = (lane & 16) != 0;
+    double v[16], rs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const double sv = S[c * 16 + r];                    // column c = row c
+        v[r] = right ? (r == c ? 1.0 : 0.0) : sv;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double p = lane_bcast(v[k], k);
+        if (!(p > 0.0) && lane == 0) atomicCAS(info, 0, pivot0 + k + 1);
+        const double ik = rcp_cubic(p);
+        rs[k] = lane_bcast(rsqrt_refined(p), 0);            // beside the chain; uniform: kept in scalar registers
+#pragma unroll
+        for (int r = k + 1; r < 16; ++r) {
+            const double m = lane_bcast(v[r] * ik, k);
+            v[r] = __builtin_fma(-m, v[k], v[r]);
+        }
+    }
+    if (lane >= 16 && lane < 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) D[r * 16 + c] = (r >= c) ? rs[r] * v[r] : 0.0;
+    }
+}
+
+#ifndef DCA_LEAF16_ABLATE
+#define DCA_LEAF16_ABLATE 0      // tools/experiments/leaf16_bench.hip, timing only: 1 no diagonal tiles, 2 no panel, 4 no updates, 8 no X stores
+#endif
+template <int NB>
+__device__ __forceinline__ void cholinv_leaf16_body(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info)
+{
+    DCA_CHAIN_PRIO();
+    constexpr int NT = NB / 16;
+    constexpr int NTILES = NT * (NT + 1) / 2;
+    constexpr int WORKERS = 7;
+    constexpr int SLOTS = (NTILES + WORKERS - 1) / WORKERS;
+    constexpr int PS = NB + 2;                        // row stride of the k-major buffers (doubles)
+    extern __shared__ __attribute__((aligned(16))) unsigned char dca_gemm_smem[];
+    double* const colbuf = reinterpret_cast<double*>(dca_gemm_smem);        // [16][PS]: C(i, T) of the tile rows below T, [column][row]
+    double* const panel = colbuf + 16 * PS;                                 // [16][PS]: [m][idx] = X(T, idx)[m] up to the tile, L(idx, T)[m] below
+    double* const diagbuf = panel + 16 * PS;                                // [16][16]: the next diagonal tile
+    double* const dinv = diagbuf + 256;                                     // [16][16]: D16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, lr = lane >> 4;
+
+    if (wave == 0) {
+        // the chain wave: nothing but the diagonal tiles (same barriers as the workers below)
+        __syncthreads();
+        factor16(diagbuf, dinv, lane, info, pivotBase);
+        leaf_step_barrier();
+#pragma unroll 1
+        for (int T = 0; T < NT; ++T) {
+            leaf_step_barrier();
+            if (T + 1 == NT) break;
+            if (!(DCA_LEAF16_ABLATE & 1)) factor16(diagbuf, dinv, lane, info, pivotBase + 16 * (T + 1));
+            leaf_step_barrier();
+        }
+        return;
+    }
+
+    int tI[SLOTS], tJ[SLOTS];
+    double4_t acc[SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int t = wave - 1 + sl * WORKERS;
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        tI[sl] = t < NTILES ? ti : -1;
+        tJ[sl] = t - ti * (ti + 1) / 2;
+        acc[sl] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        if (tI[sl] >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + lr + 4 * r, j = 16 * tJ[sl] + lc;
+                acc[sl][r] = M[(size_t)max(i, j) * ld + min(i, j)];          // diagonal tiles: the full symmetric tile
+            }
+        }
+    }
+    // the tiles of column T1 BELOW the diagonal publish themselves as C(i, T1) and start over as B(i, T1) = 0
+    auto publish_column = [&](int T1) {
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            if (tI[sl] <= T1 || tJ[sl] != T1) continue;                      // wave-uniform (also passes over empty slots: -1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) colbuf[lc * PS + 16 * tI[sl] + lr + 4 * r] = acc[sl][r];
+            acc[sl] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        }
+    };
+    auto publish_diag = [&](int sl) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) diagbuf[(lr + 4 * r) * 16 + lc] = acc[sl][r];
+    };
+    auto update = [&](int sl) {
+        const int i0 = 16 * tI[sl], j0 = 16 * tJ[sl];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double a = -panel[(4 * kk + lr) * PS + i0 + lc];
+            const double b = panel[(4 * kk + lr) * PS + j0 + lc];
+            acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[sl], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // one tile's operands at a time: hoisting every slot's LDS reads costs more registers than a wave has
+    };
+    auto panel_row = [&](int i) {                   // L(i, T) = C(i, T) D16^T -> panel
+        double4_t l = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            l = __builtin_amdgcn_mfma_f64_16x16x4f64(colbuf[(4 * kk + lr) * PS + 16 * i + lc], dinv[lc * 16 + 4 * kk + lr], l, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) panel[lc * PS + 16 * i + lr + 4 * r] = l[r];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // rows 16 T .. 16 T + 15 of X (final: they stand in `panel`) go to memory, lower part and mirror; all worker lanes, no per-tile addresses
+    auto store_x_rows = [&](int T) {
+        if (DCA_LEAF16_ABLATE & 8) return;
+        const int W = 16 * (T + 1);
+#pragma unroll 1
+        for (int e = tid - 64; e < 16 * W; e += 64 * WORKERS) {
+            const int m = e / W, col = e - m * W, row = 16 * T + m;
+            const double x = panel[m * PS + col];
+            if (col <= row) {
+                M[(size_t)row * ld + col] = x;
+                if (col < row) M[(size_t)col * ld + row] = x;
+            }
+        }
+    };
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl)
+        if (tI[sl] == 0) publish_diag(sl);
+    publish_column(0);
+    __syncthreads();
+    leaf_step_barrier();
+
+#pragma unroll 1
+    for (int T = 0; T < NT; ++T) {
+        // ---- A. the panel of the step.  The owner of the NEXT diagonal tile makes that tile's row of the panel itself, updates the
+        // tile and publishes it: the chain wave waits for nothing else
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            if (tI[sl] != T + 1 || tJ[sl] != T + 1) continue;
+            if (!(DCA_LEAF16_ABLATE & 2)) panel_row(T + 1);
+            update(sl);                                                      // reads what this wave has just written (LDS keeps a wave's order)
+            publish_diag(sl);
+        }
+#pragma unroll 1
+        for (int i = T + 1 + wave; i < NT && !(DCA_LEAF16_ABLATE & 2); i += WORKERS) panel_row(i);
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            if (tI[sl] != T) continue;
+            double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0};
+            if (tJ[sl] < T) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[lc * 16 + lr + 4 * r], acc[sl][r], x, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = dinv[(lr + 4 * r) * 16 + lc];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) panel[(lr + 4 * r) * PS + 16 * tJ[sl] + lc] = x[r];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        leaf_step_barrier();
+        if (T + 1 == NT) break;
+        // ---- B. everybody's updates, column T + 1 first (wave 0 factors the next diagonal tile meanwhile)
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl)
+            if (tI[sl] > T + 1 && tJ[sl] == T + 1) update(sl);
+        publish_column(T + 1);
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl)
+            if (tI[sl] > T && tJ[sl] != T + 1 && !(DCA_LEAF16_ABLATE & 4)) update(sl);      // (T + 1, T + 1) is in column T + 1: done in A
+        store_x_rows(T);
+        leaf_step_barrier();
+    }
+    store_x_rows(NT - 1);
+}
+// 144 registers: two of its waves per SIMD next to one wave of an update workgroup (224)
+template <int NB>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(144)))
+void cholinv_leaf16_small_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info) { cholinv_leaf16_body<NB>(M, ld, pivotBase, info); }
+template <int NB>
+__global__ __launch_bounds__(512)
+void cholinv_leaf16_kernel(double* __restrict__ M, int ld, int pivotBase, int* __restrict__ info) { cholinv_leaf16_body<NB>(M, ld, pivotBase, info); }
+template <int NB> constexpr size_t leaf16_lds_bytes() { return (size_t)(2 * 16 * (NB + 2) + 512) * sizeof(double); }
+
 constexpr size_t kLeafLds = 0;
 
 struct Arena {
@@ -1236,6 +1458,7 @@ int gemm_kernels_prepare(int device)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, small));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_small_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, small));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f64_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<64>()));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cholinv_leaf16_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)leaf16_lds_bytes<256>()));
     done.push_back(device);
     return DCA_OK;
 }
@@ -1258,10 +1481,14 @@ int launch_gemm_banded(dca_ctx* ctx, hipStream_t stream, GemmArgs g, int maxWGs)
     return DCA_OK;
 }
 
+// The block sweep's chain runs NEXT TO its update launches: there the few-tile products do better as fewer, larger workgroups
+// (n = 10 048: 21.4 -> 20.6 ms with both bounds at 16), so the sweep lowers the two bounds for the launches it makes
+thread_local int tl_small32_max = -1, tl_deep_max_tiles = -1;
 static int small32_max()
 {
     static const int v = getenv("DCA_GEMM_SMALL32_MAX") ? atoi(getenv("DCA_GEMM_SMALL32_MAX")) : 400;     // 0: the 64 x 64 deep kernel
-    return v;
+    static const bool fixed = getenv("DCA_GEMM_SMALL32_MAX") != nullptr;
+    return (!fixed && tl_small32_max >= 0) ? tl_small32_max : v;
 }
 static dim3 grid64(const GemmArgs& g) { return g.walk == WALK_COLUMNS_REVERSED ? dim3(g.M / BM, g.N / BN) : dim3(g.N / BN, g.M / BM); }
 
@@ -1281,7 +1508,9 @@ int launch_gemm_on(hipStream_t stream, const GemmArgs& g)
 {
     dim3 grid(g.N / BN, g.M / BM);
     if (g.walk == WALK_COLUMNS_REVERSED) grid = dim3(g.M / BM, g.N / BN);
-    static const int deepMaxTiles = getenv("DCA_GEMM_DEEP_MAX_TILES") ? atoi(getenv("DCA_GEMM_DEEP_MAX_TILES")) : 400;
+    static const int deepMaxTilesEnv = getenv("DCA_GEMM_DEEP_MAX_TILES") ? atoi(getenv("DCA_GEMM_DEEP_MAX_TILES")) : 400;
+    static const bool deepFixed = getenv("DCA_GEMM_DEEP_MAX_TILES") != nullptr;
+    const int deepMaxTiles = (!deepFixed && tl_deep_max_tiles >= 0) ? tl_deep_max_tiles : deepMaxTilesEnv;
     const int small32Max = small32_max();
     // inverse at n = 10 048 / 4000 by this bound: 0 -> 27.1 / 4.96 ms, 16 -> 25.8 / 4.36, 128 -> 24.7 / 4.08, 400 -> 24.2 / 3.95, 1200 -> 23.9 / 4.01, 1600 -> 24.8 / 3.99
     if ((long long)grid.x * grid.y <= small32Max) {          // far fewer tiles than CUs: 32 x 32 tiles on four times as many CUs
@@ -1338,6 +1567,8 @@ constexpr int kSideDepths = DCA_SIDE_DEPTHS;
 // made once per process and device and lent to one inverse at a time (contexts of several host threads get a set each).
 struct SideSet {
     hipStream_t s[kSideDepths] = {};
+    hipStream_t masked[2] = {};       // round 6 (block sweep): two streams that may use only `maskedCus` of the CUs (the rest stay the chain's)
+    int maskedCus = 0;
     hipEvent_t fork[kSideDepths] = {}, join[kSideDepths] = {}, mid[kSideDepths] = {};
     int device = -1;
     bool busy = false;
@@ -1366,6 +1597,21 @@ SideSet* side_set_acquire(int device)
     g_sideSets.push_back(S);
     return S;
 }
+// the set's two CU-masked streams, made the first time a sweep asks for them (`cus` CUs, striped over the XCDs: bit i of the
+// mask is a CU of XCD i % 8, tools/experiments/cumask_probe.hip); false: no such streams, the caller uses the plain ones
+bool side_set_masked(SideSet* S, int cus)
+{
+    if (S->maskedCus == cus && S->masked[0] && S->masked[1]) return true;
+    for (hipStream_t& m : S->masked) if (m) { hipStreamDestroy(m); m = nullptr; }
+    S->maskedCus = 0;
+    uint32_t mask[8] = {};
+    for (int i = 0; i < cus && i < 256; ++i) mask[i / 32] |= 1u << (i % 32);
+    for (hipStream_t& m : S->masked)
+        if (hipExtStreamCreateWithCUMask(&m, 8, mask) != hipSuccess) { m = nullptr; (void)hipGetLastError(); return false; }
+    S->maskedCus = cus;
+    return true;
+}
+
 void side_set_release(SideSet* S)
 {
     if (!S) return;
@@ -1375,10 +1621,21 @@ void side_set_release(SideSet* S)
 
 // pending: an event on a side stream after which the blocks (2,1) and (2,2) of M have received their update from the
 // PARENT's panel (see the deferred SYRK below); the main stream waits for it only when it first touches those blocks.
-int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws, int* dInfo, SideSet* side, int depth = 0, hipEvent_t pending = nullptr)
+int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws, int* dInfo, SideSet* side, int depth = 0, hipEvent_t pending = nullptr, int leafMaxOverride = 0)
 {
     static const bool leaf128 = !(getenv("DCA_CHOLINV_LEAF128") && atoi(getenv("DCA_CHOLINV_LEAF128")) == 0);
     static const bool leafMfma = !(getenv("DCA_CHOLINV_LEAF_MFMA") && atoi(getenv("DCA_CHOLINV_LEAF_MFMA")) == 0);
+    static const int leaf16Max = getenv("DCA_CHOLINV_LEAF16") ? atoi(getenv("DCA_CHOLINV_LEAF16")) : 128;      // 0: the four-column leaves
+    const int l16 = leafMaxOverride > 0 ? leafMaxOverride : leaf16Max;
+    if (n <= l16 && leaf16Max > 0) {
+        switch (n) {
+        case 64: hipLaunchKernelGGL(cholinv_leaf16_small_kernel<64>, dim3(1), dim3(512), leaf16_lds_bytes<64>(), ctx->stream, M, ld, pivotBase, dInfo); return DCA_OK;
+        case 128: hipLaunchKernelGGL(cholinv_leaf16_small_kernel<128>, dim3(1), dim3(512), leaf16_lds_bytes<128>(), ctx->stream, M, ld, pivotBase, dInfo); return DCA_OK;
+        case 192: hipLaunchKernelGGL(cholinv_leaf16_kernel<192>, dim3(1), dim3(512), leaf16_lds_bytes<192>(), ctx->stream, M, ld, pivotBase, dInfo); return DCA_OK;
+        case 256: hipLaunchKernelGGL(cholinv_leaf16_kernel<256>, dim3(1), dim3(512), leaf16_lds_bytes<256>(), ctx->stream, M, ld, pivotBase, dInfo); return DCA_OK;
+        default: break;
+        }
+    }
     if (n == 64) {
         if (leafMfma) hipLaunchKernelGGL(cholinv_leaf_mfma_kernel<64>, dim3(1), dim3(320), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
         else hipLaunchKernelGGL(cholinv_leaf_kernel<64>, dim3(1), dim3(256), kLeafLds, ctx->stream, M, ld, pivotBase, dInfo);
@@ -1396,7 +1653,7 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
     double* M12 = M + n1;
     double* M21 = M + (size_t)n1 * ld;
     double* M22 = M + (size_t)n1 * ld + n1;
-    DCA_TRY(cholinv_rec(ctx, M11, ld, n1, pivotBase, ws, dInfo, side, depth + 1));
+    DCA_TRY(cholinv_rec(ctx, M11, ld, n1, pivotBase, ws, dInfo, side, depth + 1, nullptr, leafMaxOverride));
     if (pending) HIP_TRY(hipStreamWaitEvent(ctx->stream, pending, 0));        // M21 and M22 are read / updated from here on
     const size_t mark = ws.top;
     double* L21 = ws.alloc((size_t)n2 * n1);
@@ -1472,7 +1729,7 @@ int cholinv_rec(dca_ctx* ctx, double* M, int ld, int n, int pivotBase, Arena& ws
         if ((rc = launch_gemm(ctx, deferred ? q00 : syrkArgs)) != DCA_OK) return bail(rc);
     }
     if (useSide && !forkBeforeSyrk && (rc = fork_side()) != DCA_OK) return bail(rc);
-    if ((rc = cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo, side, depth + 1, deferred ? side->mid[depth] : nullptr)) != DCA_OK) return bail(rc);
+    if ((rc = cholinv_rec(ctx, M22, ld, n2, pivotBase + n1, ws, dInfo, side, depth + 1, deferred ? side->mid[depth] : nullptr, leafMaxOverride)) != DCA_OK) return bail(rc);
     if (onSide) {
         if (hipStreamWaitEvent(ctx->stream, side->join[depth], 0) != hipSuccess) { dca_set_error("cholinv: join of the side stream failed"); return bail(DCA_ERR_HIP); }
     } else if (!paired) DCA_TRY(launch_gemm(ctx, ttArgs));
@@ -1844,7 +2101,8 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
 enum { SWEEP_REST = 0, SWEEP_PRIO = 1 };
 struct SweepArgs {
     const double* W; int ldw;      // n x w: the scaled panel
-    double* M; int ld;             // n x n, symmetric, both halves
+    const double* Q; int ldq;      // n x w: the pivot panel's columns as they were before the step (compact copy, all rows)
+    double* M; int ld;             // n x n: the lower triangle is kept up to date
     int n, c, w;                   // pivot columns [c, c + w)
     int nt;                        // tile rows of M (128 rows each, the last one may be short)
     int skip0, skipN;              // tile rows left out: the pivot panel and the panel after it
@@ -1958,7 +2216,7 @@ void sweep_update_kernel(SweepArgs g)
             const int R = 8 * (PW * wave + i) + (lane >> 3);
             const int piece = (lane & 7) ^ ((R >> 1) & 7);
             srcA[i] = g.W + (size_t)min(ti * BM + R, g.n - 1) * g.ldw + 2 * piece;
-            srcB[i] = g.M + (size_t)min(tj * BN + R, g.n - 1) * g.ld + g.c + 2 * piece;
+            srcB[i] = g.Q + (size_t)min(tj * BN + R, g.n - 1) * g.ldq + 2 * piece;
         }
         auto issue = [&](int st, int k0) {
 #pragma unroll
@@ -2026,14 +2284,20 @@ void sweep_update_kernel(SweepArgs g)
     }
 }
 
-// M[:, c .. c + w) <- W and M[c .. c + w, :) <- W^T outside the pivot block, the pivot block itself <- -P (32 x 32 pieces)
+// The swept panel in the lower triangle: M[i][c .. c + w) <- W[i] for the rows below the pivot block, M[c .. c + w)[j] <- W[j]^T
+// for the columns left of it, the pivot block itself <- -P (32 x 32 pieces)
 __global__ __launch_bounds__(256)
 void sweep_finalize_kernel(double* __restrict__ M, int ld, int c, int w, const double* __restrict__ W, int ldw, const double* __restrict__ P, int ldp)
 {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int k0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    if (r0 >= c && r0 < c + w) {
+    if (r0 >= c + w) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) M[(size_t)(r0 + ty + 8 * s) * ld + c + k0 + tx] = W[(size_t)(r0 + ty + 8 * s) * ldw + k0 + tx];
+        return;
+    }
+    if (r0 >= c) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int r = r0 + ty + 8 * s;
@@ -2042,31 +2306,31 @@ void sweep_finalize_kernel(double* __restrict__ M, int ld, int c, int w, const d
         return;
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int r = r0 + ty + 8 * s;
-        const double v = W[(size_t)r * ldw + k0 + tx];
-        M[(size_t)r * ld + c + k0 + tx] = v;
-        tile[ty + 8 * s][tx] = v;
-    }
+    for (int s = 0; s < 4; ++s) tile[ty + 8 * s][tx] = W[(size_t)(r0 + ty + 8 * s) * ldw + k0 + tx];
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 4; ++s) M[(size_t)(c + k0 + ty + 8 * s) * ld + r0 + tx] = tile[tx][ty + 8 * s];
 }
 
-// dst[j][c + k] = src[c + k][j] for the rows [c, c + w) and the columns j < cols: the part of a column panel that lies ABOVE
-// the diagonal, from the row panel left of it (the sweep keeps the lower triangle up to date; the operand loads of a
-// step read whole columns of the pivot panel)
+// Q[i][k] = M[i][c + k] as the symmetric matrix has it, read from the LOWER triangle only: rows below the panel's diagonal
+// block as they stand, rows above it from the row panel left of the block (transposed through LDS).  The rows of the block
+// itself are copied as they stand (nothing reads them).
 __global__ __launch_bounds__(256)
-void mirror_row_panel_kernel(double* __restrict__ M, int ld, int c, int w, int cols)
+void gather_panel_kernel(const double* __restrict__ M, int ld, int c, int w, double* __restrict__ Q, int ldq)
 {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int k0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int k0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    if (r0 >= c) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) tile[ty + 8 * s][tx] = M[(size_t)(c + k0 + ty + 8 * s) * ld + j0 + tx];
+        for (int s = 0; s < 4; ++s) Q[(size_t)(r0 + ty + 8 * s) * ldq + k0 + tx] = M[(size_t)(r0 + ty + 8 * s) * ld + c + k0 + tx];
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) tile[ty + 8 * s][tx] = M[(size_t)(c + k0 + ty + 8 * s) * ld + r0 + tx];
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 4; ++s) M[(size_t)(j0 + ty + 8 * s) * ld + c + k0 + tx] = tile[tx][ty + 8 * s];
+    for (int s = 0; s < 4; ++s) Q[(size_t)(r0 + ty + 8 * s) * ldq + k0 + tx] = tile[tx][ty + 8 * s];
 }
 
 // upper triangle <- transposed lower triangle, 32 x 32 pieces (the sweep's last pass: the result is bit-symmetric)
@@ -2115,7 +2379,7 @@ void scale_matrix_kernel(double* __restrict__ M, size_t count, double f)
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) M[e] *= f;
 }
 
-struct SweepCfg { int minN, wide, narrow, wideMinN, cap, stages, perCu; };
+struct SweepCfg { int minN, wide, narrow, wideMinN, cap, stages, perCu, maskCus, prioCap; };
 void sweep_update_launch(hipStream_t stream, int G, int stages, int perCu, const SweepArgs& g)
 {
     // dynamic LDS: what the stages need; with perCu == 1 never less than 96 KB, so that a CU takes ONE of these workgroups
@@ -2128,13 +2392,15 @@ void sweep_update_launch(hipStream_t stream, int G, int stages, int perCu, const
 static const SweepCfg& sweep_cfg()
 {
     static const SweepCfg c = [] {
-        SweepCfg v{1024, 512, 256, 6000, 496, 2, 2};
+        SweepCfg v{2560, 512, 256, 7000, 0, 2, 2, 0, 64};      // measured (ms, sweep / three-phase): n = 2048 1.43 / 1.30, 3072 2.16 / 2.31, 4032 3.41 / 3.55, 6016 6.46 / 7.54, 8000 12.25 / 13.25, 10 048 20.6 / 22.4, 12 032 34.0 / 34.9
+        if (const char* e = getenv("DCA_SWEEP_PRIO_CAP")) v.prioCap = std::max(8, atoi(e) / 8 * 8);
         if (const char* e = getenv("DCA_SWEEP_MIN")) v.minN = atoi(e);
         if (const char* e = getenv("DCA_SWEEP")) if (atoi(e) == 0) v.minN = INT_MAX;
         if (const char* e = getenv("DCA_SWEEP_PANEL")) v.wide = v.narrow = std::max(128, atoi(e) / 128 * 128);
         if (const char* e = getenv("DCA_SWEEP_CAP")) v.cap = std::max(8, atoi(e) / 8 * 8);
         if (const char* e = getenv("DCA_SWEEP_STAGES")) v.stages = std::max(2, std::min(4, atoi(e)));
         if (const char* e = getenv("DCA_SWEEP_PER_CU")) v.perCu = atoi(e);
+        if (const char* e = getenv("DCA_SWEEP_MASK")) v.maskCus = std::max(0, std::min(256, atoi(e) / 8 * 8));      // 0: plain streams
         return v;
     }();
     return c;
@@ -2157,6 +2423,7 @@ int cholinv_sweep(dca_ctx* ctx, double* A, int n, double* work, int* dInfo, Side
 {
     const SweepCfg& cfg = sweep_cfg();
     DCA_TRY(sweep_kernels_prepare(ctx->device));
+    struct Bounds { Bounds(int n) { if (n >= 6000) { tl_small32_max = 16; tl_deep_max_tiles = 16; } } ~Bounds() { tl_small32_max = -1; tl_deep_max_tiles = -1; } } bounds(n);
     static const bool traceOn = getenv("DCA_CHOLINV_TRACE") && atoi(getenv("DCA_CHOLINV_TRACE")) != 0;
     StepTrace tr;
     tr.on = traceOn;
@@ -2168,22 +2435,31 @@ int cholinv_sweep(dca_ctx* ctx, double* A, int n, double* work, int* dInfo, Side
     const int np = (int)b.size() - 1;
     const int nt = (n + 127) / 128;
     EventPool* pool = event_pool_of(side);
-    hipStream_t chain = ctx->stream, bulk = side->s[0], prio = side->s[1];
-    // events of step p: 0 the inverse of the pivot block is there (chain), 1 the tiles the chain reads next are updated (prio),
-    // 2 the chain has read the pivot panel -- it may be overwritten (chain), 3 the scaled panel W is there (bulk), 4 the next
-    // pivot panel's rows are mirrored into its columns above the diagonal (prio)
+    // Three streams.  chain (the context's): pivot blocks.  rest: the bulk of every step's update, one persistent launch after the
+    // other.  side: everything else of a step -- W, the swept panel, the tiles the next steps' pivots need (prio), the next
+    // panel's copy -- next to the rest launch of the step before or of its own.
+    static const int restIdx = getenv("DCA_SWEEP_REST_STREAM") ? atoi(getenv("DCA_SWEEP_REST_STREAM")) % kSideDepths : 0;
+    static const int sideIdx = getenv("DCA_SWEEP_SIDE_STREAM") ? atoi(getenv("DCA_SWEEP_SIDE_STREAM")) % kSideDepths : 1;
+    hipStream_t chain = ctx->stream, rest = side->s[restIdx], sd = side->s[sideIdx];
+    int bulkCus = 256;
+    if (cfg.maskCus > 0 && cfg.maskCus < 256 && side_set_masked(side, cfg.maskCus)) { rest = side->masked[0]; sd = side->masked[1]; bulkCus = cfg.maskCus; }
+    const int capAll = std::max(1, cfg.perCu) * bulkCus;
+    const int capRest = cfg.cap > 0 ? cfg.cap : capAll * 3 / 4 / 8 * 8;           // the rest launch leaves room for the side stream's and the chain's kernels
+    // events of step p: 0 P is there (chain), 1 prio tiles done (side), 2 the chain has read the pivot panel in M (chain), 3 W is there
+    // (side), 4 rest done (rest)
     constexpr int EV = 5;
     auto ev = [&](int kind, int p) { return pool->get((size_t)EV * p + kind); };
     if (!ev(EV - 1, np)) { dca_set_error("cholinv: event creation failed"); return DCA_ERR_HIP; }
-    // workspace: W | P[2] | S[2] | Wn | arena of the recursion on a pivot block | tile counters
-    const size_t BB = (size_t)B * B;
-    double* W = work;
-    double* P[2] = {W + (size_t)n * B, W + (size_t)n * B + BB};
+    // workspace: W[2] | Q[2] | P[2] | S[2] | Wn | arena of the recursion on a pivot block | tile counters
+    const size_t BB = (size_t)B * B, NB_ = (size_t)n * B;
+    double* W[2] = {work, work + NB_};
+    double* Q[2] = {work + 2 * NB_, work + 3 * NB_};
+    double* P[2] = {work + 4 * NB_, work + 4 * NB_ + BB};
     double* S[2] = {P[1] + BB, P[1] + 2 * BB};
     double* Wn = S[1] + BB;
     Arena chainWs{Wn + BB, 2 * BB};
     int* ctr = reinterpret_cast<int*>(Wn + 3 * BB);                 // [np][2][8]
-    if ((size_t)n * B + 7 * BB + (size_t)np * 8 + 8 > (size_t)2 * n * n) { dca_set_error("cholinv sweep: workspace too small"); return DCA_ERR_NOMEM; }
+    if (4 * NB_ + 7 * BB + (size_t)np * 8 + 8 > (size_t)2 * n * n) { dca_set_error("cholinv sweep: workspace too small"); return DCA_ERR_NOMEM; }
     HIP_TRY(hipMemsetAsync(ctr, 0, (size_t)np * 16 * sizeof(int), chain));
     bool sideInFlight = false;
     int rc = DCA_OK;
@@ -2192,6 +2468,9 @@ int cholinv_sweep(dca_ctx* ctx, double* A, int n, double* work, int* dInfo, Side
     };
 #define SWEEP_HIP(expr) if ((expr) != hipSuccess) { dca_set_error("cholinv sweep: %s failed", #expr); rc = DCA_ERR_HIP; break; }
     copy_block(S[0], B, A, b[1], b[1]);
+    if (hipEventRecord(ev(0, np), chain) != hipSuccess || hipStreamWaitEvent(sd, ev(0, np), 0) != hipSuccess) { dca_set_error("cholinv sweep: fork failed"); return DCA_ERR_HIP; }
+    hipLaunchKernelGGL(gather_panel_kernel, dim3(b[1] / 32, n / 32), dim3(256), 0, sd, A, ld, 0, b[1], Q[0], B);
+    sideInFlight = true;
     for (int p = 0; p < np && rc == DCA_OK; ++p) {
         const int c = b[p], w = b[p + 1] - c;
         const bool last = p + 1 == np;
@@ -2199,6 +2478,8 @@ int cholinv_sweep(dca_ctx* ctx, double* A, int n, double* work, int* dInfo, Side
         const int c2 = c1 + w1, w2 = (last || p + 2 == np) ? 0 : b[p + 3] - c2;
         double* Sp = S[p & 1];
         double* Pp = P[p & 1];
+        double* Wp = W[p & 1];
+        double* Qp = Q[p & 1];
         // ---- chain: X = inv(chol(S)), P = X^T X
         tr.mark(chain, "chain: pivot block begins", p);
         if ((rc = cholinv_rec(ctx, Sp, B, w, c, chainWs, dInfo, nullptr)) != DCA_OK) break;
@@ -2215,61 +2496,64 @@ int cholinv_sweep(dca_ctx* ctx, double* A, int n, double* work, int* dInfo, Side
             SWEEP_HIP(hipEventRecord(ev(2, p), chain));
             tr.mark(chain, "chain: next pivot block formed", p);
         }
-        // ---- bulk: W, then the tiles outside the next panel
-        SWEEP_HIP(hipStreamWaitEvent(bulk, ev(0, p), 0));
-        if (p >= 1) SWEEP_HIP(hipStreamWaitEvent(bulk, ev(4, p - 1), 0));     // the pivot panel's columns above the diagonal
-        sideInFlight = true;
-        tr.mark(bulk, "bulk: step begins", p);
-        if ((rc = launch_gemm_on(bulk, GemmArgs{A + c, ld, MASK_NONE, Pp, B, MASK_NONE, W, B, nullptr, 0, n, w, w, 1.0, 0.0, 0})) != DCA_OK) break;
-        SWEEP_HIP(hipEventRecord(ev(3, p), bulk));
-        tr.mark(bulk, "bulk: W done", p);
-        SweepArgs g{W, B, A, ld, n, c, w, nt, c / 128, (c1 + w1 + 127) / 128 - c / 128, SWEEP_REST, c1 / 128, (c1 + w1 + 127) / 128 - c1 / 128,
+        // ---- side: W = Q P (Q: this panel's copy, made at the end of the side stream's previous step), then the swept panel
+        SWEEP_HIP(hipStreamWaitEvent(sd, ev(0, p), 0));
+        tr.mark(sd, "side: step begins", p);
+        if ((rc = launch_gemm_on(sd, GemmArgs{Qp, B, MASK_NONE, Pp, B, MASK_NONE, Wp, B, nullptr, 0, n, w, w, 1.0, 0.0, 0})) != DCA_OK) break;
+        SWEEP_HIP(hipEventRecord(ev(3, p), sd));
+        tr.mark(sd, "side: W done", p);
+        if (!last) SWEEP_HIP(hipStreamWaitEvent(sd, ev(2, p), 0));
+        hipLaunchKernelGGL(sweep_finalize_kernel, dim3(w / 32, n / 32), dim3(256), 0, sd, A, ld, c, w, Wp, B, Pp, B);
+        SweepArgs g{Wp, B, Qp, B, A, ld, n, c, w, nt, c / 128, (c1 + w1 + 127) / 128 - c / 128, SWEEP_REST, c1 / 128, (c1 + w1 + 127) / 128 - c1 / 128,
                     c2 / 128, w2 > 0 ? (c2 + w2 + 127) / 128 - c2 / 128 : 0, 0, nullptr};
         if (w1 == 0) { g.prN = 0; g.skipN = nt - g.skip0; }
         const int nR = nt - g.skipN;
         if (!last) {
-            // ---- prio (its own stream, next to the rest): the next panel's tiles and the diagonal block after it, then the mirror
-            SWEEP_HIP(hipStreamWaitEvent(prio, ev(3, p), 0));
-            tr.mark(prio, "prio: begins", p);
+            // ---- side: the next panel's tiles and the diagonal block after it (they were tiles of the rest launch one step ago), then the
+            // next panel's copy
+            if (p >= 1) SWEEP_HIP(hipStreamWaitEvent(sd, ev(4, p - 1), 0));
+            tr.mark(sd, "side: prio begins", p);
             SweepArgs gp = g;
             gp.mode = SWEEP_PRIO;
             gp.nTiles = g.prN * nR + g.dgN * (g.dgN + 1) / 2;
             gp.ctr = ctr + (size_t)p * 16 + 8;
-            if (gp.nTiles > 0) sweep_update_launch(prio, std::min(cfg.cap, (gp.nTiles + 7) / 8 * 8), cfg.stages, cfg.perCu, gp);
-            SWEEP_HIP(hipEventRecord(ev(1, p), prio));
-            tr.mark(prio, "prio: tiles done", p);
-            if (c > 0) hipLaunchKernelGGL(mirror_row_panel_kernel, dim3(w1 / 32, c / 32), dim3(256), 0, prio, A, ld, c1, w1, c);
-            SWEEP_HIP(hipEventRecord(ev(4, p), prio));
+            if (gp.nTiles > 0) sweep_update_launch(sd, std::min(cfg.prioCap, (gp.nTiles + 7) / 8 * 8), cfg.stages, cfg.perCu, gp);
+            SWEEP_HIP(hipEventRecord(ev(1, p), sd));
+            tr.mark(sd, "side: prio done", p);
+            hipLaunchKernelGGL(gather_panel_kernel, dim3(w1 / 32, n / 32), dim3(256), 0, sd, A, ld, c1, w1, Q[(p + 1) & 1], B);
         }
+        // ---- rest
         if (nR > 0) {
+            SWEEP_HIP(hipStreamWaitEvent(rest, ev(3, p), 0));
             g.mode = SWEEP_REST;
             const int bands = (nR + 3) / 4;
             g.nTiles = 8 * bands * bands + 2 * bands;
             g.ctr = ctr + (size_t)p * 16;
-            sweep_update_launch(bulk, std::min(cfg.cap, (g.nTiles + 7) / 8 * 8), cfg.stages, cfg.perCu, g);
-            tr.mark(bulk, "bulk: rest done", p);
+            tr.mark(rest, "rest: begins", p);
+            sweep_update_launch(rest, std::min(last ? capAll : capRest, (g.nTiles + 7) / 8 * 8), cfg.stages, cfg.perCu, g);
+            tr.mark(rest, "rest: done", p);
         }
-        if (!last) {
-            SWEEP_HIP(hipStreamWaitEvent(bulk, ev(1, p), 0));       // prio reads the pivot panel and W too
-            SWEEP_HIP(hipStreamWaitEvent(bulk, ev(2, p), 0));
-        }
-        hipLaunchKernelGGL(sweep_finalize_kernel, dim3(w / 32, n / 32), dim3(256), 0, bulk, A, ld, c, w, W, B, Pp, B);
-        tr.mark(bulk, "bulk: panel written", p);
+        SWEEP_HIP(hipEventRecord(ev(4, p), rest));
         if (hipGetLastError() != hipSuccess) { dca_set_error("cholinv sweep: launch failed"); rc = DCA_ERR_HIP; }
     }
 #undef SWEEP_HIP
     if (rc != DCA_OK) {
-        if (sideInFlight) { hipStreamSynchronize(bulk); hipStreamSynchronize(prio); }   // they write A and read the workspace: drain them before the caller may free either
+        if (sideInFlight) { hipStreamSynchronize(rest); hipStreamSynchronize(sd); }   // they write A and read the workspace: drain them before the caller may free either
         tr.dump();
         return rc;
     }
-    // the lower triangle is the result: mirror it (everything the prio stream did was joined into the bulk stream before the last panel was written)
+    // the lower triangle is the result: mirror it, once the last panel is written (side) and the last tiles are (rest)
     const int nb32 = n / 32;
-    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb32 * (nb32 - 1) / 2), dim3(256), 0, bulk, A, ld, nb32);
-    hipLaunchKernelGGL(symmetrize_diag_kernel, dim3(nb32), dim3(256), 0, bulk, A, ld);
-    if (hipEventRecord(ev(0, np), bulk) != hipSuccess || hipStreamWaitEvent(chain, ev(0, np), 0) != hipSuccess) {
-        hipStreamSynchronize(bulk);
-        dca_set_error("cholinv sweep: join of the bulk stream failed");
+    if (hipEventRecord(ev(1, np), sd) != hipSuccess || hipStreamWaitEvent(rest, ev(1, np), 0) != hipSuccess) {
+        hipStreamSynchronize(rest); hipStreamSynchronize(sd);
+        dca_set_error("cholinv sweep: join of the side stream failed");
+        return DCA_ERR_HIP;
+    }
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb32 * (nb32 - 1) / 2), dim3(256), 0, rest, A, ld, nb32);
+    hipLaunchKernelGGL(symmetrize_diag_kernel, dim3(nb32), dim3(256), 0, rest, A, ld);
+    if (hipEventRecord(ev(2, np), rest) != hipSuccess || hipStreamWaitEvent(chain, ev(2, np), 0) != hipSuccess) {
+        hipStreamSynchronize(rest);
+        dca_set_error("cholinv sweep: join of the rest stream failed");
         return DCA_ERR_HIP;
     }
     tr.mark(chain, "sweep done", np);
@@ -2294,7 +2578,9 @@ int dca_spd_inverse_device(dca_ctx* ctx, double* dA, int n, double* dWork, int* 
         ScopedKernelClock kr(ctx, "mf_inverse_recursion");
         // a set of side streams only where the recursion will use one (see cholinv_rec); everything they run is joined
         // into ctx->stream before the recursion returns, so the set can go back as soon as the launches are enqueued
-        const bool wantSweep = n >= sweep_cfg().minN;
+        const int sweepB = n >= sweep_cfg().wideMinN ? sweep_cfg().wide : sweep_cfg().narrow;
+        const bool wantSweep = n >= sweep_cfg().minN && n >= 2 * sweepB &&
+                               (size_t)4 * n * sweepB + (size_t)7 * sweepB * sweepB + (size_t)(n / sweepB + 2) * 8 + 8 <= (size_t)2 * n * n;
         SideSet* side = (n >= 2048 || wantSweep) ? side_set_acquire(ctx->device) : nullptr;
         if (wantSweep && side) {
             // the block sweep (round 6): -inv(A) in place

@@ -33,7 +33,7 @@ int main(int argc, char** argv)
     const int c = (nt / 2) * 128 / w * w;                   // a middle panel
     const int c1 = c + w, w1 = w, c2 = c1 + w1, w2 = w;
     int* ctr; hipMalloc(&ctr, 64);
-    SweepArgs g{W, w, M, n, n, c, w, nt, c / 128, (c1 + w1) / 128 - c / 128, SWEEP_REST, c1 / 128, w1 / 128, c2 / 128, w2 / 128, 0, ctr};
+    SweepArgs g{W, w, M + c, n, M, n, n, c, w, nt, c / 128, (c1 + w1) / 128 - c / 128, SWEEP_REST, c1 / 128, w1 / 128, c2 / 128, w2 / 128, 0, ctr};
     const int nR = nt - g.skipN;
     for (int mode = 0; mode < 2; ++mode) {
         g.mode = mode == 0 ? SWEEP_REST : SWEEP_PRIO;
