@@ -367,11 +367,13 @@ def test_lbfgs_float32_default_path_scores_close(L_, oracle_plm, oracle_mf):
     ctx.close()
 
 
-@pytest.mark.parametrize("env", [{"DCA_CHOLINV_LEAF_MFMA": "0"}, {"DCA_CHOLINV_LEAF_MFMA": "0", "DCA_CHOLINV_LEAF128": "0"},
-                                 {"DCA_CHOLINV_LEAF128": "0"}])
+@pytest.mark.parametrize("env", [{"DCA_CHOLINV_LEAF16": "0"}, {"DCA_CHOLINV_LEAF16": "0", "DCA_CHOLINV_LEAF_MFMA": "0"},
+                                 {"DCA_CHOLINV_LEAF16": "0", "DCA_CHOLINV_LEAF_MFMA": "0", "DCA_CHOLINV_LEAF128": "0"},
+                                 {"DCA_CHOLINV_LEAF16": "0", "DCA_CHOLINV_LEAF128": "0"}, {"DCA_CHOLINV_LEAF16": "64"}, {"DCA_CHOLINV_LEAF16": "256"}])
 def test_spd_inverse_alternative_leaves(env):
-    """The recursion's other leaf kernels (register-block leaf, 64-only recursion; selected by environment variables
-    that the library reads once, hence a subprocess) give the same inverse to 1e-11."""
+    """The recursion's other leaf kernels (the four-column MFMA leaf of rounds 2 - 5, the register-block leaf, 64-only recursion, the
+    16-column-step leaf up to 64 / 256 columns instead of 128; selected by environment variables that the library reads once,
+    hence a subprocess) give the same inverse to 1e-11."""
     import subprocess
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
@@ -413,14 +415,14 @@ def test_spd_inverse_blocked_form_at_small_sizes(env):
         "except _lib.DcaBackendError as e:\n"
         "    assert e.code == _lib.DCA_ERR_NOT_SPD, e\n"
         "print(worst)\n" % ROOT)
-    full = dict(os.environ, DCA_CHOLINV_BLOCKED_MIN="0", DCA_CHOLINV_SPLITK_MIN="128", **env)
+    full = dict(os.environ, DCA_SWEEP="0", DCA_CHOLINV_BLOCKED_MIN="0", DCA_CHOLINV_SPLITK_MIN="128", **env)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=full)
     assert p.returncode == 0, p.stderr[-2000:]
     assert float(p.stdout.strip().splitlines()[-1]) < 1e-11
 
 
-def test_spd_inverse_blocked_form_at_its_own_size(L_):
-    """n = 5056: above the size from which dca_spd_inverse_device takes the blocked form by itself (default settings)."""
+def test_spd_inverse_default_form_at_n_5056(L_):
+    """n = 5056: above the size from which dca_spd_inverse_device takes the block sweep by itself (default settings)."""
     n = 5056
     rng = np.random.default_rng(n)
     B = rng.standard_normal((n, n + 8))
@@ -430,6 +432,39 @@ def test_spd_inverse_blocked_form_at_its_own_size(L_):
     ctx.close()
     assert rel_err(inv, np.linalg.inv(A)) < 1e-11
     assert np.array_equal(inv, inv.T)
+
+
+SWEEP_SMALL = {"DCA_SWEEP_MIN": "256", "DCA_SWEEP_PANEL": "128"}
+
+
+@pytest.mark.parametrize("env", [{}, {"DCA_SWEEP_CAP": "8", "DCA_SWEEP_PRIO_CAP": "8"}, {"DCA_SWEEP_PER_CU": "1", "DCA_SWEEP_STAGES": "4"},
+                                 {"DCA_SWEEP_PER_CU": "1", "DCA_SWEEP_STAGES": "3", "DCA_SWEEP_CAP": "16"}, {"DCA_SWEEP_PANEL": "256"},
+                                 {"DCA_SWEEP_MASK": "240"}, {"DCA_SWEEP": "0", "DCA_CHOLINV_BLOCKED_MIN": "5000"}])
+def test_spd_inverse_block_sweep_at_small_sizes(env):
+    """Round 6: the symmetric block sweep (cholinv_sweep) is what runs from n = 2560 on; forced here onto small matrices (panels of 128 /
+    256 columns -- ragged last panel, last tile row of 64, a 64-column last panel --, tiny workgroup caps so that the tile
+    hand-out wraps and steals across the XCD chunks, one workgroup per CU with three / four operand stages, CU-masked streams)
+    and compared with LAPACK; an indefinite matrix must come back as DCA_ERR_NOT_SPD with the pivot of the Cholesky
+    factorisation.  The last parameter set is the three-phase form on the same matrices."""
+    import subprocess
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from pydca_amd import _lib\n"
+        "worst = 0.0\n"
+        "for n in (448, 500, 1000, 1088, 1472, 2100):\n"
+        "    rng = np.random.default_rng(n); B = rng.standard_normal((n, n + 8)); A = B @ B.T / n + 0.5 * np.diag(rng.random(n) + 0.5)\n"
+        "    ctx = _lib.Context(0, _lib.DCA_F64); inv = ctx.spd_inverse(A); ctx.close(); ref = np.linalg.inv(A)\n"
+        "    worst = max(worst, float(np.linalg.norm(inv - ref) / np.linalg.norm(ref))); assert np.array_equal(inv, inv.T)\n"
+        "A[700, 700] = -1.0\n"
+        "ctx = _lib.Context(0, _lib.DCA_F64)\n"
+        "try:\n"
+        "    ctx.spd_inverse(A); raise SystemExit('an indefinite matrix was accepted')\n"
+        "except _lib.DcaBackendError as e:\n"
+        "    assert e.code == _lib.DCA_ERR_NOT_SPD and 'pivot 701' in str(e), e\n"
+        "print(worst)\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **dict(SWEEP_SMALL, **env)))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert float(p.stdout.strip().splitlines()[-1]) < 1e-11
 
 
 def test_scores_kernel(L_, oracle_mf):
