@@ -56,6 +56,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise DcaBackendError(-100, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                     "(pydca_amd has no CPU fallback)" % LIB_PATH)
+    # the SPD inverse overlaps three streams; HIP's default of four hardware queues makes the streams of a process share queues
+    # (read by the runtime at its first call; the library sets the same default when it is loaded and probes its streams anyway)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     L = C.CDLL(LIB_PATH)
     vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
     sig = {

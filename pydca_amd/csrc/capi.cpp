@@ -611,6 +611,11 @@ int dca_mf_run(dca_ctx* ctx, double pseudocount, int apc, double* scores_out, do
     return dca_mf_engine_scores(ctx->mf, apc, scores_out);
 }
 
+// The inverse overlaps three streams (cholinv.hip, block sweep); the HIP runtime's default of four hardware queues makes streams of a
+// process share queues as soon as it holds more than four.  Raised when the library is loaded -- it takes effect if the
+// runtime has not been initialised yet (it reads the variable at its first call); the sweep also probes the streams it uses.
+namespace { struct HwQueues { HwQueues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_hwQueues; }
+
 int dca_spd_inverse(dca_ctx* ctx, const double* A, int n, double* Ainv_out)
 {
     CHECK_CTX(ctx);

@@ -1569,6 +1569,10 @@ struct SideSet {
     hipStream_t s[kSideDepths] = {};
     hipStream_t masked[2] = {};       // round 6 (block sweep): two streams that may use only `maskedCus` of the CUs (the rest stay the chain's)
     int maskedCus = 0;
+    // round 6: the sweep's two side streams, PROBED to run concurrently with the context's stream and with each other (see sweep_streams)
+    std::vector<hipStream_t> extra;
+    hipStream_t selFor = nullptr, selRest = nullptr, selSide = nullptr;
+    int* probe = nullptr;             // device: flag, result
     hipEvent_t fork[kSideDepths] = {}, join[kSideDepths] = {}, mid[kSideDepths] = {};
     int device = -1;
     bool busy = false;
@@ -2379,6 +2383,60 @@ void scale_matrix_kernel(double* __restrict__ M, size_t count, double f)
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) M[e] *= f;
 }
 
+// HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and two streams on one queue run one after the
+// other.  The sweep needs three streams that really overlap (measured at n = 10 048 inside the mfDCA chain, where the
+// process holds a dozen streams: 26.0 ms with the sweep's streams sharing queues, 19.4 ms with them apart), so it PROBES:
+// a kernel on stream a waits (at most 300 us) for a flag that a kernel enqueued afterwards on stream b sets.
+__global__ void probe_wait_kernel(int* flag, int* result, long long ticks)
+{
+    const long long t0 = wall_clock64();
+    int seen = 0;
+    while (wall_clock64() - t0 < ticks) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { seen = 1; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    *result = seen;
+}
+__global__ void probe_set_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+static bool streams_overlap(SideSet* S, hipStream_t a, hipStream_t b)
+{
+    if (a == b) return false;
+    if (!S->probe && hipMalloc(reinterpret_cast<void**>(&S->probe), 2 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return true; }
+    if (hipMemset(S->probe, 0, 2 * sizeof(int)) != hipSuccess) return true;
+    hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, a, S->probe, S->probe + 1, 30000LL);      // wall clock: 100 MHz
+    hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, b, S->probe);
+    int seen = 1;
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
+    if (hipMemcpy(&seen, S->probe + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return true;
+    return seen != 0;
+}
+// two streams of the set that overlap with `chain` and with each other (cached per chain stream); the set's first two if none are found
+static void sweep_streams(SideSet* S, hipStream_t chain, hipStream_t& rest, hipStream_t& side)
+{
+    static const bool probeOn = !(getenv("DCA_SWEEP_PROBE") && atoi(getenv("DCA_SWEEP_PROBE")) == 0);
+    rest = S->s[0]; side = S->s[1];
+    if (!probeOn) return;
+    if (S->selFor == chain && S->selRest) { rest = S->selRest; side = S->selSide; return; }
+    if (hipStreamSynchronize(chain) != hipSuccess) return;              // the probe's kernel must be the stream's next
+    std::vector<hipStream_t> cand(S->s, S->s + kSideDepths);
+    cand.insert(cand.end(), S->extra.begin(), S->extra.end());
+    std::vector<hipStream_t> good;                                      // overlap with the chain
+    for (size_t i = 0; good.size() < 2 && i < 16; ++i) {
+        if (i >= cand.size()) {
+            hipStream_t ns = nullptr;
+            if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+            S->extra.push_back(ns);
+            cand.push_back(ns);
+        }
+        if (!streams_overlap(S, chain, cand[i]) || !streams_overlap(S, cand[i], chain)) continue;
+        if (good.size() == 1 && (!streams_overlap(S, good[0], cand[i]) || !streams_overlap(S, cand[i], good[0]))) continue;
+        good.push_back(cand[i]);
+    }
+    if (good.size() == 2) { rest = good[0]; side = good[1]; }
+    S->selFor = chain; S->selRest = rest; S->selSide = side;
+}
+
 struct SweepCfg { int minN, wide, narrow, wideMinN, cap, stages, perCu, maskCus, prioCap; };
 void sweep_update_launch(hipStream_t stream, int G, int stages, int perCu, const SweepArgs& g)
 {
@@ -2441,6 +2499,7 @@ int cholinv_sweep(dca_ctx* ctx, double* A, int n, double* work, int* dInfo, Side
     static const int restIdx = getenv("DCA_SWEEP_REST_STREAM") ? atoi(getenv("DCA_SWEEP_REST_STREAM")) % kSideDepths : 0;
     static const int sideIdx = getenv("DCA_SWEEP_SIDE_STREAM") ? atoi(getenv("DCA_SWEEP_SIDE_STREAM")) % kSideDepths : 1;
     hipStream_t chain = ctx->stream, rest = side->s[restIdx], sd = side->s[sideIdx];
+    if (!getenv("DCA_SWEEP_REST_STREAM") && !getenv("DCA_SWEEP_SIDE_STREAM")) sweep_streams(side, chain, rest, sd);
     int bulkCus = 256;
     if (cfg.maskCus > 0 && cfg.maskCus < 256 && side_set_masked(side, cfg.maskCus)) { rest = side->masked[0]; sd = side->masked[1]; bulkCus = cfg.maskCus; }
     const int capAll = std::max(1, cfg.perCu) * bulkCus;
