@@ -1,6 +1,10 @@
 #!/bin/bash
 cd "$(dirname "$0")/../.."
-run() { tag=$1; n=$2; shift 2; env "$@" python tools/time_inv.py --n $n --reps 3 --tag "$tag" | tail -1; }
-for n in 1024 1536 2048 3072 4032 5056 6016 8000 10048 12032; do
-  run "sweep256" $n DCA_SWEEP_PANEL=256; run "sweep512" $n DCA_SWEEP_PANEL=512; run "three-phase" $n DCA_SWEEP=0
-done
+for n in 2112 4032; do python tools/time_inv.py --n $n --reps 2 --check --tag sweep | tail -2; done
+python tools/time_inv.py --n 10048 --reps 3 --check --tag sweep | tail -2
+DCA_CHOLINV_TRACE=1 python tools/experiments/mf_twice.py 2> gpurun_out/sweep_trace_mf.txt | tail -2
+python tools/experiments/sweep_trace_summary.py gpurun_out/sweep_trace_mf.txt
+for w in D C; do python bench.py --workload $w --no-cpu-baseline --no-e2e --no-rna --no-modes 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w', d['value'], d['mfdca']['stages_ms'])"; done
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "spd_inverse or mf_" 2>&1 | tail -3
