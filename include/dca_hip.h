@@ -153,6 +153,10 @@ int dca_plm_get_g(dca_ctx* ctx, void* g_out, int dtype);
 int dca_comm_unique_id(const char* rccl_path, void* id128);
 int dca_comm_init(dca_ctx* ctx, const char* rccl_path, const void* id128, int world, int rank);
 int dca_comm_destroy(dca_ctx* ctx);
+/* For a WATCHDOG thread (the only entry point that may be called while another thread is inside a call on the same context): a
+ * peer rank has died; ncclCommAbort releases the communicator and makes the collectives that wait for the peer fail, so the
+ * driving thread's call returns an error instead of hanging.  DCA_ERR_STATE if the collective library has no ncclCommAbort. */
+int dca_comm_abort(dca_ctx* ctx);
 /* world size and rank as the communicator itself reports them (ncclCommCount / ncclCommUserRank): a launcher asserts with
  * it that its N processes form ONE communicator of N ranks.  dca_comm_init / dca_comm_destroy answer DCA_ERR_STATE, and
  * change nothing, while an optimisation whose vectors are cut for the current communicator is in progress. */

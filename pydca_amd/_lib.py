@@ -123,6 +123,7 @@ def lib():
         "dca_mf_run": (i, [vp, d, i, vp, vp]),
         "dca_mf_corr_from_freqs": (i, [vp, vp, vp, i, i, vp]),
         "dca_spd_inverse": (i, [vp, vp, i, vp]),
+        "dca_comm_abort": (i, [vp]),
         "dca_scores_order": (i, [vp, vp, i]),
         "dca_sw_scores": (i, [C.c_char_p, i, C.c_char_p, vp, i, vp, i, i, vp]),
         "dca_sw_align": (i, [C.c_char_p, i, C.c_char_p, i, vp, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p,
@@ -143,7 +144,7 @@ def lib():
 
 
 EXPORTS = ["dca_weights_work", "dca_compute_weights_sharded", "dca_weights_partial_counts", "dca_set_weight_counts", "dca_comm_unique_id",
-           "dca_comm_init", "dca_comm_destroy", "dca_comm_info", "dca_plm_set_native_comm", "dca_mf_set_native_comm",
+           "dca_comm_init", "dca_comm_destroy", "dca_comm_abort", "dca_comm_info", "dca_plm_set_native_comm", "dca_mf_set_native_comm",
            "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_read_msa_alloc", "dca_mf_set_row_window", "dca_comm_allgather_host", "dca_fasta_shape", "dca_read_fasta", "dca_read_fasta_alloc", "dca_host_free", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_configure_strips", "dca_plm_num_params", "dca_plm_init_x",
@@ -295,6 +296,10 @@ class Context:
 
     def comm_destroy(self):
         check(self._l.dca_comm_destroy(self._h))
+
+    def comm_abort(self):
+        """From a watchdog thread: a peer died -- make this context's pending collectives fail (ncclCommAbort)."""
+        check(self._l.dca_comm_abort(self._h))
 
     def comm_info(self):
         """(world, rank) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)."""

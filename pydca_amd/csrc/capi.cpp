@@ -536,6 +536,11 @@ int dca_comm_destroy(dca_ctx* ctx)
     dca_comm_destroy_impl(ctx);
     return DCA_OK;
 }
+int dca_comm_abort(dca_ctx* ctx)
+{
+    if (!ctx) return DCA_ERR_ARG;          // no device switch, no stream work: this runs beside the thread that drives the context
+    return dca_comm_abort_impl(ctx);
+}
 int dca_comm_info(dca_ctx* ctx, int* world, int* rank)
 {
     CHECK_CTX(ctx);

@@ -33,6 +33,7 @@ struct RcclApi {
     int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
     int (*CommCount)(RcclComm, int*) = nullptr;         // optional: what the communicator itself reports (dca_comm_info)
     int (*CommUserRank)(RcclComm, int*) = nullptr;
+    int (*CommAbort)(RcclComm) = nullptr;               // optional: dca_comm_abort
 };
 RcclApi g_api;
 
@@ -82,6 +83,7 @@ int load_api(const char* path)
     if (!ok) { dlclose(h); return DCA_ERR_IO; }
     api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(h, "ncclCommCount"));
     api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
+    api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(h, "ncclCommAbort"));
     api.handle = h;
     g_api = api;
     return DCA_OK;
@@ -136,8 +138,24 @@ int dca_comm_info_impl(dca_ctx* ctx, int* world, int* rank)
     return DCA_OK;
 }
 
+// From ANOTHER thread than the one that drives the context (a watchdog that has seen a peer process die): ncclCommAbort makes
+// the collectives that wait for the dead peer return with an error, so that the driving thread's call comes back instead of
+// hanging for ever.  The communicator is gone afterwards (dca_comm_destroy only clears the context's fields).
+int dca_comm_abort_impl(dca_ctx* ctx)
+{
+    if (!ctx->comm) return DCA_OK;
+    if (!g_api.CommAbort) { dca_set_error("this librccl has no ncclCommAbort"); return DCA_ERR_STATE; }
+    if (ctx->comm_aborted.exchange(true)) return DCA_OK;
+    RCCL_TRY(g_api.CommAbort(static_cast<RcclComm>(ctx->comm)));
+    return DCA_OK;
+}
+
 void dca_comm_destroy_impl(dca_ctx* ctx)
 {
+    if (ctx->comm && ctx->comm_aborted.load()) {
+        ctx->comm = nullptr;               // released by ncclCommAbort
+        ctx->comm_aborted.store(false);
+    }
     if (ctx->comm && g_api.CommDestroy) {
         hipStreamSynchronize(ctx->stream);
         g_api.CommDestroy(static_cast<RcclComm>(ctx->comm));

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -85,6 +86,7 @@ struct dca_ctx {
 
     // native communicator (comm_rccl.cpp): an RCCL communicator whose collectives run on `stream`
     void* comm = nullptr;
+    std::atomic<bool> comm_aborted{false};      // dca_comm_abort ran (from a watchdog thread): the communicator is already released
     int comm_rank = 0, comm_world = 0;
     void* commStage = nullptr;        // pieces received by the direct-exchange reduce-scatter ((world - 1) slices)
     size_t commStageBytes = 0;
@@ -130,6 +132,7 @@ int dca_weights_finish(dca_ctx* ctx);     // w = 1 / count, Meff from ctx->dCoun
 int dca_comm_unique_id_impl(const char* rccl_path, void* id128);
 int dca_comm_init_impl(dca_ctx* ctx, const char* rccl_path, const void* id128, int world, int rank);
 void dca_comm_destroy_impl(dca_ctx* ctx);
+int dca_comm_abort_impl(dca_ctx* ctx);
 int dca_comm_info_impl(dca_ctx* ctx, int* world, int* rank);
 int dca_comm_p2p_begin(dca_ctx* ctx);
 int dca_comm_p2p_send(dca_ctx* ctx, const void* buf, size_t count, int dtype, int peer);

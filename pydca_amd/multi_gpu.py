@@ -10,17 +10,22 @@ created the communicators' unique ids before it started the helpers and hands th
 rendezvous (no torch.distributed, no MPI) is needed.
 
 plmDCA: sequence weights with the comparisons divided over the ranks, then the optimisation under one of the four
-exchange schemes of DESIGN.md section 6 -- timed on the node at start-up like `bench.py --gpus N` does (three iterations
-each, the fastest runs; float64 always takes the column strips, whose gradient is bit-identical to the single-GPU run's)
--- and the optimised parameters end up resident in rank 0's single-GPU context, so scores, DI and parameter export are
-what they are on one GPU.  mfDCA: sharded weights, every rank counts a window of the sequences, ONE all-reduce of the raw
+exchange schemes of DESIGN.md section 6.  The scheme is chosen DETERMINISTICALLY -- the column strips (scheme 4: 1 / world
+of the bytes of the others on the wires, and the scheme whose float64 gradient is bit-identical to the single-GPU run's),
+scheme 2 where the strips do not come up -- so that the same command gives the same scores from run to run; `scheme=` /
+DCA_EXCHANGE_SCHEME=1..4 forces one, DCA_EXCHANGE_SCHEME=auto times all four on the node at start-up like `bench.py --gpus N`
+does (three iterations each, the fastest runs: float32 scores then depend on which scheme won).  The optimised parameters
+end up resident in rank 0's single-GPU context, so scores, DI and parameter export are what they are on one GPU.  mfDCA: sharded weights, every rank counts a window of the sequences, ONE all-reduce of the raw
 pair counts; correlation matrix, inverse and scores then run on rank 0 (the inverse is not sharded).
 
-Failures: every helper reports 'ready' (alignment loaded, device context up) before any collective starts; a helper that
+Failures: every helper reports 'ready' (alignment on its device, context up) before any collective starts; a helper that
 fails -- then or later -- leaves its exception type and message in its status file, and rank 0 re-raises it as the
 exception type the caller's class uses (PlmDCAException / MeanFieldDCAException, ValueError, FileNotFoundError).  A helper
-that DIES inside a collective cannot be recovered from (the peers' kernels wait for it): rank 0 notices the exit, kills
-the other helpers and aborts with the helper's message instead of hanging for ever."""
+that dies LATER leaves rank 0 inside a collective that waits for it: rank 0's share runs in a worker thread, the calling
+thread notices the exit, kills the other helpers and ABORTS rank 0's communicators (dca_comm_abort -> ncclCommAbort), which
+makes the pending call return an error; the caller gets the helper's error and its process lives on.  Where that does not
+release the worker (no ncclCommAbort in the collective library, or the communicator was still being set up) the worker
+thread is left behind after 15 s and the error is raised all the same -- never a hang, never os._exit."""
 import json
 import os
 import shutil
@@ -38,7 +43,21 @@ SCHEMES = {1: "sequences sharded, all-reduce(g)",
            2: "sequences sharded, reduce-scatter(g) + all-gather(x), optimiser vectors sharded",
            3: "sequences sharded, direct exchange (grouped send / recv, rank-ordered local sum), optimiser vectors sharded",
            4: "column strips: every rank all sequences x the columns of its sites, point-to-point exchange"}
+ABANDON_S = 15.0     # how long rank 0's worker thread gets to come back after its communicators were aborted
 NUM_IDS = 3          # communicators a run may need: weights / resident context, sequence-sharded context, column-strip context
+
+
+_COMM_CONTEXTS = []      # contexts of THIS process with a live communicator (what the watchdog aborts)
+
+
+def _comm_up(ctx, unique_id, world, rank, rccl):
+    ctx.comm_init(unique_id, world, rank, rccl)
+    _COMM_CONTEXTS.append(ctx)
+
+
+def _comm_forget(ctx):
+    if ctx in _COMM_CONTEXTS:
+        _COMM_CONTEXTS.remove(ctx)
 
 
 class MultiGpuError(RuntimeError):
@@ -81,17 +100,19 @@ def _agree(ctx, ok):
     return bool(np.all(ctx.comm_allgather([1.0 if ok else 0.0]) > 0.5))
 
 
-def plm_rank(job, rank, X, log=None):
-    """The plmDCA run of one rank -> (x on rank 0 / None, stats dict, selection dict, resident context on rank 0 / None)."""
+def plm_rank(job, rank, X, log=None, ctx=None):
+    """The plmDCA run of one rank -> (x on rank 0 / None, stats dict, selection dict, resident context on rank 0 / None).
+    ctx: this rank's context with the alignment already on the device (a helper makes it before it reports 'ready')."""
     devices, q, prec = job["devices"], job["q"], job["precision"]
     world, dev, ids, rccl = len(devices), devices[rank], _ids(job), job.get("rccl_path")
     lh, lJ, carry, seqid, cap = job["lambda_h"], job["lambda_J"], job["carry_mode"], job["seqid"], job["max_iterations"]
     dtype = np.float64 if prec == _lib.DCA_F64 else np.float32
-    full = _lib.Context(dev, prec)
+    full = ctx if ctx is not None else _lib.Context(dev, prec)
     seq_ctx = strip_ctx = None
     try:
-        full.set_msa(X, q)
-        full.comm_init(ids[0], world, rank, rccl)
+        if ctx is None:
+            full.set_msa(X, q)
+        _comm_up(full, ids[0], world, rank, rccl)
         # every rank counts 1 / world of the identity comparisons, ONE all-reduce of the N integer counts (SURVEY 8 e2)
         full.compute_weights_sharded(seqid, prec)
         counts = full.weight_counts()
@@ -104,14 +125,14 @@ def plm_rank(job, rank, X, log=None):
         def seq_up():
             c = parallel.make_sharded_plm_context(_lib, X, q, w.astype(np.float64), lh, lJ, rank, world, dev,
                                                   precision=prec, carry_mode=carry, warmup=80 if prec == _lib.DCA_F64 else 40)
-            c.comm_init(ids[1], world, rank, rccl)
+            _comm_up(c, ids[1], world, rank, rccl)
             return c
 
         def strips_up():
             c = _lib.Context(dev, prec)
             c.set_msa(X, q)
             c.set_weight_counts(counts)
-            c.comm_init(ids[2], world, rank, rccl)
+            _comm_up(c, ids[2], world, rank, rccl)
             c.plm_configure_strips(lh, lJ, carry)
             return c
 
@@ -129,6 +150,8 @@ def plm_rank(job, rank, X, log=None):
                 print("pydca_amd rank %d: exchange scheme %d unavailable (%r)" % (rank, mode, exc), file=sys.stderr)
                 ok = False
             if not _agree(full, ok):
+                if ok:
+                    c.plm_lbfgs_end()              # the run this rank began must not block the next scheme's set-up
                 return None
             full.comm_allgather([0.0])               # barrier
             t0 = time.perf_counter()
@@ -139,37 +162,53 @@ def plm_rank(job, rank, X, log=None):
 
         forced = job.get("scheme")
         timings = {}
-        if forced:
+        if forced and str(forced).lower() != "auto":
             chosen = int(forced)
-        elif prec == _lib.DCA_F64:
-            chosen = 4          # the parity mode: column strips reproduce the single-GPU float64 gradient bit for bit
+        elif not forced:
+            # deterministic: the column strips; scheme 2 if they do not come up on every rank (e.g. fewer sites than ranks)
+            ok = True
+            try:
+                strip_ctx = strips_up()
+            except Exception as exc:
+                print("pydca_amd rank %d: column strips unavailable (%r)" % (rank, exc), file=sys.stderr)
+                ok = False
+            chosen = 4 if _agree(full, ok) else 2
         else:
             seq_ctx = seq_up()
             for mode in (1, 2, 3):
                 t = time_mode(seq_ctx, mode)
                 if t is not None:
                     timings[mode] = t
+            seq_ctx.close()                          # the two decompositions are never resident together
+            _comm_forget(seq_ctx)
+            seq_ctx = None
             strip_ctx = strips_up()
             t = time_mode(strip_ctx, 4)
             if t is not None:
                 timings[4] = t
-            chosen = min(timings, key=lambda m: timings[m]) if timings else 2
+            if not timings:
+                raise RuntimeError("no exchange scheme came up on every rank")
+            chosen = min(timings, key=lambda m: timings[m])
         if chosen not in SCHEMES:
             raise ValueError("exchange scheme must be one of 1, 2, 3, 4 (got %r)" % (chosen,))
         if chosen == 4:
             if seq_ctx is not None:
                 seq_ctx.close()
+                _comm_forget(seq_ctx)
                 seq_ctx = None
             run = strip_ctx if strip_ctx is not None else strips_up()
             strip_ctx = run
         else:
             if strip_ctx is not None:
                 strip_ctx.close()
+                _comm_forget(strip_ctx)
                 strip_ctx = None
             run = seq_ctx if seq_ctx is not None else seq_up()
             seq_ctx = run
             run.plm_set_native_comm(chosen)
         run.plm_set_x(x0)
+        if os.environ.get("DCA_MULTI_GPU_TEST_DIE_IN_RUN") == str(rank):        # tests: a rank that dies with every communicator up
+            os._exit(9)
         t0 = time.perf_counter()
         run.plm_lbfgs_begin(cap, bool(job.get("verbose")) and rank == 0)
         st = run.plm_lbfgs_iterate(cap if cap else 1 << 30)
@@ -180,12 +219,15 @@ def plm_rank(job, rank, X, log=None):
         selection = dict(chosen_scheme=chosen, scheme=SCHEMES[chosen], ms_per_iteration={str(k): v for k, v in timings.items()},
                          ranks=run.comm_info()[0], devices=list(devices))
         run.close()
+        _comm_forget(run)
         seq_ctx = strip_ctx = None
         if rank != 0:
             full.close()
+            _comm_forget(full)
             return None, stats, selection, None
         # rank 0 keeps ONE single-GPU context with the result resident: the first one (whole alignment, all weights)
         full.comm_destroy()
+        _comm_forget(full)
         full.plm_configure(lh, lJ, carry)
         full.plm_set_x(x)
         return x, stats, selection, full
@@ -193,20 +235,24 @@ def plm_rank(job, rank, X, log=None):
         for c in (seq_ctx, strip_ctx, full):
             try:
                 if c is not None:
+                    _comm_forget(c)
                     c.close()
             except Exception:
                 pass
         raise
 
 
-def mf_rank(job, rank, X):
+def mf_rank(job, rank, X, ctx=None):
     """The sharded stages of mfDCA on one rank -> resident context with weights and the summed pair counts (rank 0) / None."""
     devices, q, seqid = job["devices"], job["q"], job["seqid"]
     world, dev, ids, rccl = len(devices), devices[rank], _ids(job), job.get("rccl_path")
-    ctx = _lib.Context(dev, _lib.DCA_F64)
+    made = ctx is None
+    if made:
+        ctx = _lib.Context(dev, _lib.DCA_F64)
     try:
-        ctx.set_msa(X, q)
-        ctx.comm_init(ids[0], world, rank, rccl)
+        if made:
+            ctx.set_msa(X, q)
+        _comm_up(ctx, ids[0], world, rank, rccl)
         if seqid < 1.0:
             ctx.compute_weights_sharded(seqid, _lib.DCA_F64)
         else:
@@ -217,11 +263,14 @@ def mf_rank(job, rank, X):
         ctx.mf_single_site_freqs()                 # counts of the window + ONE all-reduce of the (L q)^2 raw pair counts
         if rank != 0:
             ctx.close()
+            _comm_forget(ctx)
             return None
         ctx.comm_destroy()                         # the summed counts stay (dca_mf_set_row_window)
+        _comm_forget(ctx)
         return ctx
     except BaseException:
         try:
+            _comm_forget(ctx)
             ctx.close()
         except Exception:
             pass
@@ -247,8 +296,6 @@ class _Helpers:
             log = open(os.path.join(self.dir, "rank%d.log" % r), "w")
             self.procs.append((r, subprocess.Popen([sys.executable, "-m", "pydca_amd.multi_gpu", self.dir, str(r)], env=env,
                                                    stdout=log, stderr=subprocess.STDOUT), log))
-        self._stop = threading.Event()
-        self._watch = threading.Thread(target=self._watchdog, daemon=True)
 
     def _status(self, r):
         try:
@@ -289,23 +336,15 @@ class _Helpers:
                 raise MultiGpuError(min(pending), "TimeoutError", "helper did not come up within %.0f s" % timeout)
             if pending:
                 time.sleep(0.02)
-        self._watch.start()
 
-    def _watchdog(self):
-        # a helper that dies inside a collective leaves rank 0's kernels waiting for ever: say why and stop the process
-        while not self._stop.wait(0.2):
-            for r, p, _l in self.procs:
-                if p.poll() not in (None, 0):
-                    self.failed = self._error_of(r, p)
-                    sys.stderr.write("pydca_amd: %s\npydca_amd: a rank died inside a collective; aborting.\n" % self.failed)
-                    sys.stderr.flush()
-                    for _r, q, _l2 in self.procs:
-                        if q.poll() is None:
-                            q.kill()
-                    os._exit(70)
+    def dead_helper(self):
+        """-> MultiGpuError of the first helper that has exited with a failure, or None."""
+        for r, p, _l in self.procs:
+            if p.poll() not in (None, 0):
+                return self._error_of(r, p)
+        return None
 
     def finish(self, timeout=600.0):
-        self._stop.set()
         err = None
         for r, p, log in self.procs:
             try:
@@ -321,7 +360,6 @@ class _Helpers:
             raise err
 
     def abort(self):
-        self._stop.set()
         for _r, p, log in self.procs:
             if p.poll() is None:
                 p.kill()
@@ -342,17 +380,73 @@ def _job(kind, devices, q, seqid, **more):
 
 
 def _run(job, X, rank_fn):
+    """Rank 0's share runs in a worker thread of the calling process; the calling thread watches the helpers meanwhile.  A helper
+    that dies after 'ready' leaves rank 0 inside (or on its way into) a collective that waits for it: the other helpers are
+    killed, rank 0's communicators aborted (dca_comm_abort -> ncclCommAbort: the pending call fails and the worker ends), and
+    the helper's error is raised.  Should the worker not come back within ABANDON_S seconds all the same (a collective library
+    without ncclCommAbort, or a rank that died while the communicator was still being set up), it is left behind as a
+    daemon thread and the error is raised anyway: the caller is never blocked for ever and never killed."""
     helpers = _Helpers(job, X)
+    box = {}
+
+    def work():
+        try:
+            box["out"] = rank_fn(job, 0, X)
+        except BaseException as exc:            # handed to the calling thread
+            box["exc"] = exc
+
     try:
         helpers.wait_ready()
-        out = rank_fn(job, 0, X)
     except MultiGpuError:
         raise
     except BaseException:
         helpers.abort()
         raise
+    worker = threading.Thread(target=work, daemon=True)
+    worker.start()
+    failed = None
+    try:
+        while worker.is_alive():
+            worker.join(0.1)
+            if worker.is_alive():
+                failed = helpers.dead_helper()
+                if failed is not None:
+                    break
+    except BaseException:                       # KeyboardInterrupt in the calling thread
+        for c in list(_COMM_CONTEXTS):
+            try:
+                c.comm_abort()
+            except Exception:
+                pass
+        helpers.abort()
+        raise
+    if failed is not None:
+        for _r, p, _l in helpers.procs:
+            if p.poll() is None:
+                p.kill()
+        for c in list(_COMM_CONTEXTS):
+            try:
+                c.comm_abort()
+            except Exception:
+                pass
+        worker.join(ABANDON_S)
+        if worker.is_alive():
+            sys.stderr.write("pydca_amd: %s\npydca_amd: rank 0's collective could not be aborted; its thread is left behind.\n" % failed)
+            del _COMM_CONTEXTS[:]
+        helpers.abort()
+        raise failed
+    if "exc" in box:
+        exc = box["exc"]
+        if isinstance(exc, MultiGpuError):
+            helpers.abort()
+            raise exc
+        failed = helpers.dead_helper()
+        helpers.abort()
+        if failed is not None:
+            raise failed from exc
+        raise exc
     helpers.finish()
-    return out
+    return box["out"]
 
 
 def run_plm(X, q, seqid, lambda_h, lambda_J, max_iterations, precision, carry_mode, devices, verbose=False, scheme=None):
@@ -382,13 +476,17 @@ def _helper_main(jobdir, rank):
         with open(os.path.join(jobdir, "job.json")) as fh:
             job = json.load(fh)
         X = np.load(os.path.join(jobdir, "X.npy"))
-        probe = _lib.Context(job["devices"][rank], _lib.DCA_F64)        # the device exists and the library loads
-        probe.close()
+        # everything that can fail WITHOUT a peer happens before 'ready': the device exists, the library loads, the alignment
+        # fits on the device
+        ctx = _lib.Context(job["devices"][rank], job["precision"] if job["kind"] == "plm" else _lib.DCA_F64)
+        ctx.set_msa(X, job["q"])
         say(state="ready")
+        if os.environ.get("DCA_MULTI_GPU_TEST_DIE_AFTER_READY") == str(rank):      # tests: a rank that dies between collectives
+            os._exit(9)
         if job["kind"] == "plm":
-            plm_rank(job, rank, X)
+            plm_rank(job, rank, X, ctx=ctx)
         else:
-            mf_rank(job, rank, X)
+            mf_rank(job, rank, X, ctx=ctx)
         say(state="done")
         return 0
     except BaseException as exc:

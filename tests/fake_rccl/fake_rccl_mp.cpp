@@ -21,7 +21,7 @@
 namespace {
 
 struct Control { std::atomic<int> arrived; std::atomic<long> generation; };
-struct Comm { std::string id; int nranks, rank; Control* ctl; long p2pSeq; };
+struct Comm { std::string id; int nranks, rank; Control* ctl; long p2pSeq; std::atomic<bool> aborted{false}; };
 struct P2P { bool send; void* buf; size_t bytes; int peer; Comm* comm; hipStream_t stream; };
 thread_local int t_depth = 0;
 thread_local std::vector<P2P> t_ops;
@@ -29,15 +29,21 @@ thread_local std::vector<P2P> t_ops;
 size_t type_size(int t) { return t == 3 || t == 7 ? 4 : t == 8 ? 8 : 0; }
 std::string path_of(const Comm* c, const std::string& what) { return "/dev/shm/" + c->id + "." + what; }
 
-void barrier(Comm* c)
+// false: the communicator was aborted while this rank waited for its peers (ncclCommAbort from a watchdog thread)
+bool barrier(Comm* c)
 {
+    if (c->aborted.load()) return false;
     const long gen = c->ctl->generation.load();
     if (c->ctl->arrived.fetch_add(1) + 1 == c->nranks) {
         c->ctl->arrived.store(0);
         c->ctl->generation.fetch_add(1);
     } else {
-        while (c->ctl->generation.load() == gen) usleep(50);
+        while (c->ctl->generation.load() == gen) {
+            if (c->aborted.load()) return false;
+            usleep(50);
+        }
     }
+    return true;
 }
 
 bool write_file(const std::string& p, const void* data, size_t bytes)
@@ -73,7 +79,7 @@ int reduce_all(Comm* c, const void* send, size_t count, int type, hipStream_t st
     std::vector<char> mine(count * esz);
     if (hipMemcpy(mine.data(), send, count * esz, hipMemcpyDeviceToHost) != hipSuccess) return 1;
     if (!write_file(path_of(c, "slot" + std::to_string(c->rank)), mine.data(), mine.size())) return 1;
-    barrier(c);
+    if (!barrier(c)) return 6;
     result.assign(count * esz, 0);
     std::vector<char> v(count * esz);
     for (int r = 0; r < c->nranks; ++r) {
@@ -83,7 +89,7 @@ int reduce_all(Comm* c, const void* send, size_t count, int type, hipStream_t st
         else if (type == 7) add_into<float>(result, v, count);
         else add_into<double>(result, v, count);
     }
-    barrier(c);                // nobody overwrites its slot before everyone has read it
+    if (!barrier(c)) return 6;      // nobody overwrites its slot before everyone has read it
     return 0;
 }
 
@@ -104,7 +110,8 @@ int ncclGetUniqueId(ncclUniqueId* id)
 int ncclCommInitRank(void** comm, int nranks, ncclUniqueId id, int rank)
 {
     if (rank < 0 || rank >= nranks) return 4;
-    Comm* c = new Comm{std::string(id.internal), nranks, rank, nullptr, 0};
+    Comm* c = new Comm;
+    c->id = id.internal; c->nranks = nranks; c->rank = rank; c->ctl = nullptr; c->p2pSeq = 0;
     const std::string p = path_of(c, "ctl");
     const int fd = open(p.c_str(), O_RDWR | O_CREAT, 0600);
     if (fd < 0) return 1;
@@ -118,10 +125,17 @@ int ncclCommInitRank(void** comm, int nranks, ncclUniqueId id, int rank)
     return 0;
 }
 
+// the real call also releases the communicator; this one only makes every wait on it return (the object is leaked: a test aid)
+int ncclCommAbort(void* comm)
+{
+    static_cast<Comm*>(comm)->aborted.store(true);
+    return 0;
+}
+
 int ncclCommDestroy(void* comm)
 {
     Comm* c = static_cast<Comm*>(comm);
-    barrier(c);
+    if (!barrier(c)) return 6;
     unlink(path_of(c, "slot" + std::to_string(c->rank)).c_str());
     if (c->rank == 0) unlink(path_of(c, "ctl").c_str());
     munmap(c->ctl, 4096);
@@ -148,7 +162,7 @@ int ncclGroupEnd()
         if (hipMemcpy(box.data(), o.buf, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
         if (!write_file(path_of(c, "p2p." + std::to_string(c->rank) + "." + std::to_string(o.peer) + "." + std::to_string(sent[o.peer]++)), box.data(), box.size())) return 1;
     }
-    barrier(c);
+    if (!barrier(c)) return 6;
     int rc = 0;
     for (const P2P& o : ops) {
         if (o.send) continue;
@@ -159,7 +173,7 @@ int ncclGroupEnd()
         if (!read_file(p, box.data(), o.bytes) || hipMemcpy(o.buf, box.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) rc = 1;
         unlink(p.c_str());
     }
-    barrier(c);
+    if (!barrier(c)) return 6;
     return rc;
 }
 int ncclSend(const void* buf, size_t count, int type, int peer, void* comm, hipStream_t stream)
@@ -200,14 +214,14 @@ int ncclAllGather(const void* send, void* recv, size_t sendcount, int type, void
     std::vector<char> mine(sendcount * esz);
     if (hipMemcpy(mine.data(), send, mine.size(), hipMemcpyDeviceToHost) != hipSuccess) return 1;
     if (!write_file(path_of(c, "slot" + std::to_string(c->rank)), mine.data(), mine.size())) return 1;
-    barrier(c);
+    if (!barrier(c)) return 6;
     int rc = 0;
     std::vector<char> v(sendcount * esz);
     for (int r = 0; r < c->nranks && !rc; ++r) {
         if (!read_file(path_of(c, "slot" + std::to_string(r)), v.data(), v.size())) rc = 1;
         else if (hipMemcpy(static_cast<char*>(recv) + (size_t)r * sendcount * esz, v.data(), v.size(), hipMemcpyHostToDevice) != hipSuccess) rc = 1;
     }
-    barrier(c);
+    if (!barrier(c)) return 6;
     return rc;
 }
 

@@ -796,13 +796,17 @@ def test_plmdca_command_line_devices_equals_one_gpu_float64(tmp_path, msa, bio):
     print("\n%s: identical order; %d of %d scores byte-identical" % (msa, int(np.sum(s1 == s2)), len(s1)))
 
 
-def test_plmdca_devices_float32_times_the_schemes_and_follows_one_gpu():
-    """The default float32 mode with devices=[0, 0]: all four exchange schemes come up and are timed at start-up, the fastest
-    runs, and the result follows the one-GPU run (another order of float32 sums: the P4 regime, bounded loosely); the
-    exception type of a failing rank is the class's own."""
+def test_plmdca_devices_float32_scheme_choice_and_failures():
+    """The default float32 mode with devices=[0, 0].  The exchange scheme is chosen deterministically (the column strips): two runs
+    of the same command give byte-identical scores, and the result follows the one-GPU run (another order of float32 sums: the
+    P4 regime, bounded loosely).  DCA_EXCHANGE_SCHEME=auto still brings all four schemes up, times them and runs the fastest.
+    The exception type of a rank that fails before the collectives is the class's own; a rank that DIES after it reported
+    'ready' ends in the same exception -- before the communicators are up (rank 0's worker thread, stuck in the set-up, is left
+    behind after 15 s) as well as between two collectives (dca_comm_abort releases rank 0 at once) -- and the calling process
+    lives on and runs the next job."""
     import subprocess
     code = (
-        "import json, sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import json, os, sys, numpy as np; sys.path.insert(0, %r)\n"
         "from pydca_amd.plmdca import plmdca\n"
         "f = %r\n"
         "a = plmdca.PlmDCA(f, 'rna', max_iterations=10)\n"
@@ -810,24 +814,54 @@ def test_plmdca_devices_float32_times_the_schemes_and_follows_one_gpu():
         "b = plmdca.PlmDCA(f, 'rna', max_iterations=10, devices=[0, 0])\n"
         "sb = b.compute_sorted_FN_APC()\n"
         "sel = b.last_status['multi_gpu']\n"
+        "b2 = plmdca.PlmDCA(f, 'rna', max_iterations=10, devices=[0, 0])\n"
+        "same = b2.compute_sorted_FN_APC() == sb\n"
+        "os.environ['DCA_EXCHANGE_SCHEME'] = 'auto'\n"
+        "c = plmdca.PlmDCA(f, 'rna', max_iterations=10, devices=[0, 0])\n"
+        "sc = c.compute_sorted_FN_APC()\n"
+        "auto = c.last_status['multi_gpu']\n"
+        "del os.environ['DCA_EXCHANGE_SCHEME']\n"
         "da = dict(sa); top = [p for p, _ in sa[:20]]\n"
         "dev = max(abs(dict(sb)[p] - da[p]) / abs(da[p]) for p in top)\n"
+        "dev_auto = max(abs(dict(sc)[p] - da[p]) / abs(da[p]) for p in top)\n"
         "try:\n"
         "    plmdca.PlmDCA(f, 'rna', max_iterations=2, devices=[0, 4097]).compute_sorted_FN()\n"
         "    err = 'no error'\n"
         "except plmdca.PlmDCAException as e:\n"
         "    err = 'PlmDCAException'\n"
-        "print(json.dumps(dict(sel=sel, dev=dev, status=[a.last_status['status'], b.last_status['status']],\n"
+        "os.environ['DCA_MULTI_GPU_TEST_DIE_AFTER_READY'] = '1'\n"
+        "try:\n"
+        "    plmdca.PlmDCA(f, 'rna', max_iterations=2, devices=[0, 0]).compute_sorted_FN()\n"
+        "    died = 'no error'\n"
+        "except plmdca.PlmDCAException as e:\n"
+        "    died = 'PlmDCAException'\n"
+        "del os.environ['DCA_MULTI_GPU_TEST_DIE_AFTER_READY']\n"
+        "os.environ['DCA_MULTI_GPU_TEST_DIE_IN_RUN'] = '1'\n"
+        "import time; t0 = time.time()\n"
+        "try:\n"
+        "    plmdca.PlmDCA(f, 'rna', max_iterations=2, devices=[0, 0]).compute_sorted_FN()\n"
+        "    died2 = 'no error'\n"
+        "except plmdca.PlmDCAException as e:\n"
+        "    died2 = 'PlmDCAException'\n"
+        "abort_s = time.time() - t0\n"
+        "del os.environ['DCA_MULTI_GPU_TEST_DIE_IN_RUN']\n"
+        "d = plmdca.PlmDCA(f, 'rna', max_iterations=10, devices=[0, 0])\n"
+        "alive = d.compute_sorted_FN_APC() == sb\n"
+        "print(json.dumps(dict(sel=sel, auto=auto, dev=dev, dev_auto=dev_auto, same=same, alive=alive, died=died, died2=died2, abort_s=abort_s,\n"
+        "                      status=[a.last_status['status'], b.last_status['status']],\n"
         "                      its=[a.last_status['iterations'], b.last_status['iterations']], err=err)))\n" % (ROOT, data_file("MSA_RF00167_trimmed71.fa")))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, DCA_RCCL_PATH=FAKE_MP))
     assert p.returncode == 0, p.stderr[-3000:]
     import json
     d = json.loads(p.stdout.strip().splitlines()[-1])
-    assert sorted(d["sel"]["ms_per_iteration"]) == ["1", "2", "3", "4"], d
-    assert str(d["sel"]["chosen_scheme"]) == min(d["sel"]["ms_per_iteration"], key=lambda m: d["sel"]["ms_per_iteration"][m])
+    assert d["sel"]["chosen_scheme"] == 4 and d["sel"]["ms_per_iteration"] == {} and d["same"], d
+    assert sorted(d["auto"]["ms_per_iteration"]) == ["1", "2", "3", "4"], d
+    assert str(d["auto"]["chosen_scheme"]) == min(d["auto"]["ms_per_iteration"], key=lambda m: d["auto"]["ms_per_iteration"][m])
     assert d["sel"]["ranks"] == 2 and d["its"] == [10, 10] and d["status"][0] == d["status"][1], d
-    assert d["dev"] < 1e-3, d
-    assert d["err"] == "PlmDCAException", d
+    assert d["dev"] < 1e-3 and d["dev_auto"] < 1e-3, d
+    assert d["err"] == "PlmDCAException" and d["died"] == "PlmDCAException" and d["alive"], d
+    # a death BETWEEN collectives (the communicators are up): the abort releases rank 0 at once, well inside the abandon time-out
+    assert d["died2"] == "PlmDCAException" and d["abort_s"] < 10.0, d
 
 
 def test_mfdca_command_line_devices_equals_one_gpu(tmp_path):
