@@ -737,7 +737,14 @@ def main():
             # per lane x (planes xor / or + 1 popcount-add) VALU instructions) against the integer-VALU issue rate -- one wave
             # instruction per SIMD every 4 clocks; the exact early exit skips the rest of the N^2 L / 2 comparisons, which the
             # round-4 figure still counted (a "fraction" of 1.56)
-            groups, groups_all, planes = mctx.weights_work()
+            # one extra, untimed pass with the kernel's work counter on (DCA_WEIGHTS_WORK: off in the timed passes)
+            os.environ["DCA_WEIGHTS_WORK"] = "1"
+            wctx = _lib.Context(local_rank, _lib.DCA_F64)
+            wctx.set_msa(X, q)
+            wctx.compute_weights(0.8, _lib.DCA_F64)
+            groups, groups_all, planes = wctx.weights_work()
+            wctx.close()
+            del os.environ["DCA_WEIGHTS_WORK"]
             valu_per_group = 16.0 * (planes + 3.0)          # q <= 32: 5 xor + 2 or3 + 1 bcnt = 8; q <= 8: 3 + 1 + 1 = 5
             peak = 256 * 4 * 2.4e9 / 4.0                    # wave instructions per second
             issued = groups * valu_per_group / t_w

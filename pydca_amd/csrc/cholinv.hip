@@ -1947,6 +1947,7 @@ int trtri_tree(dca_ctx* ctx, double* A, const double* Lm, int ld, const std::vec
 struct StepTrace {
     bool on = false;
     std::vector<std::pair<std::string, hipEvent_t>> marks;
+    ~StepTrace() { for (auto& m : marks) hipEventDestroy(m.second); }      // an early return does not leak the events
     void mark(hipStream_t st, const char* what, int j)
     {
         if (!on) return;
@@ -1996,6 +1997,8 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
         if (twoStreams && bulkInFlight) hipStreamSynchronize(bulk);     // the bulk writes A and reads Lm: drain it before the caller may free them
         return r;
     };
+    // a failing event call inside the loop must not leave this frame before the bulk stream is drained (bail)
+#define BLK_HIP(expr) if ((expr) != hipSuccess) { dca_set_error("%s failed (%s:%d)", #expr, __FILE__, __LINE__); rc = DCA_ERR_HIP; break; }
     for (int j = 0; j < nb && rc == DCA_OK; ++j) {
         const int c = b[j], w = b[j + 1] - c, m = n - c - w;
         double* D = A + (size_t)c * ld + c;
@@ -2004,7 +2007,7 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
         tr.mark(ctx->stream, "chain: block factored", j);
         if (m == 0) break;
         // ---- chain: the panel of the factor below the block
-        if (twoStreams && j > 0) HIP_TRY(hipStreamWaitEvent(ctx->stream, ev(1, j), 0));
+        if (twoStreams && j > 0) BLK_HIP(hipStreamWaitEvent(ctx->stream, ev(1, j), 0));
         double* Lj = Lm + (size_t)(c + w) * ld + c;
         const int w1 = b[j + 2] - b[j + 1];
         // the chain needs only the rows of the NEXT diagonal block from this panel of the factor; with two streams the rows
@@ -2013,8 +2016,8 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
         if ((rc = launch_gemm(ctx, GemmArgs{A + (size_t)(c + w) * ld + c, ld, MASK_NONE, D, ld, MASK_LOWER, Lj, ld, nullptr, 0, mTop, w, w, 1.0, 0.0, 0, WALK_COLUMNS_REVERSED})) != DCA_OK) break;
         tr.mark(ctx->stream, "chain: panel of the factor done", j);
         if (twoStreams) {
-            HIP_TRY(hipEventRecord(ev(0, j), ctx->stream));
-            HIP_TRY(hipStreamWaitEvent(bulk, ev(0, j), 0));
+            BLK_HIP(hipEventRecord(ev(0, j), ctx->stream));
+            BLK_HIP(hipStreamWaitEvent(bulk, ev(0, j), 0));
         }
         tr.mark(bulk, "bulk: begins step", j);
         if (mTop < m) {
@@ -2033,7 +2036,7 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
                                                         m - w1, w1, w, -1.0, 1.0, 0}, cfg.cap);
             if (rc != DCA_OK) break;
             bulkInFlight = true;
-            if (twoStreams) HIP_TRY(hipEventRecord(ev(1, j + 1), bulk));
+            if (twoStreams) BLK_HIP(hipEventRecord(ev(1, j + 1), bulk));
             tr.mark(bulk, "bulk: rows of the next panel done", j);
             // ---- bulk: panel j + 2 from all the panels up to j at once
             const int c2 = b[j + 2], w2 = b[j + 3 <= nb ? j + 3 : nb] - c2;
@@ -2059,19 +2062,22 @@ int cholinv_blocked(dca_ctx* ctx, double* A, int n, Arena& ws, double* Lm, int* 
                 else rc = launch_gemm_capped(bulk, GemmArgs{Lrows, ld, MASK_NONE, Lrows, ld, MASK_NONE, A + (size_t)c2 * ld + c2, ld, nullptr, 0,
                                                             n - c2, w2, K, -1.0, 1.0, 1}, cfg.cap);
                 if (rc != DCA_OK) break;
-                if (twoStreams) HIP_TRY(hipEventRecord(ev(2, j + 2), bulk));
+                if (twoStreams) BLK_HIP(hipEventRecord(ev(2, j + 2), bulk));
                 tr.mark(bulk, "bulk: deep update of panel j + 2 done", j);
             }
         }
         // ---- chain: the next diagonal block from L_j (after the deep-K update of the same block)
-        if (twoStreams && j >= 1) HIP_TRY(hipStreamWaitEvent(ctx->stream, ev(2, j + 1), 0));
+        if (twoStreams && j >= 1) BLK_HIP(hipStreamWaitEvent(ctx->stream, ev(2, j + 1), 0));
         if ((rc = launch_gemm(ctx, GemmArgs{Lj, ld, MASK_NONE, Lj, ld, MASK_NONE, A + (size_t)(c + w) * ld + c + w, ld, nullptr, 0, w1, w1, w, -1.0, 1.0, 1})) != DCA_OK) break;
     }
     if (rc != DCA_OK) return bail(rc);
     if (twoStreams && bulkInFlight) {
-        HIP_TRY(hipEventRecord(ev(0, nb), bulk));
-        HIP_TRY(hipStreamWaitEvent(ctx->stream, ev(0, nb), 0));
+        if (hipEventRecord(ev(0, nb), bulk) != hipSuccess || hipStreamWaitEvent(ctx->stream, ev(0, nb), 0) != hipSuccess) {
+            dca_set_error("cholinv: join of the bulk stream failed");
+            return bail(DCA_ERR_HIP);
+        }
     }
+#undef BLK_HIP
     tr.mark(ctx->stream, "factorisation done", nb);
     rc = trtri_tree(ctx, A, Lm, ld, b, 0, nb, ws);
     tr.mark(ctx->stream, "triangular inverse done", nb);

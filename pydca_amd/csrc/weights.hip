@@ -201,7 +201,7 @@ void weights_count_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__
     // the issued integer work that bench.py prices against the integer-VALU rate
     // (kWorkSlots counters, summed on the host: one address for the 1.2 million waves of config D serialised their atomics
     // into 27 ms)
-    if ((threadIdx.x & 63) == 0 && groupsDone) atomicAdd(&work[(blockIdx.x * 4u + (threadIdx.x >> 6)) % kWorkSlots], (unsigned long long)groupsDone);
+    if (work && (threadIdx.x & 63) == 0 && groupsDone) atomicAdd(&work[(blockIdx.x * 4u + (threadIdx.x >> 6)) % kWorkSlots], (unsigned long long)groupsDone);
     // ident = L - mismatches (padding sites are state 0 in every row and never mismatch).  A wave whose pairs have all
     // passed the bound has nothing to count (ident >= thresh <=> mismatches <= L - thresh): most waves skip the epilogue.
     if (!waveDone) {
@@ -276,8 +276,13 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int p
         unsigned long long* dWork = nullptr;
         hipError_t ea = dca_dev_malloc(reinterpret_cast<void**>(&dP), (size_t)N * G * PLP * sizeof(uint32_t));
         if (ea == hipSuccess) ea = dca_dev_malloc(reinterpret_cast<void**>(&dPerm), (size_t)ctx->Ls * sizeof(int));
-        if (ea == hipSuccess) ea = dca_dev_malloc(reinterpret_cast<void**>(&dWork), kWorkSlots * sizeof(unsigned long long));
-        if (ea == hipSuccess) ea = hipMemsetAsync(dWork, 0, kWorkSlots * sizeof(unsigned long long), ctx->stream);
+        // the work counter (a 64-bit atomic per wave, a 32 KB read-back: what bench.py prices the kernel with) only on request
+        const bool countWork = getenv("DCA_WEIGHTS_WORK") && atoi(getenv("DCA_WEIGHTS_WORK")) != 0;       // read per call: bench.py asks for ONE counted pass
+        ctx->weightsWork[0] = ctx->weightsWork[1] = 0;
+        if (countWork) {
+            if (ea == hipSuccess) ea = dca_dev_malloc(reinterpret_cast<void**>(&dWork), kWorkSlots * sizeof(unsigned long long));
+            if (ea == hipSuccess) ea = hipMemsetAsync(dWork, 0, kWorkSlots * sizeof(unsigned long long), ctx->stream);
+        }
         if (ea == hipSuccess && ranked) {            // the site histogram only exists for the ranked order
             ea = dca_dev_malloc(reinterpret_cast<void**>(&dHist), (size_t)L * 32 * sizeof(uint32_t));
             if (ea == hipSuccess) ea = hipMemsetAsync(dHist, 0, (size_t)L * 32 * sizeof(uint32_t), ctx->stream);
@@ -304,7 +309,7 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int p
             hipLaunchKernelGGL(weights_count_kernel<5>, grid, dim3(256), 0, ctx->stream, dP, ctx->dCounts, N, L, G, thresh, tilesPerSide, part, parts, dWork);
         }
         hipError_t e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) {
+        if (e == hipSuccess && dWork) {
             std::vector<unsigned long long> slots(kWorkSlots);
             e = hipMemcpy(slots.data(), dWork, kWorkSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost);
             unsigned long long done = 0;
@@ -313,8 +318,8 @@ int dca_weights_compute(dca_ctx* ctx, double seqid, int compare_precision, int p
             const unsigned long long tp = (unsigned long long)tilesPerSide * (tilesPerSide + 1) / 2;
             ctx->weightsWork[0] = done;
             ctx->weightsWork[1] = (tp + parts - 1 - part) / parts * 4ull * (unsigned long long)G;
-            ctx->weightsPlanes = small ? 3 : 5;
         }
+        ctx->weightsPlanes = small ? 3 : 5;
         dca_dev_free(dWork);
         dca_dev_free(dP);
         dca_dev_free(dHist);
