@@ -323,6 +323,8 @@ def main():
     ap.add_argument("--no-rna", action="store_true")
     ap.add_argument("--no-modes", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="also time ONE full evaluation of the reference C++/OpenMP on all sequences (about a minute at config D) and report it beside the fit")
     args = ap.parse_args()
 
     # DCA_BENCH_SELFTEST: several ranks on ONE GPU (tests): "1" = gloo + torch.distributed hooks; "native" = the library's
@@ -692,6 +694,19 @@ def main():
             "note": "sent per rank and evaluation; 1-3: reduce-scatter(g) + all-gather(x) of the P-vector (1: as one all-reduce); "
                     "4: couplings up + gradient-table rows down, (L q)^2 / 2 (1 - 1/world) elements each way over the node, averaged over the ranks"}
         out["comm_selection"] = comm_selection
+        # the one-GPU prediction of this run (tools/scaling_prediction.py -> profiles/r06_scaling_prediction.json), if one was made for
+        # this workload: measured / predicted turns the first node run into a test of the model
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_scaling_prediction.json")) as fh:
+                pred = json.load(fh)
+            e = pred["worlds"].get(str(world), {})
+            ms = e.get("predicted_ms_per_step", {}).get(str(comm_selection["chosen_mode"]))
+            if pred.get("workload") == args.workload and args.precision == 32 and ms:
+                out["prediction"] = {"predicted_ms_per_step": ms, "measured_ms_per_step": out["ms_per_step"],
+                                     "measured_over_predicted": out["ms_per_step"] / ms, "all_schemes_predicted_ms_per_step": e.get("predicted_ms_per_step"),
+                                     "source": "profiles/r06_scaling_prediction.json (per-rank kernel time on ONE GPU + wire arithmetic)"}
+        except (OSError, ValueError, KeyError):
+            pass
 
     if world == 1 and not args.no_mfdca:
         # second half of the headline metric: mfDCA residue pairs/s, encoded MSA on host ->
@@ -801,6 +816,15 @@ def main():
         sample = min(sample, N)
         try:
             out["cpu_baseline"] = cpu_baseline(X, q, lh, lJ, max(evals / max(steps_done, 1), 1.0), sample)
+            if args.cpu_full:
+                from oracle import plm as oplm
+                threads = max(1, min(os.cpu_count() or 1, L))
+                t_full, kind_full = _time_reference_eval(oplm, X, q, lh, lJ, threads)
+                epi = max(evals / max(steps_done, 1), 1.0)
+                out["cpu_baseline"]["full_evaluation"] = {
+                    "seconds_per_evaluation": t_full, "value": 1.0 / (t_full * epi), "unit": "L-BFGS iterations/s", "cores": threads, "kind": kind_full,
+                    "fit_over_measured": out["cpu_baseline"]["seconds_per_evaluation"] / t_full,
+                    "sample": "ONE objective+gradient evaluation of the reference on ALL %d sequences (no extrapolation)" % N}
         except Exception as exc:   # pragma: no cover
             out["cpu_baseline"] = {"error": repr(exc)}
 
