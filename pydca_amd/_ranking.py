@@ -6,10 +6,32 @@ were re-made on every call although they depend on L alone (cached here, picked 
 call), and the cyclic garbage collector ran several full passes over the quarter of a million new tuples, none of which
 can be part of a cycle (paused for the construction)."""
 import gc
+import importlib.machinery
+import importlib.util
 import operator
+import os
 import threading
 
 import numpy as np
+
+
+def _load_fastrank():
+    """csrc/fastrank.c (built by `make -C pydca_amd/csrc` into lib/_fastrank.so): the same list in one C loop; None if it is not
+    there (the Python construction below is then used -- host logic either way)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_fastrank.so")
+    if os.environ.get("DCA_FASTRANK") == "0" or not os.path.exists(path):
+        return None
+    try:
+        loader = importlib.machinery.ExtensionFileLoader("_fastrank", path)
+        spec = importlib.util.spec_from_loader("_fastrank", loader)
+        mod = importlib.util.module_from_spec(spec)
+        loader.exec_module(mod)
+        return mod
+    except Exception:            # a NumPy / CPython ABI the module was not built for
+        return None
+
+
+_fast = _load_fastrank()
 
 _pair_tuples = {}
 _lock = threading.Lock()
@@ -20,8 +42,11 @@ def pair_tuples(L):
     with _lock:
         pairs = _pair_tuples.get(L)
         if pairs is None:
-            iu, ju = np.triu_indices(L, k=1)
-            pairs = list(zip(iu.tolist(), ju.tolist()))
+            if _fast is not None:
+                pairs = _fast.pair_tuples(int(L))
+            else:
+                iu, ju = np.triu_indices(L, k=1)
+                pairs = list(zip(iu.tolist(), ju.tolist()))
             if len(_pair_tuples) >= 4:
                 _pair_tuples.clear()
             _pair_tuples[L] = pairs
@@ -39,6 +64,8 @@ def ranked(scores, L, order=None):
     was_enabled = gc.isenabled()
     gc.disable()
     try:
+        if _fast is not None:
+            return _fast.ranked(pairs, np.ascontiguousarray(order, dtype=np.int32), np.ascontiguousarray(scores, dtype=np.float64))
         idx = order.tolist()
         picked = operator.itemgetter(*idx)(pairs) if len(idx) > 1 else (pairs[idx[0]],)
         return list(zip(picked, list(scores[order])))

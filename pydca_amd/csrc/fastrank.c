@@ -1,0 +1,91 @@
+/* The ranked list both classes return -- [((i, j), score), ...] -- built with the CPython / NumPy C API.
+ *
+ * The order comes from the device (csrc/rank.hip); what was left on the host is making L (L - 1) / 2 Python tuples, which at
+ * L = 500 cost 16 - 19 ms in pure Python (tolist + itemgetter + a list of NumPy scalars + zip) against 21 ms for the whole GPU
+ * chain of `mfdca compute_fn`.  Here it is one loop: the (i, j) tuples are shared objects picked from a per-L cache the caller
+ * keeps, the scores become numpy.float64 scalars as in the reference (meanfield_dca.py:940, plmdca.py:479), and each outer
+ * tuple is filled in place.  Host logic only -- nothing of the device path lives here; without this module pydca_amd/_ranking.py
+ * builds the same list in Python. */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
+#include <numpy/arrayobject.h>
+#include <numpy/arrayscalars.h>
+
+/* ranked(pairs: list of (i, j) tuples in pair order, order: int32[n] contiguous, scores: float64[m] contiguous) -> list of n tuples */
+static PyObject* fastrank_ranked(PyObject* self, PyObject* args)
+{
+    PyObject *pairs, *order_o, *scores_o;
+    if (!PyArg_ParseTuple(args, "O!OO", &PyList_Type, &pairs, &order_o, &scores_o)) return NULL;
+    PyArrayObject* order = (PyArrayObject*)PyArray_FROM_OTF(order_o, NPY_INT32, NPY_ARRAY_IN_ARRAY);
+    if (!order) return NULL;
+    PyArrayObject* scores = (PyArrayObject*)PyArray_FROM_OTF(scores_o, NPY_FLOAT64, NPY_ARRAY_IN_ARRAY);
+    if (!scores) { Py_DECREF(order); return NULL; }
+    const npy_intp n = PyArray_SIZE(order), m = PyArray_SIZE(scores);
+    const Py_ssize_t np_ = PyList_GET_SIZE(pairs);
+    const npy_int32* ord = (const npy_int32*)PyArray_DATA(order);
+    const double* sc = (const double*)PyArray_DATA(scores);
+    PyObject* out = PyList_New(n);
+    if (!out) goto fail;
+    for (npy_intp k = 0; k < n; ++k) {
+        const npy_int32 idx = ord[k];
+        if (idx < 0 || idx >= m || idx >= np_) { PyErr_SetString(PyExc_IndexError, "rank order points outside the score vector"); goto fail_out; }
+        PyObject* s = PyArrayScalar_New(Double);
+        if (!s) goto fail_out;
+        PyArrayScalar_ASSIGN(s, Double, sc[idx]);
+        PyObject* t = PyTuple_New(2);
+        if (!t) { Py_DECREF(s); goto fail_out; }
+        PyObject* pr = PyList_GET_ITEM(pairs, idx);
+        Py_INCREF(pr);
+        PyTuple_SET_ITEM(t, 0, pr);
+        PyTuple_SET_ITEM(t, 1, s);
+        PyList_SET_ITEM(out, k, t);
+    }
+    Py_DECREF(order); Py_DECREF(scores);
+    return out;
+fail_out:
+    Py_DECREF(out);
+fail:
+    Py_DECREF(order); Py_DECREF(scores);
+    return NULL;
+}
+
+/* pair_tuples(L) -> [(0, 1), (0, 2), ..., (L - 2, L - 1)] with ONE int object per site index */
+static PyObject* fastrank_pair_tuples(PyObject* self, PyObject* args)
+{
+    int L;
+    if (!PyArg_ParseTuple(args, "i", &L)) return NULL;
+    if (L < 0) { PyErr_SetString(PyExc_ValueError, "L < 0"); return NULL; }
+    PyObject** ints = (PyObject**)PyMem_Malloc(sizeof(PyObject*) * (size_t)(L > 0 ? L : 1));
+    if (!ints) return PyErr_NoMemory();
+    for (int i = 0; i < L; ++i) {
+        ints[i] = PyLong_FromLong(i);
+        if (!ints[i]) { for (int j = 0; j < i; ++j) Py_DECREF(ints[j]); PyMem_Free(ints); return NULL; }
+    }
+    const Py_ssize_t n = (Py_ssize_t)L * (L - 1) / 2;
+    PyObject* out = PyList_New(n > 0 ? n : 0);
+    Py_ssize_t k = 0;
+    for (int i = 0; out && i < L; ++i)
+        for (int j = i + 1; j < L; ++j) {
+            PyObject* t = PyTuple_New(2);
+            if (!t) { Py_CLEAR(out); break; }
+            Py_INCREF(ints[i]); Py_INCREF(ints[j]);
+            PyTuple_SET_ITEM(t, 0, ints[i]);
+            PyTuple_SET_ITEM(t, 1, ints[j]);
+            PyList_SET_ITEM(out, k++, t);
+        }
+    for (int i = 0; i < L; ++i) Py_DECREF(ints[i]);
+    PyMem_Free(ints);
+    return out;
+}
+
+static PyMethodDef methods[] = {
+    {"ranked", fastrank_ranked, METH_VARARGS, "ranked(pairs, order, scores) -> [((i, j), numpy.float64), ...]"},
+    {"pair_tuples", fastrank_pair_tuples, METH_VARARGS, "pair_tuples(L) -> [(0, 1), ..., (L-2, L-1)]"},
+    {NULL, NULL, 0, NULL}};
+static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_fastrank", NULL, -1, methods};
+PyMODINIT_FUNC PyInit__fastrank(void)
+{
+    import_array();
+    return PyModule_Create(&moduledef);
+}

@@ -359,3 +359,27 @@ def test_devices_argument_is_validated_like_the_other_arguments():
         plmdca.PlmDCA(data_file("toy_rna.fa"), "rna", devices="0;1")
     p = plmdca.PlmDCA(data_file("toy_rna.fa"), "rna", devices=[3])             # one entry: the same as device=3; nothing runs yet
     assert p.sequences_len == 10
+
+
+def test_ranked_list_c_module_equals_python_construction():
+    """pydca_amd/csrc/fastrank.c builds the ranked list [((i, j), numpy.float64), ...] in one C loop; the pure-Python construction of
+    pydca_amd/_ranking.py is the same list (ties in pair order, as sorted(..., reverse=True) on the pair-ordered list gives the
+    reference, meanfield_dca.py:940)."""
+    from pydca_amd import _ranking as R
+    assert R._fast is not None, "build it: make -C pydca_amd/csrc"
+    rng = np.random.default_rng(4)
+    for L in (2, 3, 17, 120):
+        n = L * (L - 1) // 2
+        s = np.round(rng.random(n), 2)                   # many ties
+        fast = R.ranked(s, L)
+        keep, R._fast = R._fast, None
+        try:
+            R._pair_tuples.clear()
+            slow = R.ranked(s, L)
+        finally:
+            R._fast = keep
+            R._pair_tuples.clear()
+        ref = sorted(zip(zip(*[a.tolist() for a in np.triu_indices(L, 1)]), s), key=lambda t: t[1], reverse=True)
+        assert fast == slow == ref
+        assert all(type(sc) is np.float64 and type(p) is tuple and type(p[0]) is int for p, sc in fast)
+    assert R.ranked(np.array([]), 1) == []
