@@ -107,7 +107,8 @@ int dca_sw_align(const char* a, int la, const char* b, int lb, const int* sub, i
 int dca_create(dca_ctx** out, int device, int precision /* DCA_F32 | DCA_F64 */);
 void dca_destroy(dca_ctx* ctx);
 /* X: N x L, 0-based codes < q, gap = q-1 (the C++ coding; the Python mfDCA layer
- * converts from the reference's 1-based coding).  Copies to the device. */
+ * converts from the reference's 1-based coding).  Copies to the device; the range of the codes is checked there (a code >= q
+ * is DCA_ERR_ARG with the element's position, and the context then holds NO alignment -- not the one it held before). */
 int dca_set_msa(dca_ctx* ctx, const uint8_t* X, int N, int L, int q);
 
 /* Sequence weights: PlmDCA::computeSeqsWeight (plmdca_numerics.cpp:611-671) when

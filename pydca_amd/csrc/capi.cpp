@@ -128,14 +128,21 @@ hipError_t dca_dev_free(void* p)
     } while (0)
 
 namespace {
-// dst[n][0..Ls) = src[n][0..L), zero padded
-__global__ void pad_rows_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int N, int L, int Ls)
+// dst[n][0..Ls) = src[n][0..L), zero padded; *maxCode = the largest code met (the range check of dca_set_msa, on the device: a
+// pass over the 25 MB of config D costs the host 2.5 ms)
+__global__ void pad_rows_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int N, int L, int Ls, unsigned* __restrict__ maxCode)
 {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= (size_t)N * Ls) return;
-    const size_t n = t / Ls;
-    const int c = (int)(t % Ls);
-    dst[t] = c < L ? src[n * L + c] : (uint8_t)0;
+    unsigned v = 0;
+    if (t < (size_t)N * Ls) {
+        const size_t n = t / Ls;
+        const int c = (int)(t % Ls);
+        v = c < L ? src[n * L + c] : 0u;
+        dst[t] = (uint8_t)v;
+    }
+    // wave maximum, one atomic per wave that holds a code above the smallest alphabet
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
+    if ((threadIdx.x & 63) == 0 && v >= 2) atomicMax(maxCode, v);
 }
 __global__ void unpad_rows_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int N, int L, int Ls)
 {
@@ -284,32 +291,34 @@ int dca_set_msa(dca_ctx* ctx, const uint8_t* X, int N, int L, int q)
 {
     CHECK_CTX(ctx);
     if (!X || N <= 0 || L <= 1 || q < 2 || q > 32) { dca_set_error("dca_set_msa: bad arguments"); return DCA_ERR_ARG; }
-    {
-        uint8_t mx = 0;                                   // vectorisable pass; the slow search only runs on failure
-        const size_t total = (size_t)N * L;
-        for (size_t k = 0; k < total; ++k) mx = X[k] > mx ? X[k] : mx;
-        if (mx >= q) {
-            size_t k = 0;
-            while (X[k] < q) ++k;
-            dca_set_error("dca_set_msa: code %d >= q at element %zu", (int)X[k], k);
-            return DCA_ERR_ARG;
-        }
-    }
     free_msa(ctx);
     ctx->N = ctx->L = ctx->q = ctx->Ls = 0;                // the context holds no alignment until everything below succeeded
     const int Ls = (int)round_up((size_t)L, 128);
     ctx->hX.clear();                                       // host copy is made on demand (dca_host_msa)
     // one contiguous copy + a repack kernel (a pitched hipMemcpy2D of narrow rows takes seconds)
     uint8_t* dTmp = nullptr;
+    unsigned* dMax = nullptr;
+    unsigned maxCode = 0;
     hipError_t e = dca_dev_malloc(reinterpret_cast<void**>(&ctx->dX), (size_t)N * Ls);
     if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&dTmp), (size_t)N * L);
+    if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&dMax), sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(dMax, 0, sizeof(unsigned), ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(dTmp, X, (size_t)N * L, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         const size_t total = (size_t)N * Ls;
-        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dTmp, ctx->dX, N, L, Ls);
-        e = hipStreamSynchronize(ctx->stream);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dTmp, ctx->dX, N, L, Ls, dMax);
+        e = hipMemcpyAsync(&maxCode, dMax, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
     dca_dev_free(dTmp);
+    dca_dev_free(dMax);
+    if (e == hipSuccess && maxCode >= (unsigned)q) {      // the slow search only runs on failure
+        size_t k = 0;
+        while (X[k] < q) ++k;
+        free_msa(ctx);
+        dca_set_error("dca_set_msa: code %d >= q at element %zu", (int)X[k], k);
+        return DCA_ERR_ARG;
+    }
     if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&ctx->dCounts), (size_t)N * sizeof(uint32_t));
     if (e == hipSuccess) e = dca_dev_malloc(reinterpret_cast<void**>(&ctx->dWd), (size_t)N * sizeof(double));
     if (e != hipSuccess) {

@@ -875,3 +875,20 @@ def test_mfdca_command_line_devices_equals_one_gpu(tmp_path):
     p2, s2 = _scores_of(str(tmp_path / "two" / "MFDCA_apc_fn_scores_MSA_RF00167.txt"))
     assert p1 == p2
     np.testing.assert_allclose(s2, s1, rtol=1e-10, atol=1e-14)
+
+
+def test_set_msa_rejects_codes_outside_the_alphabet():
+    """The range check of dca_set_msa runs on the device (fused into the row-padding kernel); the error names the first bad element."""
+    from pydca_amd import _lib as L_
+    rng = np.random.default_rng(2)
+    X = rng.integers(0, 5, size=(300, 77), dtype=np.uint8)
+    ctx = L_.Context(0, L_.DCA_F32)
+    ctx.set_msa(X, 5)
+    bad = X.copy()
+    bad[123, 45] = 5
+    with pytest.raises(L_.DcaBackendError) as ei:
+        ctx.set_msa(bad, 5)
+    assert ei.value.code == L_.DCA_ERR_ARG and "element %d" % (123 * 77 + 45) in str(ei.value)
+    ctx.set_msa(X, 5)                     # the context is usable again
+    assert ctx.compute_weights(0.8).shape == (300,)
+    ctx.close()
