@@ -253,6 +253,30 @@ int dca_plm_lbfgs_iterate(dca_ctx* ctx, int iterations, dca_plm_stats* stats_out
  * (lbfgs() runs to completion, lbfgs.cpp:248-644); needed because dca_plm_lbfgs_iterate is resumable. */
 int dca_plm_lbfgs_end(dca_ctx* ctx);
 
+/* ------------------------------------------------------------------ one call
+ * The reference's single entry plmdcaBackend(biomolecule, num_site_states, msa_file, seqs_len, seqid, lambda_h, lambda_J,
+ * max_iteration, num_threads, verbose) (plmdcaBackend.cpp:151-201) with a device list in place of num_threads, either a file (one
+ * sequence per line, the reference's reader and its first-occurrence dedup) or a pre-encoded alignment, and what the reference
+ * drops -- status, iterations, evaluations, fx, norms, seconds -- in dca_plm_stats.  Several devices: one rank per device as one
+ * host thread each (no helper process), column-strip decomposition over the library's RCCL communicators; float64 gives the
+ * single-device bytes.  x_out: P = L q + L (L - 1) / 2 q^2 elements of x_dtype (DCA_F32 | DCA_F64), packed as
+ * plmdca_numerics.cpp:467-480.  Errors as everywhere: DCA_ERR_* and dca_last_error(). */
+typedef struct dca_plm_args {
+    int biomolecule;             /* DCA_BIOMOLECULE_PROTEIN (q = 21) | DCA_BIOMOLECULE_RNA (q = 5) */
+    const char* msa_file;        /* one sequence per line (as plmdcaBackend reads it), or NULL */
+    const uint8_t* msa;          /* ... or num_seqs x seqs_len codes < q, gap = q - 1 (as dca_set_msa takes them) */
+    int num_seqs, seqs_len;      /* seqs_len is needed with a file as well (as plmdcaBackend's seqs_len) */
+    float seqid, lambda_h, lambda_J;
+    int max_iterations;          /* the reference's cap (0: unlimited) */
+    int precision;               /* DCA_F32: the reference's arithmetic; DCA_F64: the parity mode */
+    const int* devices;          /* GPU indices, one rank each; NULL / num_devices 0: device 0 */
+    int num_devices;
+    int exchange_scheme;         /* 0 (default) or 4: column strips */
+    const char* rccl_path;       /* NULL: the librccl next to the HIP runtime in use (DCA_RCCL_PATH overrides) */
+    int verbose;                 /* the reference's per-iteration lines on stderr (rank 0) */
+} dca_plm_args;
+int dca_plm_run(const dca_plm_args* args, void* x_out, int x_dtype, dca_plm_stats* stats_out);
+
 /* Frobenius-norm scores of the current x: PlmDCA.get_couplings_no_gap_state +
  * compute_sorted_FN / compute_sorted_FN_APC (plmdca.py:246-268, :437-524), in pair
  * order (0,1),(0,2)...; sorting is left to the host. */

@@ -18,6 +18,7 @@ DCA_OK = 0
 DCA_ERR_ARG, DCA_ERR_IO, DCA_ERR_RESIDUE = -1, -2, -3
 DCA_ERR_NOT_SPD = -7
 DCA_F32, DCA_F64 = 32, 64
+DCA_BIOMOLECULE_PROTEIN, DCA_BIOMOLECULE_RNA = 1, 2
 CARRY_EXACT, CARRY_CHUNKED, CARRY_SERIAL = 0, 1, 2
 PROTEIN, RNA = 1, 2
 
@@ -124,6 +125,7 @@ def lib():
         "dca_mf_corr_from_freqs": (i, [vp, vp, vp, i, i, vp]),
         "dca_spd_inverse": (i, [vp, vp, i, vp]),
         "dca_comm_abort": (i, [vp]),
+        "dca_plm_run": (i, [vp, vp, i, vp]),
         "dca_scores_order": (i, [vp, vp, i]),
         "dca_sw_scores": (i, [C.c_char_p, i, C.c_char_p, vp, i, vp, i, i, vp]),
         "dca_sw_align": (i, [C.c_char_p, i, C.c_char_p, i, vp, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p,
@@ -154,7 +156,39 @@ EXPORTS = ["dca_weights_work", "dca_compute_weights_sharded", "dca_weights_parti
            "dca_mf_single_site_freqs",
            "dca_mf_pair_site_freqs", "dca_mf_corr_mat", "dca_mf_couplings", "dca_mf_scores", "dca_mf_run",
            "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_sw_scores", "dca_sw_align", "dca_scores_order", "dca_set_profiling", "dca_get_kernel_time",
-           "dca_reset_kernel_times", "plmdcaBackend", "freeFieldsAndCouplings"]
+           "dca_reset_kernel_times", "dca_plm_run", "plmdcaBackend", "freeFieldsAndCouplings"]
+
+
+class PlmArgs(C.Structure):
+    """dca_plm_args (include/dca_hip.h)"""
+    _fields_ = [("biomolecule", C.c_int), ("msa_file", C.c_char_p), ("msa", C.c_void_p), ("num_seqs", C.c_int), ("seqs_len", C.c_int),
+                ("seqid", C.c_float), ("lambda_h", C.c_float), ("lambda_J", C.c_float), ("max_iterations", C.c_int), ("precision", C.c_int),
+                ("devices", C.POINTER(C.c_int)), ("num_devices", C.c_int), ("exchange_scheme", C.c_int), ("rccl_path", C.c_char_p),
+                ("verbose", C.c_int)]
+
+
+def plm_run(biomolecule, seqs_len, msa_file=None, msa=None, seqid=0.8, lambda_h=1.0, lambda_J=20.0, max_iterations=100, precision=DCA_F32,
+            devices=None, exchange_scheme=0, rccl_path=None, verbose=False, dtype=np.float32):
+    """dca_plm_run, the library's one-call plmDCA entry (what a C host would call) -> (x, PlmStats).  msa: uint8[N, L] codes."""
+    q = 21 if biomolecule == DCA_BIOMOLECULE_PROTEIN else 5
+    a = PlmArgs()
+    a.biomolecule, a.seqs_len = int(biomolecule), int(seqs_len)
+    a.msa_file = os.fsencode(msa_file) if msa_file else None
+    keep = None
+    if msa is not None:
+        keep = np.ascontiguousarray(msa, dtype=np.uint8)
+        a.msa, a.num_seqs = keep.ctypes.data, int(keep.shape[0])
+    a.seqid, a.lambda_h, a.lambda_J = float(seqid), float(lambda_h), float(lambda_J)
+    a.max_iterations, a.precision, a.exchange_scheme, a.verbose = int(max_iterations), int(precision), int(exchange_scheme), int(bool(verbose))
+    devs = (C.c_int * len(devices))(*devices) if devices else None
+    a.devices, a.num_devices = devs, len(devices) if devices else 0
+    a.rccl_path = os.fsencode(rccl_path) if rccl_path else None
+    L = int(seqs_len)
+    x = np.zeros(L * q + L * (L - 1) // 2 * q * q, dtype=dtype)
+    st = PlmStats()
+    check(lib().dca_plm_run(C.byref(a), _ptr(x), DCA_F64 if np.dtype(dtype) == np.float64 else DCA_F32, C.byref(st)))
+    del keep
+    return x, st
 
 
 def comm_unique_id(rccl_path=None):

@@ -892,3 +892,21 @@ def test_set_msa_rejects_codes_outside_the_alphabet():
     ctx.set_msa(X, 5)                     # the context is usable again
     assert ctx.compute_weights(0.8).shape == (300,)
     ctx.close()
+
+
+def test_dca_plm_run_one_call_entry():
+    """SURVEY section 8 b1's richer entry, `int dca_plm_run(const dca_plm_args*, x_out, dtype, dca_plm_stats*)`: through ctypes as a C
+    host would call it.  One device: the bytes and the status / iterations / evaluations of the stage API.  devices = {0, 0} and
+    {0, 0, 0}: ranks as host threads over the stand-in librccl -- the float64 result of one GPU (the optimiser's dot products are
+    summed per rank and then over the ranks in double-double: usually to the last bit, bounded at 1e-12).  From a file in
+    float32: the bytes of the drop-in symbol plmdcaBackend.  Failing ranks and missing files are error codes, not hangs."""
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "plm_run_threads.py")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    print("\n", d)
+    assert d["one_device_bytes_equal"] and d["one_device_stats"], d
+    assert d["two_ranks_stats"] and d["two_ranks_max_rel"] < 1e-12 and d["three_ranks_max_rel"] < 1e-12, d
+    assert d["file_float32_equals_dropin"], d
+    assert d["bad_device"] != "no error" and d["no_file"][0] == -2, d
