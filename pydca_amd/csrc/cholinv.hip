@@ -2398,24 +2398,24 @@ __global__ void probe_wait_kernel(int* flag, int* result, long long ticks)
     const long long t0 = wall_clock64();
     int seen = 0;
     while (wall_clock64() - t0 < ticks) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { seen = 1; break; }
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { seen = 1; break; }
         __builtin_amdgcn_s_sleep(8);
     }
-    *result = seen;
+    __hip_atomic_store(result, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void probe_set_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void probe_set_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 static bool streams_overlap(SideSet* S, hipStream_t a, hipStream_t b)
 {
     if (a == b) return false;
-    if (!S->probe && hipMalloc(reinterpret_cast<void**>(&S->probe), 2 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return true; }
-    if (hipMemset(S->probe, 0, 2 * sizeof(int)) != hipSuccess) return true;
+    // flag and result live in pinned host memory the kernels reach directly: no memset / copy calls around the two launches
+    if (!S->probe && hipHostMalloc(reinterpret_cast<void**>(&S->probe), 2 * sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); S->probe = nullptr; return true; }
+    volatile int* h = S->probe;
+    h[0] = 0; h[1] = 0;
     hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, a, S->probe, S->probe + 1, 30000LL);      // wall clock: 100 MHz
     hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, b, S->probe);
-    int seen = 1;
     if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return true;
-    if (hipMemcpy(&seen, S->probe + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return true;
-    return seen != 0;
+    return h[1] != 0;
 }
 // two streams of the set that overlap with `chain` and with each other (cached per chain stream); the set's first two if none are found
 static void sweep_streams(SideSet* S, hipStream_t chain, hipStream_t& rest, hipStream_t& side)
@@ -2435,8 +2435,8 @@ static void sweep_streams(SideSet* S, hipStream_t chain, hipStream_t& rest, hipS
             S->extra.push_back(ns);
             cand.push_back(ns);
         }
-        if (!streams_overlap(S, chain, cand[i]) || !streams_overlap(S, cand[i], chain)) continue;
-        if (good.size() == 1 && (!streams_overlap(S, good[0], cand[i]) || !streams_overlap(S, cand[i], good[0]))) continue;
+        if (!streams_overlap(S, chain, cand[i])) continue;            // (two streams on one queue fail in whichever order they are asked)
+        if (good.size() == 1 && !streams_overlap(S, good[0], cand[i])) continue;
         good.push_back(cand[i]);
     }
     if (good.size() == 2) { rest = good[0]; side = good[1]; }
