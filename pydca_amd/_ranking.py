@@ -34,6 +34,7 @@ def _load_fastrank():
 _fast = _load_fastrank()
 
 _pair_tuples = {}
+_seen_once = set()
 _lock = threading.Lock()
 
 
@@ -58,6 +59,20 @@ def ranked(scores, L, order=None):
     numpy scalars, as in the reference."""
     if order is None:
         order = np.argsort(-scores, kind='stable')
+    if _fast is not None and L not in _pair_tuples:
+        # the FIRST list of this process for L: the (i, j) tuples are made on the fly (a command line ranks once: building the
+        # cache first would cost as much again); the cache is made when a second list is asked for
+        with _lock:
+            seen = L in _seen_once
+            _seen_once.add(L)
+        if not seen:
+            was_enabled = gc.isenabled()
+            gc.disable()
+            try:
+                return _fast.ranked(None, np.ascontiguousarray(order, dtype=np.int32), np.ascontiguousarray(scores, dtype=np.float64), int(L))
+            finally:
+                if was_enabled:
+                    gc.enable()
     pairs = pair_tuples(L)
     if len(pairs) == 0:
         return []

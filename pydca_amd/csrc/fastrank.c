@@ -12,21 +12,38 @@
 #include <numpy/arrayobject.h>
 #include <numpy/arrayscalars.h>
 
-/* ranked(pairs: list of (i, j) tuples in pair order, order: int32[n] contiguous, scores: float64[m] contiguous) -> list of n tuples */
+/* ranked(pairs: list of (i, j) tuples in pair order -- or None with L given: the tuples are then made on the fly, which is what a
+ * process that ranks ONCE wants --, order: int32[n] contiguous, scores: float64[m] contiguous, L = 0) -> list of n tuples */
 static PyObject* fastrank_ranked(PyObject* self, PyObject* args)
 {
     PyObject *pairs, *order_o, *scores_o;
-    if (!PyArg_ParseTuple(args, "O!OO", &PyList_Type, &pairs, &order_o, &scores_o)) return NULL;
+    int L = 0;
+    if (!PyArg_ParseTuple(args, "OOO|i", &pairs, &order_o, &scores_o, &L)) return NULL;
+    if (pairs == Py_None) pairs = NULL;
+    else if (!PyList_Check(pairs)) { PyErr_SetString(PyExc_TypeError, "pairs: list or None"); return NULL; }
+    if (!pairs && L < 2) return PyList_New(0);
     PyArrayObject* order = (PyArrayObject*)PyArray_FROM_OTF(order_o, NPY_INT32, NPY_ARRAY_IN_ARRAY);
     if (!order) return NULL;
     PyArrayObject* scores = (PyArrayObject*)PyArray_FROM_OTF(scores_o, NPY_FLOAT64, NPY_ARRAY_IN_ARRAY);
     if (!scores) { Py_DECREF(order); return NULL; }
     const npy_intp n = PyArray_SIZE(order), m = PyArray_SIZE(scores);
-    const Py_ssize_t np_ = PyList_GET_SIZE(pairs);
+    const Py_ssize_t np_ = pairs ? PyList_GET_SIZE(pairs) : (Py_ssize_t)L * (L - 1) / 2;
     const npy_int32* ord = (const npy_int32*)PyArray_DATA(order);
     const double* sc = (const double*)PyArray_DATA(scores);
+    PyObject** ints = NULL;          /* on-the-fly mode: one int object per site index, the first pair index of every i */
+    Py_ssize_t* first = NULL;
     PyObject* out = PyList_New(n);
     if (!out) goto fail;
+    if (!pairs) {
+        ints = (PyObject**)PyMem_Calloc((size_t)L, sizeof(PyObject*));
+        first = (Py_ssize_t*)PyMem_Malloc(sizeof(Py_ssize_t) * (size_t)L);
+        if (!ints || !first) { PyErr_NoMemory(); goto fail_out; }
+        for (int i = 0; i < L; ++i) {
+            ints[i] = PyLong_FromLong(i);
+            if (!ints[i]) goto fail_out;
+            first[i] = (Py_ssize_t)i * (2 * (Py_ssize_t)L - i - 1) / 2;      /* pairs (0, .) ... (i - 1, .) come before (i, i + 1) */
+        }
+    }
     for (npy_intp k = 0; k < n; ++k) {
         const npy_int32 idx = ord[k];
         if (idx < 0 || idx >= m || idx >= np_) { PyErr_SetString(PyExc_IndexError, "rank order points outside the score vector"); goto fail_out; }
@@ -35,16 +52,30 @@ static PyObject* fastrank_ranked(PyObject* self, PyObject* args)
         PyArrayScalar_ASSIGN(s, Double, sc[idx]);
         PyObject* t = PyTuple_New(2);
         if (!t) { Py_DECREF(s); goto fail_out; }
-        PyObject* pr = PyList_GET_ITEM(pairs, idx);
-        Py_INCREF(pr);
+        PyObject* pr;
+        if (pairs) { pr = PyList_GET_ITEM(pairs, idx); Py_INCREF(pr); }
+        else {
+            int lo = 0, hi = L - 2;                  /* the i with first[i] <= idx < first[i + 1] */
+            while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (first[mid] <= idx) lo = mid; else hi = mid - 1; }
+            const int i = lo, j = i + 1 + (int)(idx - first[i]);
+            pr = PyTuple_New(2);
+            if (!pr) { Py_DECREF(s); Py_DECREF(t); goto fail_out; }
+            Py_INCREF(ints[i]); Py_INCREF(ints[j]);
+            PyTuple_SET_ITEM(pr, 0, ints[i]);
+            PyTuple_SET_ITEM(pr, 1, ints[j]);
+        }
         PyTuple_SET_ITEM(t, 0, pr);
         PyTuple_SET_ITEM(t, 1, s);
         PyList_SET_ITEM(out, k, t);
     }
+    if (ints) { for (int i = 0; i < L; ++i) Py_XDECREF(ints[i]); PyMem_Free(ints); }
+    PyMem_Free(first);
     Py_DECREF(order); Py_DECREF(scores);
     return out;
 fail_out:
-    Py_DECREF(out);
+    Py_XDECREF(out);
+    if (ints) { for (int i = 0; i < L; ++i) Py_XDECREF(ints[i]); PyMem_Free(ints); }
+    PyMem_Free(first);
 fail:
     Py_DECREF(order); Py_DECREF(scores);
     return NULL;

@@ -371,7 +371,11 @@ def test_ranked_list_c_module_equals_python_construction():
     for L in (2, 3, 17, 120):
         n = L * (L - 1) // 2
         s = np.round(rng.random(n), 2)                   # many ties
-        fast = R.ranked(s, L)
+        R._seen_once.discard(L)
+        R._pair_tuples.pop(L, None)
+        first = R.ranked(s, L)                           # the first list of a process for this L: tuples made on the fly
+        fast = R.ranked(s, L)                            # the second: from the cache
+        assert first == fast and L in R._pair_tuples
         keep, R._fast = R._fast, None
         try:
             R._pair_tuples.clear()
