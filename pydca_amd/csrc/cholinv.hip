@@ -56,6 +56,7 @@ struct GemmArgs {
     // product (alpha, beta = 0) to C + z * sliceStride -- summed in slice order by gemm_slices_reduce_kernel
     int kSlices = 1, kChunk = 0;
     size_t sliceStride = 0;
+    const double* Cin = nullptr; int ldcin = 0;   // beta != 0: the addend is read from here instead of from C (C is then written only)
 };
 
 // BK = 16: the throughput form (35 KB of LDS, three workgroups per CU).  BK = 64: for the many products of
@@ -257,7 +258,7 @@ void gemm_nt_f64_kernel(GemmArgs g)
                 if (g.lowerOnly && j > i) continue;
                 double v = g.alpha * acc[m][n][r];
                 double* cp = g.C + (size_t)i * g.ldc + j;
-                if (g.beta != 0.0) v += g.beta * (*cp);
+                if (g.beta != 0.0) v += g.beta * (g.Cin ? g.Cin[(size_t)i * g.ldcin + j] : *cp);
                 *cp = v;
                 if (g.Cm && !(g.lowerOnly && i == j)) g.Cm[(size_t)j * g.ldcm + i] = v;
             }
@@ -356,7 +357,7 @@ __device__ __forceinline__ void gemm_nt_f64_small_tile(const GemmArgs& g, int bx
         if (g.lowerOnly && j > i) continue;
         double v = g.alpha * acc[r];
         double* cp = g.C + (size_t)i * g.ldc + j;
-        if (g.beta != 0.0) v += g.beta * (*cp);
+        if (g.beta != 0.0) v += g.beta * (g.Cin ? g.Cin[(size_t)i * g.ldcin + j] : *cp);
         *cp = v;
         if (g.Cm && !(g.lowerOnly && i == j)) g.Cm[(size_t)j * g.ldcm + i] = v;
     }
@@ -570,7 +571,7 @@ void gemm_nt_f64_dma_kernel(GemmArgs g)
                 if (g.lowerOnly && j > i) continue;
                 double v = g.alpha * acc[m][n][r];
                 double* cp = Cout + (size_t)i * g.ldc + j;
-                if (g.beta != 0.0) v += g.beta * (*cp);
+                if (g.beta != 0.0) v += g.beta * (g.Cin ? g.Cin[(size_t)i * g.ldcin + j] : *cp);
                 *cp = v;
                 if (g.Cm && !(g.lowerOnly && i == j)) g.Cm[(size_t)j * g.ldcm + i] = v;
             }
@@ -1573,6 +1574,8 @@ struct SideSet {
     std::vector<hipStream_t> extra;
     hipStream_t selFor = nullptr, selRest = nullptr, selSide = nullptr;
     int* probe = nullptr;             // device: flag, result
+    unsigned* reserved = nullptr;     // device: bit per CU (cu_key()), the CUs the update workgroups leave to the chain's kernels
+    int reservedPerXcd = 0;
     hipEvent_t fork[kSideDepths] = {}, join[kSideDepths] = {}, mid[kSideDepths] = {};
     int device = -1;
     bool busy = false;
@@ -2121,7 +2124,16 @@ struct SweepArgs {
     int dg0, dgN;                  // diagonal block of the panel after the next: its lower tiles belong to PRIO, not to REST
     int nTiles;                    // length of the tile list (entries that decode to no tile are passed over)
     int* ctr;                      // 8 zeroed counters: the list is cut into 8 chunks, chunk x is handed out to the workgroups of XCD x first
+    const unsigned* reserved = nullptr;   // bit per CU (cu_key()): a workgroup that finds itself on a reserved CU returns at once
 };
+
+// the CU this wave runs on: XCC_ID (hwreg 20) and SE_ID / SH_ID / CU_ID of HW_ID (hwreg 4): bits 15:13 / 12 / 11:8
+__device__ __forceinline__ unsigned cu_key()
+{
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+    return (xcc & 7) * 128 + ((hw >> 8) & 0xff) % 128;
+}
 
 // tile list entry t -> tile (ti, tj), tj <= ti
 __device__ __forceinline__ bool sweep_tile_of(const SweepArgs& g, int t, int& ti, int& tj)
@@ -2188,6 +2200,10 @@ void sweep_update_kernel(SweepArgs g)
     const int fr = lane & 15, fg = lane >> 4, swz = (fr >> 1) & 7;
     const int nk = g.w / BK;
     __shared__ int s_tile;
+    if (g.reserved) {
+        const unsigned key = cu_key();
+        if ((g.reserved[key >> 5] >> (key & 31)) & 1) return;
+    }
     int q = (int)blockIdx.x % 8, tries = 0;                         // thread 0: the chunk it draws from, chunks found empty
 
     for (;;) {
@@ -2443,7 +2459,49 @@ static void sweep_streams(SideSet* S, hipStream_t chain, hipStream_t& rest, hipS
     S->selFor = chain; S->selRest = rest; S->selSide = side;
 }
 
-struct SweepCfg { int minN, wide, narrow, wideMinN, cap, stages, perCu, maskCus, prioCap; };
+// CUs of the chain's own (round 6).  A CU-masked stream dispatches slowly (section 4 of DESIGN.md); instead the update
+// kernel looks up the CU it finds itself on and returns at once on a reserved one.  The dispatcher hands a workgroup to a
+// shader engine before it looks for room (measured: with fewer reserved CUs than engines a one-workgroup kernel waits 100 - 140 us
+// beside a full update launch, with one per engine 42 us = alone), so the unit is one CU per engine = 4 per XCD = 32.
+// Which CU ids exist is probed once per set: 4096 workgroups of 64 KB LDS that stay 20 us each visit every CU.
+__global__ __launch_bounds__(256) void cu_probe_kernel(unsigned* present)
+{
+    extern __shared__ unsigned char dca_gemm_smem[];
+    if (threadIdx.x == 0) {
+        const unsigned key = cu_key();
+        atomicOr(&present[key >> 5], 1u << (key & 31));
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < 2000) {}
+        if (dca_gemm_smem[0] == 77 && t0 == 1) present[0] = 0;
+    }
+}
+static const unsigned* sweep_reserved_cus(SideSet* S, hipStream_t st, int perXcd)
+{
+    if (perXcd <= 0) return nullptr;
+    if (S->reserved && S->reservedPerXcd == perXcd) return S->reserved;
+    if (!S->reserved && hipMalloc(reinterpret_cast<void**>(&S->reserved), 32 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); S->reserved = nullptr; return nullptr; }
+    unsigned present[32] = {}, res[32] = {};
+    if (hipMemsetAsync(S->reserved, 0, sizeof present, st) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(cu_probe_kernel, dim3(4096), dim3(256), 65536, st, S->reserved);
+    if (hipMemcpyAsync(present, S->reserved, sizeof present, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    // per XCD: engine by engine the lowest CU not yet taken, until perXcd are (cu_key(): 32 ids per engine, four engines per XCD)
+    for (int x = 0; x < 8; ++x) {
+        int taken = 0;
+        for (int round = 0; round < 32 && taken < perXcd; ++round)
+            for (int se = 0; se < 4 && taken < perXcd; ++se)
+                for (int id = 0; id < 32; ++id) {
+                    const unsigned key = x * 128 + se * 32 + id;
+                    if (!((present[key >> 5] >> (key & 31)) & 1) || ((res[key >> 5] >> (key & 31)) & 1)) continue;
+                    res[key >> 5] |= 1u << (key & 31); ++taken;
+                    break;
+                }
+    }
+    if (hipMemcpyAsync(S->reserved, res, sizeof res, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    S->reservedPerXcd = perXcd;
+    return S->reserved;
+}
+
+struct SweepCfg { int minN, wide, narrow, wideMinN, cap, stages, perCu, maskCus, prioCap, reserve, reserveMaxN, factorMaxN; };
 void sweep_update_launch(hipStream_t stream, int G, int stages, int perCu, const SweepArgs& g)
 {
     // dynamic LDS: what the stages need; with perCu == 1 never less than 96 KB, so that a CU takes ONE of these workgroups
@@ -2456,8 +2514,11 @@ void sweep_update_launch(hipStream_t stream, int G, int stages, int perCu, const
 static const SweepCfg& sweep_cfg()
 {
     static const SweepCfg c = [] {
-        SweepCfg v{2560, 512, 256, 7000, 0, 2, 2, 0, 64};      // measured (ms, sweep / three-phase): n = 2048 1.43 / 1.30, 3072 2.16 / 2.31, 4032 3.41 / 3.55, 6016 6.46 / 7.54, 8000 12.25 / 13.25, 10 048 20.6 / 22.4, 12 032 34.0 / 34.9
+        SweepCfg v{2560, 512, 256, 7000, 0, 2, 2, 0, 64, 0, 7000, 4500};      // measured (ms, sweep / three-phase): n = 2048 1.43 / 1.30, 3072 2.16 / 2.31, 4032 3.41 / 3.55, 6016 6.46 / 7.54, 8000 12.25 / 13.25, 10 048 20.6 / 22.4, 12 032 34.0 / 34.9
         if (const char* e = getenv("DCA_SWEEP_PRIO_CAP")) v.prioCap = std::max(8, atoi(e) / 8 * 8);
+        if (const char* e = getenv("DCA_SWEEP_RESERVE")) v.reserve = std::max(0, std::min(16, atoi(e)));          // CUs per XCD left to the chain's kernels
+        if (const char* e = getenv("DCA_SWEEP_RESERVE_MAX_N")) v.reserveMaxN = atoi(e);
+        if (const char* e = getenv("DCA_SWEEP_FACTOR_MAX_N")) v.factorMaxN = atoi(e);       // below: next pivot block from X (F F^T), P on the side stream
         if (const char* e = getenv("DCA_SWEEP_MIN")) v.minN = atoi(e);
         if (const char* e = getenv("DCA_SWEEP")) if (atoi(e) == 0) v.minN = INT_MAX;
         if (const char* e = getenv("DCA_SWEEP_PANEL")) v.wide = v.narrow = std::max(128, atoi(e) / 128 * 128);
@@ -2479,6 +2540,7 @@ int sweep_kernels_prepare(int device)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_update_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 16 * 8));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_update_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 16 * 8));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_update_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 16 * 8));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cu_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     done.push_back(device);
     return DCA_OK;
 }
@@ -2509,7 +2571,16 @@ int cholinv_sweep(dca_ctx* ctx, double* A, int n, double* work, int* dInfo, Side
     int bulkCus = 256;
     if (cfg.maskCus > 0 && cfg.maskCus < 256 && side_set_masked(side, cfg.maskCus)) { rest = side->masked[0]; sd = side->masked[1]; bulkCus = cfg.maskCus; }
     const int capAll = std::max(1, cfg.perCu) * bulkCus;
-    const int capRest = cfg.cap > 0 ? cfg.cap : capAll * 3 / 4 / 8 * 8;           // the rest launch leaves room for the side stream's and the chain's kernels
+    int capRest = cfg.cap > 0 ? cfg.cap : capAll * 3 / 4 / 8 * 8;           // the rest launch leaves room for the side stream's and the chain's kernels
+    int capPrio = cfg.prioCap;
+    const bool factorForm = n < cfg.factorMaxN;
+    const unsigned* reserved = n < cfg.reserveMaxN ? sweep_reserved_cus(side, chain, cfg.reserve) : nullptr;
+    if (reserved) {
+        // the launches are sized so that the workgroups that stay fill the CUs that are not reserved
+        const int freeCus = 256 - 8 * cfg.reserve;
+        if (cfg.cap <= 0) capRest = (2 * 256 - cfg.prioCap) / 8 * 8;
+        capPrio = cfg.prioCap * 256 / freeCus / 8 * 8;
+    }
     // events of step p: 0 P is there (chain), 1 prio tiles done (side), 2 the chain has read the pivot panel in M (chain), 3 W is there
     // (side), 4 rest done (rest)
     constexpr int EV = 5;
@@ -2548,29 +2619,42 @@ int cholinv_sweep(dca_ctx* ctx, double* A, int n, double* work, int* dInfo, Side
         // ---- chain: X = inv(chol(S)), P = X^T X
         tr.mark(chain, "chain: pivot block begins", p);
         if ((rc = cholinv_rec(ctx, Sp, B, w, c, chainWs, dInfo, nullptr)) != DCA_OK) break;
-        if ((rc = launch_gemm(ctx, GemmArgs{Sp, B, MASK_UPPER, Sp, B, MASK_UPPER, Pp, B, Pp, B, w, w, w, 1.0, 0.0, 1})) != DCA_OK) break;
+        // chain-bound sizes (factorForm): P = X^T X is the side stream's, the chain goes on from X itself
+        const GemmArgs pArgs{Sp, B, MASK_UPPER, Sp, B, MASK_UPPER, Pp, B, Pp, B, w, w, w, 1.0, 0.0, 1};
+        if (!factorForm && (rc = launch_gemm(ctx, pArgs)) != DCA_OK) break;
         tr.mark(chain, "chain: P done", p);
         SWEEP_HIP(hipEventRecord(ev(0, p), chain));
         if (!last) {
-            // the next pivot block from this one: S' = M[J', J'] - (M[J', J] P) M[J', J]^T
+            // the next pivot block from this one: S' = M[J', J'] - (M[J', J] P) M[J', J]^T, or with F = M[J', J] X^T (X lower: half
+            // the flop, one product less on the chain) S' = M[J', J'] - F F^T
             if (p >= 1) SWEEP_HIP(hipStreamWaitEvent(chain, ev(1, p - 1), 0));
             const double* MnJ = A + (size_t)c1 * ld + c;
-            if ((rc = launch_gemm(ctx, GemmArgs{MnJ, ld, MASK_NONE, Pp, B, MASK_NONE, Wn, B, nullptr, 0, w1, w, w, 1.0, 0.0, 0})) != DCA_OK) break;
-            copy_block(S[(p + 1) & 1], B, A + (size_t)c1 * ld + c1, w1, w1);
-            if ((rc = launch_gemm(ctx, GemmArgs{Wn, B, MASK_NONE, MnJ, ld, MASK_NONE, S[(p + 1) & 1], B, nullptr, 0, w1, w1, w, -1.0, 1.0, 1})) != DCA_OK) break;
+            if (factorForm) rc = launch_gemm(ctx, GemmArgs{MnJ, ld, MASK_NONE, Sp, B, MASK_LOWER, Wn, B, nullptr, 0, w1, w, w, 1.0, 0.0, 0, WALK_COLUMNS_REVERSED});
+            else rc = launch_gemm(ctx, GemmArgs{MnJ, ld, MASK_NONE, Pp, B, MASK_NONE, Wn, B, nullptr, 0, w1, w, w, 1.0, 0.0, 0});
+            if (rc != DCA_OK) break;
+            // (the addend comes straight from M: the block is not copied first ...
+            GemmArgs sArgs{Wn, B, MASK_NONE, factorForm ? Wn : MnJ, factorForm ? B : ld, MASK_NONE, S[(p + 1) & 1], B, nullptr, 0, w1, w1, w, -1.0, 1.0, 1};
+            // ... at the chain-bound sizes (n = 4032: 3.40 -> 3.31 with F, -> 3.20 ms without the copy kernel; at n = 10 048 the
+            // copy-free form measured 0.3 ms SLOWER on the same box: 20.1 / 20.5 ms)
+            static const int copyEnv = getenv("DCA_SWEEP_COPY") ? atoi(getenv("DCA_SWEEP_COPY")) : -1;
+            const bool copyFirst = copyEnv >= 0 ? copyEnv != 0 : !factorForm;
+            if (copyFirst) copy_block(S[(p + 1) & 1], B, A + (size_t)c1 * ld + c1, w1, w1);
+            else { sArgs.Cin = A + (size_t)c1 * ld + c1; sArgs.ldcin = ld; }
+            if ((rc = launch_gemm(ctx, sArgs)) != DCA_OK) break;
             SWEEP_HIP(hipEventRecord(ev(2, p), chain));
             tr.mark(chain, "chain: next pivot block formed", p);
         }
         // ---- side: W = Q P (Q: this panel's copy, made at the end of the side stream's previous step), then the swept panel
         SWEEP_HIP(hipStreamWaitEvent(sd, ev(0, p), 0));
         tr.mark(sd, "side: step begins", p);
+        if (factorForm && (rc = launch_gemm_on(sd, pArgs)) != DCA_OK) break;
         if ((rc = launch_gemm_on(sd, GemmArgs{Qp, B, MASK_NONE, Pp, B, MASK_NONE, Wp, B, nullptr, 0, n, w, w, 1.0, 0.0, 0})) != DCA_OK) break;
         SWEEP_HIP(hipEventRecord(ev(3, p), sd));
         tr.mark(sd, "side: W done", p);
         if (!last) SWEEP_HIP(hipStreamWaitEvent(sd, ev(2, p), 0));
         hipLaunchKernelGGL(sweep_finalize_kernel, dim3(w / 32, n / 32), dim3(256), 0, sd, A, ld, c, w, Wp, B, Pp, B);
         SweepArgs g{Wp, B, Qp, B, A, ld, n, c, w, nt, c / 128, (c1 + w1 + 127) / 128 - c / 128, SWEEP_REST, c1 / 128, (c1 + w1 + 127) / 128 - c1 / 128,
-                    c2 / 128, w2 > 0 ? (c2 + w2 + 127) / 128 - c2 / 128 : 0, 0, nullptr};
+                    c2 / 128, w2 > 0 ? (c2 + w2 + 127) / 128 - c2 / 128 : 0, 0, nullptr, reserved};
         if (w1 == 0) { g.prN = 0; g.skipN = nt - g.skip0; }
         const int nR = nt - g.skipN;
         if (!last) {
@@ -2582,7 +2666,7 @@ int cholinv_sweep(dca_ctx* ctx, double* A, int n, double* work, int* dInfo, Side
             gp.mode = SWEEP_PRIO;
             gp.nTiles = g.prN * nR + g.dgN * (g.dgN + 1) / 2;
             gp.ctr = ctr + (size_t)p * 16 + 8;
-            if (gp.nTiles > 0) sweep_update_launch(sd, std::min(cfg.prioCap, (gp.nTiles + 7) / 8 * 8), cfg.stages, cfg.perCu, gp);
+            if (gp.nTiles > 0) sweep_update_launch(sd, std::min(capPrio, reserved ? std::max(64, (gp.nTiles + 7) / 8 * 8 * 8 / 7) : (gp.nTiles + 7) / 8 * 8), cfg.stages, cfg.perCu, gp);
             SWEEP_HIP(hipEventRecord(ev(1, p), sd));
             tr.mark(sd, "side: prio done", p);
             hipLaunchKernelGGL(gather_panel_kernel, dim3(w1 / 32, n / 32), dim3(256), 0, sd, A, ld, c1, w1, Q[(p + 1) & 1], B);
@@ -2595,7 +2679,7 @@ int cholinv_sweep(dca_ctx* ctx, double* A, int n, double* work, int* dInfo, Side
             g.nTiles = 8 * bands * bands + 2 * bands;
             g.ctr = ctr + (size_t)p * 16;
             tr.mark(rest, "rest: begins", p);
-            sweep_update_launch(rest, std::min(last ? capAll : capRest, (g.nTiles + 7) / 8 * 8), cfg.stages, cfg.perCu, g);
+            sweep_update_launch(rest, std::min(last ? capAll : capRest, reserved ? std::max(64, (g.nTiles + 7) / 8 * 8 * 8 / 7) : (g.nTiles + 7) / 8 * 8), cfg.stages, cfg.perCu, g);
             tr.mark(rest, "rest: done", p);
         }
         SWEEP_HIP(hipEventRecord(ev(4, p), rest));

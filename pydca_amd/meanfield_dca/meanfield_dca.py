@@ -49,16 +49,18 @@ class MeanFieldDCA:
         self.__sequences = None           # list-of-lists form of the reference's `alignment` property, made on demand
         self.last_timings = {}            # seconds per stage of the most recent calls (reader, weights, scores, ranking)
         t0 = time.perf_counter()
-        if isinstance(msa, str):
-            self.__X0 = fasta_reader.get_alignment_int_array(msa, biomolecule=biomolecule, zero_based=True)   # uint8 [N', L], device coding
-        elif isinstance(msa, (list, tuple)) or hasattr(msa, '__iter__'):
-            # an in-memory alignment: records with a .seq attribute (Bio.Align.MultipleSeqAlignment
-            # in the reference, :102-104) or plain strings
-            seqs = [str(getattr(rec, 'seq', rec)).strip().upper() for rec in msa]
-            self.__sequences = fasta_reader.alignment_letter2int([s for s in seqs if s], biomolecule)
-            self.__X0 = np.array(self.__sequences, dtype=np.uint8) - np.uint8(1)
-        else:
-            raise ValueError("Alignment input parameter is invalid")
+        # one device: its context (stream, handles: 2 ms) is made on a worker thread while the file is read
+        try:
+            early = multi_gpu.parse_devices(devices)
+        except ValueError:
+            early = [None, None]                  # reported below, after the alignment's own errors, as before
+        pending = _lib.Context.start(int(early[0] if early else device), _lib.DCA_F64) if len(early or []) <= 1 else None
+        try:
+            self.__read_alignment(msa, biomolecule)
+        except BaseException:
+            if pending is not None:
+                pending.discard()
+            raise
         self.__num_sequences, self.__sequences_len = (int(v) for v in self.__X0.shape)
         self.__biomolecule = biomolecule
         t1 = time.perf_counter()
@@ -73,7 +75,7 @@ class MeanFieldDCA:
                 raise MeanFieldDCAException(str(exc))
             self.__sequences_weight = self.__ctx.weights()
         else:
-            self.__ctx = _lib.Context(int(devices[0] if devices else device), _lib.DCA_F64)
+            self.__ctx = pending.result()
             self.__ctx.set_msa(self.__X0, self.__num_site_states)
             if self.__seqid < 1.0:
                 self.__sequences_weight = self.compute_sequences_weight()
@@ -87,6 +89,18 @@ class MeanFieldDCA:
                     'L {}, unique sequences {}, Meff {}'.format(
                         biomolecule, self.__num_site_states, self.__pseudocount, self.__seqid,
                         self.__sequences_len, self.__num_sequences, self.__effective_num_sequences))
+
+    def __read_alignment(self, msa, biomolecule):
+        if isinstance(msa, str):
+            self.__X0 = fasta_reader.get_alignment_int_array(msa, biomolecule=biomolecule, zero_based=True)   # uint8 [N', L], device coding
+        elif isinstance(msa, (list, tuple)) or hasattr(msa, '__iter__'):
+            # an in-memory alignment: records with a .seq attribute (Bio.Align.MultipleSeqAlignment
+            # in the reference, :102-104) or plain strings
+            seqs = [str(getattr(rec, 'seq', rec)).strip().upper() for rec in msa]
+            self.__sequences = fasta_reader.alignment_letter2int([s for s in seqs if s], biomolecule)
+            self.__X0 = np.array(self.__sequences, dtype=np.uint8) - np.uint8(1)
+        else:
+            raise ValueError("Alignment input parameter is invalid")
 
     def __str__(self):
         return '<instance of MeanFieldDCA>'
