@@ -134,6 +134,11 @@ int dca_get_meff(dca_ctx* ctx, double* meff_out);
 int dca_plm_configure(dca_ctx* ctx, double lambda_h, double lambda_J, int carry_mode,
                       int chunk, int warmup, int halo, int add_regulariser);
 size_t dca_plm_num_params(int L, int q);
+/* Frees the context's plmDCA state (x, g, the N x L q logit / residual tables, optimiser vectors); alignment, weights and
+ * communicator stay.  The next dca_plm_configure starts afresh.  For callers that configure a context only to take the
+ * initial point from it (the per-rank set-up of a multi-GPU run) -- no counterpart in the reference, whose PlmDCA object owns
+ * nothing between plmdcaBackend calls (plmdcaBackend.cpp:151-204). */
+int dca_plm_release(dca_ctx* ctx);
 /* x <- initial fields/couplings: PlmDCA::initFieldsAndCouplings (plmdca_numerics.cpp:207-249) */
 int dca_plm_init_x(dca_ctx* ctx);
 int dca_plm_set_x(dca_ctx* ctx, const void* x, int dtype);

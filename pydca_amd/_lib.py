@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("DCA_LIB_PATH") or os.path.join(_HERE, "lib", "libdca_
 
 DCA_OK = 0
 DCA_ERR_ARG, DCA_ERR_IO, DCA_ERR_RESIDUE = -1, -2, -3
-DCA_ERR_NOT_SPD = -7
+DCA_ERR_NOMEM, DCA_ERR_HIP, DCA_ERR_NO_DEVICE, DCA_ERR_NOT_SPD, DCA_ERR_STATE = -4, -5, -6, -7, -8
 DCA_F32, DCA_F64 = 32, 64
 DCA_BIOMOLECULE_PROTEIN, DCA_BIOMOLECULE_RNA = 1, 2
 CARRY_EXACT, CARRY_CHUNKED, CARRY_SERIAL = 0, 1, 2
@@ -98,6 +98,7 @@ def lib():
         "dca_plm_init_x": (i, [vp]),
         "dca_plm_set_x": (i, [vp, vp, i]),
         "dca_plm_get_x": (i, [vp, vp, i]),
+        "dca_plm_release": (i, [vp]),
         "dca_plm_gradient": (i, [vp, C.POINTER(d)]),
         "dca_plm_get_g": (i, [vp, vp, i]),
         "dca_plm_set_reduce_hook": (i, [vp, REDUCE_HOOK, vp]),
@@ -150,7 +151,7 @@ EXPORTS = ["dca_weights_work", "dca_compute_weights_sharded", "dca_weights_parti
            "dca_last_error", "dca_version", "dca_device_count", "dca_release_cached_memory", "dca_read_msa", "dca_count_msa_lines", "dca_read_msa_alloc", "dca_mf_set_row_window", "dca_comm_allgather_host", "dca_fasta_shape", "dca_read_fasta", "dca_read_fasta_alloc", "dca_host_free", "dca_create",
            "dca_destroy", "dca_set_msa", "dca_compute_weights", "dca_set_weights", "dca_get_weights",
            "dca_get_weight_counts", "dca_get_meff", "dca_plm_configure", "dca_plm_configure_strips", "dca_plm_num_params", "dca_plm_init_x",
-           "dca_plm_set_x", "dca_plm_get_x", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_di_from_arrays", "dca_di_from_fields", "dca_plm_set_vector_sharding",
+           "dca_plm_set_x", "dca_plm_get_x", "dca_plm_release", "dca_plm_gradient", "dca_plm_get_g", "dca_plm_set_reduce_hook", "dca_mf_set_reduce_hook", "dca_di_from_arrays", "dca_di_from_fields", "dca_plm_set_vector_sharding",
            "dca_plm_lbfgs_begin", "dca_plm_lbfgs_iterate", "dca_plm_lbfgs_end", "dca_plm_scores", "dca_plm_di_scores",
            "dca_mf_di_scores", "dca_plm_pair_couplings", "dca_mf_fields", "dca_mf_pair_couplings",
            "dca_mf_single_site_freqs",
@@ -435,6 +436,10 @@ class Context:
         x = np.zeros(self.num_params(), dtype=dtype)
         check(self._l.dca_plm_get_x(self._h, _ptr(x), DCA_F32 if x.dtype == np.float32 else DCA_F64))
         return x
+
+    def plm_release(self):
+        """Frees the plmDCA engine of this context (tables, vectors); alignment, weights and communicator stay."""
+        check(self._l.dca_plm_release(self._h))
 
     def plm_get_g(self, dtype=np.float32):
         g = np.zeros(self.num_params(), dtype=dtype)

@@ -450,6 +450,15 @@ int dca_plm_configure_strips(dca_ctx* ctx, double lambda_h, double lambda_J, int
     if (carry_mode < 0 || carry_mode > 2) return DCA_ERR_ARG;
     return ctx->plm->configure_strips(lambda_h, lambda_J, carry_mode, chunk, warmup);
 }
+int dca_plm_release(dca_ctx* ctx)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->plm) return DCA_OK;
+    // the engine's kernels may still be running on the context's stream
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { dca_set_error("dca_plm_release: stream synchronisation failed"); return DCA_ERR_HIP; }
+    delete ctx->plm; ctx->plm = nullptr;
+    return DCA_OK;
+}
 int dca_plm_init_x(dca_ctx* ctx) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->init_x(); }
 int dca_plm_set_x(dca_ctx* ctx, const void* x, int dtype) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->set_x(x, dtype); }
 int dca_plm_get_x(dca_ctx* ctx, void* x, int dtype) { CHECK_CTX(ctx); DCA_TRY(need_plm(ctx)); return ctx->plm->get_x(x, dtype); }

@@ -95,6 +95,7 @@ void rank_main(Shared& s, int rank)
         STEP(dca_plm_init_x(full));
         if (rc == DCA_OK) x0.resize(P * (prec == DCA_F64 ? 8 : 4));
         STEP(dca_plm_get_x(full, x0.data(), prec));
+        STEP(dca_plm_release(full));            // only the initial point was wanted: its N x L q tables do not stay beside the strip's
         STEP(dca_set_weight_counts(run, counts.data()));
         STEP(dca_comm_init(run, a.rccl_path, s.ids[1], s.world, rank));
         if (rc == DCA_OK && run->comm) track(s, run);

@@ -121,6 +121,9 @@ def plm_rank(job, rank, X, log=None, ctx=None):
         full.plm_configure(lh, lJ, carry)
         full.plm_init_x()
         x0 = full.plm_get_x(dtype)
+        # ... and nothing else of that engine: its N x L q tables would sit beside the shard's for the whole run (rank 0 configures
+        # `full` again once the run is over)
+        full.plm_release()
 
         def seq_up():
             c = parallel.make_sharded_plm_context(_lib, X, q, w.astype(np.float64), lh, lJ, rank, world, dev,

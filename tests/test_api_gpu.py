@@ -894,6 +894,32 @@ def test_set_msa_rejects_codes_outside_the_alphabet():
     ctx.close()
 
 
+def test_plm_release_frees_the_engine_and_keeps_the_context():
+    """dca_plm_release: the plmDCA tables and vectors go (a multi-GPU rank configures its whole-alignment context only for the initial
+    point), alignment and weights stay, a second configure gives the same initial point, releasing twice is harmless."""
+    from pydca_amd import _lib as L_
+    rng = np.random.default_rng(3)
+    X = rng.integers(0, 21, size=(400, 60), dtype=np.uint8)
+    ctx = L_.Context(0, L_.DCA_F32)
+    ctx.set_msa(X, 21)
+    w = ctx.compute_weights(0.8)
+    ctx.plm_configure(1.0, 20.0)
+    ctx.plm_init_x()
+    x0 = ctx.plm_get_x()
+    ctx.plm_release()
+    ctx.plm_release()
+    with pytest.raises(L_.DcaBackendError) as ei:
+        ctx.plm_get_x()
+    assert ei.value.code == L_.DCA_ERR_STATE
+    np.testing.assert_array_equal(ctx.weights(), w)
+    ctx.plm_configure(1.0, 20.0)
+    ctx.plm_init_x()
+    np.testing.assert_array_equal(ctx.plm_get_x(), x0)
+    fx = ctx.plm_gradient()
+    assert np.isfinite(fx)
+    ctx.close()
+
+
 def test_dca_plm_run_one_call_entry():
     """SURVEY section 8 b1's richer entry, `int dca_plm_run(const dca_plm_args*, x_out, dtype, dca_plm_stats*)`: through ctypes as a C
     host would call it.  One device: the bytes and the status / iterations / evaluations of the stage API.  devices = {0, 0} and
