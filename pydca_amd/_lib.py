@@ -263,32 +263,6 @@ def read_fasta(path, biomolecule):
     return out, raw.value
 
 
-class _ContextFuture:
-    def __init__(self, cls, device, precision):
-        import threading
-        self._ctx = self._exc = None
-        self._t = threading.Thread(target=self._run, args=(cls, device, precision), daemon=True)
-        self._t.start()
-
-    def _run(self, cls, device, precision):
-        try:
-            self._ctx = cls(device, precision)
-        except BaseException as exc:             # handed to the thread that asks for the result
-            self._exc = exc
-
-    def result(self):
-        self._t.join()
-        if self._exc is not None:
-            raise self._exc
-        return self._ctx
-
-    def discard(self):
-        """The caller failed before it needed the context."""
-        self._t.join()
-        if self._ctx is not None:
-            self._ctx.close()
-
-
 class Context:
     """One GPU, one stream, one alignment (include/dca_hip.h `dca_ctx`)."""
 
@@ -310,12 +284,6 @@ class Context:
             self.close()
         except Exception:
             pass
-
-    @classmethod
-    def start(cls, device=0, precision=DCA_F32):
-        """The context made on a worker thread (2 ms of stream / handle creation at first use of a device in a process): the caller
-        reads its alignment file meanwhile and takes the context with .result(), which re-raises what the creation raised."""
-        return _ContextFuture(cls, device, precision)
 
     # ---- alignment / weights
     def set_msa(self, X, q):

@@ -49,18 +49,7 @@ class MeanFieldDCA:
         self.__sequences = None           # list-of-lists form of the reference's `alignment` property, made on demand
         self.last_timings = {}            # seconds per stage of the most recent calls (reader, weights, scores, ranking)
         t0 = time.perf_counter()
-        # one device: its context (stream, handles: 2 ms) is made on a worker thread while the file is read
-        try:
-            early = multi_gpu.parse_devices(devices)
-        except ValueError:
-            early = [None, None]                  # reported below, after the alignment's own errors, as before
-        pending = _lib.Context.start(int(early[0] if early else device), _lib.DCA_F64) if len(early or []) <= 1 else None
-        try:
-            self.__read_alignment(msa, biomolecule)
-        except BaseException:
-            if pending is not None:
-                pending.discard()
-            raise
+        self.__read_alignment(msa, biomolecule)
         self.__num_sequences, self.__sequences_len = (int(v) for v in self.__X0.shape)
         self.__biomolecule = biomolecule
         t1 = time.perf_counter()
@@ -75,7 +64,7 @@ class MeanFieldDCA:
                 raise MeanFieldDCAException(str(exc))
             self.__sequences_weight = self.__ctx.weights()
         else:
-            self.__ctx = pending.result()
+            self.__ctx = _lib.Context(int(devices[0] if devices else device), _lib.DCA_F64)
             self.__ctx.set_msa(self.__X0, self.__num_site_states)
             if self.__seqid < 1.0:
                 self.__sequences_weight = self.compute_sequences_weight()
