@@ -1153,27 +1153,33 @@ __global__ void lbfgs_two_loop_kernel(double* __restrict__ scal, LbfgsDev* __res
 // s_e = x - xp, y_e = g - gp (lbfgs.cpp:546-558) are formed, stored and used in one pass, so the newest pair is not
 // read back and g is read once (14 vector passes; 19 as two kernels, 0.75 -> 0.6 ms at D).  partials[v * gridDim.x +
 // block]: v = 0, 1 are y_e.s_e and y_e.y_e, v = 2 + kind * 5 + k the Gram entries (kinds in the order above).
-template <typename T>
+template <typename T, int E>
 __global__ __launch_bounds__(kVecThreads)
 void vec_diff_gram_kernel(VecPtrs5 P, T* __restrict__ se, T* __restrict__ ye, const T* __restrict__ x, const T* __restrict__ xp,
-                          const T* __restrict__ g, const T* __restrict__ gp, int e, size_t n, double* __restrict__ partials)
+                          const T* __restrict__ g, const T* __restrict__ gp, size_t n, double* __restrict__ partials)
 {
+    // E = slot of the newest pair, a template parameter: as a run-time value the test `k != e` stood in front of every pair's two
+    // loads, which the compiler then issued and WAITED for pair by pair -- six round trips per pack with two to four loads in
+    // flight (config D: 3.7 TB/s where the other vector kernels reach 5.3 - 6.4).  All twelve loads of a pack are issued before
+    // the first store (the stores may alias the history for all the compiler knows).
     __shared__ double red[kVecThreads / 64][54];
     DotAcc<sizeof(T) == 8> acc[27];
     DCA_VEC_LOOP(n, se,
         const Pack<T> px = ldp(x, iv); const Pack<T> pxp = ldp(xp, iv); const Pack<T> pg = ldp(g, iv); const Pack<T> pgp = ldp(gp, iv);
+        Pack<T> psk[5]; Pack<T> pyk[5];
+        _Pragma("unroll") for (int k = 0; k < 5; ++k)
+            if (k != E) { psk[k] = ldp(static_cast<const T*>(P.s[k]), iv); pyk[k] = ldp(static_cast<const T*>(P.y[k]), iv); }
         Pack<T> pse; Pack<T> pye;
         _Pragma("unroll") for (int u = 0; u < VEC; ++u) {
             pse.v[u] = px.v[u] - pxp.v[u]; pye.v[u] = pg.v[u] - pgp.v[u];
             acc[0].add((double)pye.v[u], (double)pse.v[u]); acc[1].add((double)pye.v[u], (double)pye.v[u]);
         }
+        psk[E] = pse; pyk[E] = pye;
         stp(se, iv, pse); stp(ye, iv, pye);
         _Pragma("unroll") for (int k = 0; k < 5; ++k) {
-            Pack<T> psk = pse; Pack<T> pyk = pye;
-            if (k != e) { psk = ldp(static_cast<const T*>(P.s[k]), iv); pyk = ldp(static_cast<const T*>(P.y[k]), iv); }
             _Pragma("unroll") for (int u = 0; u < VEC; ++u) {
                 const double gv = pg.v[u]; const double sev = pse.v[u]; const double yev = pye.v[u];
-                const double sk = psk.v[u]; const double yk = pyk.v[u];
+                const double sk = psk[k].v[u]; const double yk = pyk[k].v[u];
                 acc[2 + k].add(sk, gv); acc[7 + k].add(yk, gv); acc[12 + k].add(sev, yk); acc[17 + k].add(yev, sk); acc[22 + k].add(yev, yk);
             }
         },
@@ -1181,7 +1187,7 @@ void vec_diff_gram_kernel(VecPtrs5 P, T* __restrict__ se, T* __restrict__ ye, co
           const double gv = g[i]; const double sev = sev_; const double yev = yev_;
           acc[0].add(yev, sev); acc[1].add(yev, yev);
           _Pragma("unroll") for (int k = 0; k < 5; ++k) {
-              const double sk = k == e ? sev : (double)static_cast<const T*>(P.s[k])[i]; const double yk = k == e ? yev : (double)static_cast<const T*>(P.y[k])[i];
+              const double sk = k == E ? sev : (double)static_cast<const T*>(P.s[k])[i]; const double yk = k == E ? yev : (double)static_cast<const T*>(P.y[k])[i];
               acc[2 + k].add(sk, gv); acc[7 + k].add(yk, gv); acc[12 + k].add(sev, yk); acc[17 + k].add(yev, sk); acc[22 + k].add(yev, yk);
           } })
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2308,8 +2314,17 @@ struct PlmEngine : PlmEngineBase {
             for (int i = 0; i < M; ++i) { ptrs.s[i] = dS[i] + vlo; ptrs.y[i] = dY[i] + vlo; }
             {
                 ScopedKernelClock kc(ctx, "lbfgs_vec");
-                hipLaunchKernelGGL(vec_diff_gram_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, ptrs, dS[e] + vlo, dY[e] + vlo,
-                                   dx + vlo, dxp + vlo, dg + vlo, dgp + vlo, e, vn, dVecPart);
+                auto gram = [&](auto slot) {
+                    hipLaunchKernelGGL((vec_diff_gram_kernel<T, decltype(slot)::value>), dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, ptrs, dS[e] + vlo, dY[e] + vlo,
+                                       dx + vlo, dxp + vlo, dg + vlo, dgp + vlo, vn, dVecPart);
+                };
+                switch (e) {
+                case 0: gram(std::integral_constant<int, 0>()); break;
+                case 1: gram(std::integral_constant<int, 1>()); break;
+                case 2: gram(std::integral_constant<int, 2>()); break;
+                case 3: gram(std::integral_constant<int, 3>()); break;
+                default: gram(std::integral_constant<int, 4>()); break;
+                }
                 hipLaunchKernelGGL(vec_final_kernel, dim3(27), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 27, ctx->dScal + 1);
             }
             DCA_TRY(reduce_scalars(1, 27));
