@@ -956,12 +956,14 @@ template <typename T> __device__ __forceinline__ void stp_at(T* p, size_t iv, co
 // start at that boundary (ldp / stp inside the loop body index from there), so every 16-byte access is aligned.
 #define ldp(p, iv) ldp_at((p) + head_, iv)
 #define stp(p, iv, o) stp_at((p) + head_, iv, o)
-#define DCA_VEC_LOOP(n, ALIGNP, BODY_PACK, BODY_TAIL)                                                     \
+#define DCA_VEC_LOOP(n, ALIGNP, BODY_PACK, BODY_TAIL) DCA_VEC_LOOP_G(n, ALIGNP, gridDim.x, BODY_PACK, BODY_TAIL)
+/* GRID: the number of workgroups that walk the vector (a launch may carry other workgroups behind them) */
+#define DCA_VEC_LOOP_G(n, ALIGNP, GRID, BODY_PACK, BODY_TAIL)                                             \
     {                                                                                                      \
         constexpr int VEC = 16 / (int)sizeof(T);                                                           \
         const size_t lead_ = ((16 - (reinterpret_cast<uintptr_t>(ALIGNP) & 15)) & 15) / sizeof(T);         \
         const size_t head_ = lead_ < (size_t)(n) ? lead_ : (size_t)(n);                                    \
-        const size_t nv_ = ((n) - head_) / VEC, stride_ = (size_t)gridDim.x * blockDim.x;                  \
+        const size_t nv_ = ((n) - head_) / VEC, stride_ = (size_t)(GRID) * blockDim.x;                     \
         const size_t t0_ = blockIdx.x * (size_t)blockDim.x + threadIdx.x;                                  \
         for (size_t iv = t0_; iv < nv_; iv += stride_) { BODY_PACK }                                       \
         const size_t rest_ = (n) - nv_ * VEC;                     /* head_ + tail, fewer than 2 VEC */      \
@@ -1041,13 +1043,13 @@ template <> struct DotAcc<true> {
 };
 // the workgroup's waves leave their (hi, lo) in red[wave][2 * v], [2 * v + 1]; thread v < nv adds them in wave order
 template <int NV>
-__device__ __forceinline__ void dot_block_store(double (*red)[2 * NV], int nv, double* __restrict__ partials)
+__device__ __forceinline__ void dot_block_store(double (*red)[2 * NV], int nv, double* __restrict__ partials, unsigned grid = 0)
 {
     __syncthreads();
     if ((int)threadIdx.x < nv) {
         double hi = 0.0, lo = 0.0;
         for (int w = 0; w < (int)blockDim.x / 64; ++w) dd_add2(hi, lo, red[w][2 * threadIdx.x], red[w][2 * threadIdx.x + 1]);
-        const size_t slot = (size_t)threadIdx.x * gridDim.x + blockIdx.x;
+        const size_t slot = (size_t)threadIdx.x * (grid ? grid : gridDim.x) + blockIdx.x;
         partials[2 * slot] = hi;
         partials[2 * slot + 1] = lo;
     }
@@ -1276,6 +1278,74 @@ void dd_sum_final_kernel(const double* __restrict__ A, int nA, const double* __r
 
 // first stage for long partial vectors: block b sums its contiguous chunk (fixed tree) into out[b]
 constexpr int kSumStageBlocks = 64;
+
+// The two reductions that end an evaluation of the optimiser -- fx from its per-pair / per-chunk partial sums (dd_sum_chunks_kernel,
+// dd_sum_final_kernel) and the three dot products of the line search (vec_dot3_kernel, vec_final_kernel) -- as TWO launches instead
+// of four: the workgroups behind the first kVecBlocks of the first launch sum the fx chunks, the workgroup behind the dot products'
+// of the second finishes fx.  Every sum is formed by the same code over the same operands in the same order as in the separate
+// kernels (the vector walk with its grid given, the 256-thread tree inside the 1024-thread workgroups), so the bits are theirs; what
+// goes is two launch boundaries and ~11 us of two tiny kernels per evaluation (config C: 1.6 % of the step).
+template <typename T>
+__global__ __launch_bounds__(kVecThreads)
+void vec_dot3_fx_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, size_t n, double* __restrict__ partials,
+                        const double* __restrict__ fxParts, int nFxParts, double* __restrict__ fxChunks)
+{
+    if (blockIdx.x >= (unsigned)kVecBlocks) {
+        __shared__ double redHi[256], redLo[256];
+        const int blk = (int)blockIdx.x - kVecBlocks;
+        const int chunk = (nFxParts + kSumStageBlocks - 1) / kSumStageBlocks;
+        const int lo_ = blk * chunk, hi_ = min(nFxParts, lo_ + chunk);
+        double hi = 0.0, lo = 0.0;
+        for (int p = lo_ + threadIdx.x; p < hi_; p += blockDim.x) dd_add2(hi, lo, fxParts[2 * (size_t)p], fxParts[2 * (size_t)p + 1]);
+        dd_block_reduce(hi, lo, redHi, redLo);
+        if (threadIdx.x == 0) { fxChunks[2 * blk] = hi; fxChunks[2 * blk + 1] = lo; }
+        return;
+    }
+    __shared__ double red[kVecThreads / 64][6];
+    DotAcc<sizeof(T) == 8> s0, s1, s2;
+    DCA_VEC_LOOP_G(n, a, kVecBlocks,
+        const Pack<T> pa = ldp_at(a + head_, iv); const Pack<T> pb = ldp_at(b + head_, iv); const Pack<T> pc = ldp_at(c + head_, iv);
+        _Pragma("unroll") for (int k = 0; k < VEC; ++k) {
+            const double av = pa.v[k]; const double bv = pb.v[k]; const double cv = pc.v[k];
+            s0.add(av, bv); s1.add(cv, cv); s2.add(av, av);
+        },
+        { const double av = a[i]; const double bv = b[i]; const double cv = c[i]; s0.add(av, bv); s1.add(cv, cv); s2.add(av, av); })
+    s0.wave_reduce(); s1.wave_reduce(); s2.wave_reduce();
+    if ((threadIdx.x & 63) == 0) {
+        double* r = red[threadIdx.x >> 6];
+        r[0] = s0.hi; r[1] = s0.lo; r[2] = s1.hi; r[3] = s1.lo; r[4] = s2.hi; r[5] = s2.lo;
+    }
+    dot_block_store<3>(red, 3, partials, kVecBlocks);
+}
+// 1024 threads per workgroup.  Workgroups 0 .. nk - 1: vec_final_kernel's sum of dot product k with its 256 threads (the others only
+// keep the barriers company); workgroup nk: dd_sum_final_kernel's sum of fx with all 1024.
+__global__ __launch_bounds__(1024)
+void vec_final_fx_kernel(const double* __restrict__ partials, int nb, int nk, double* __restrict__ out,
+                         const double* __restrict__ A, int nA, const double* __restrict__ B, int nB, double* __restrict__ fxOut)
+{
+    __shared__ double redHi[1024], redLo[1024];
+    const int k = blockIdx.x;
+    double hi = 0.0, lo = 0.0;
+    if (k < nk) {
+        constexpr int NT = 256;
+        if ((int)threadIdx.x < NT) {
+            for (int b = threadIdx.x; b < nb; b += NT) dd_add2(hi, lo, partials[2 * ((size_t)k * nb + b)], partials[2 * ((size_t)k * nb + b) + 1]);
+            redHi[threadIdx.x] = hi;
+            redLo[threadIdx.x] = lo;
+        }
+        __syncthreads();
+        for (int st = NT / 2; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) dd_add2(redHi[threadIdx.x], redLo[threadIdx.x], redHi[threadIdx.x + st], redLo[threadIdx.x + st]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[k] = redHi[0] + redLo[0];
+        return;
+    }
+    for (int b = threadIdx.x; b < nA; b += blockDim.x) dd_add2(hi, lo, A[2 * (size_t)b], A[2 * (size_t)b + 1]);
+    for (int b = threadIdx.x; b < nB; b += blockDim.x) dd_add2(hi, lo, B[2 * (size_t)b], B[2 * (size_t)b + 1]);
+    dd_block_reduce(hi, lo, redHi, redLo);
+    if (threadIdx.x == 0) fxOut[0] = hi + lo;
+}
 __global__ void sum_chunks_kernel(const double* __restrict__ partials, int n, double* __restrict__ out)
 {
     __shared__ double red[256];
@@ -1459,6 +1529,7 @@ struct PlmEngine : PlmEngineBase {
     size_t owned_hi(int r) const { return (size_t)L * q + pair_start(siteB[r + 1]) * q * q; }
     int nFxPart = 0, nRegPart = 0;
     bool lbfgs_alloc = false;
+    bool deferFx = false, fxPending = false;      // fx of the last evaluation still lies in its partial sums (eval_scalars finishes it)
     // vector sharding (dca_plm_set_vector_sharding): this rank's slice [vlo, vlo + vn) of every P-vector;
     // collectives run over Ppad = world * slice elements.  Unsharded: vlo = 0, vn = Ppad = P.
     static constexpr size_t kVecPad = 256;
@@ -1964,16 +2035,23 @@ struct PlmEngine : PlmEngineBase {
         DCA_ROUND_STAGE(16, dg, P);
         // fx = regulariser + data term  -> ctx->dScal[0]
         // (one partial per site pair: summed in two stages, a single workgroup needs 28 us for the 125 000 of config D)
-        hipLaunchKernelGGL(dd_sum_chunks_kernel, dim3(kSumStageBlocks), dim3(256), 0, st, dRegPart, nRegPart, dRegPart + 2 * (size_t)nRegPart);
-        hipLaunchKernelGGL(dd_sum_final_kernel, dim3(1), dim3(1024), 0, st, dRegPart + 2 * (size_t)nRegPart, kSumStageBlocks, dFxPart, nFxPart, ctx->dScal);
+        // (the optimiser on one GPU sums fx inside the two launches of its dot products: eval_scalars)
+        fxPending = deferFx;
+        if (!deferFx) {
+            hipLaunchKernelGGL(dd_sum_chunks_kernel, dim3(kSumStageBlocks), dim3(256), 0, st, dRegPart, nRegPart, dRegPart + 2 * (size_t)nRegPart);
+            hipLaunchKernelGGL(dd_sum_final_kernel, dim3(1), dim3(1024), 0, st, dRegPart + 2 * (size_t)nRegPart, kSumStageBlocks, dFxPart, nFxPart, ctx->dScal);
+        }
         HIP_TRY(hipGetLastError());
         return DCA_OK;
     }
 
     // leaves fx in ctx->dScal[0] (device); no host sync unless a reduce hook is set
-    int evaluate_async()
+    // defer_fx: the caller is eval_scalars' (one GPU, no hook: nothing reads fx before the dot products are formed)
+    int evaluate_async(bool defer_fx = false)
     {
         if (!configured) { dca_set_error("dca_plm_configure first"); return DCA_ERR_STATE; }
+        static const bool fuseFx = !(getenv("DCA_PLM_FUSE_FX") && atoi(getenv("DCA_PLM_FUSE_FX")) == 0);
+        deferFx = defer_fx && fuseFx && native_mode == 0 && !hook && !comm && !stripEmulate;
         int rc = (q == 21) ? launch_eval<21>() : launch_eval<5>();
         if (rc != DCA_OK) return rc;
         o.evals += 1;
@@ -2163,8 +2241,17 @@ struct PlmEngine : PlmEngineBase {
     // after an evaluation: fx (slot 0), g.d, x.x, g.g (slots 1..3) in one round trip
     int eval_scalars(double* fx, double* gd, double* xx, double* gg)
     {
-        hipLaunchKernelGGL(vec_dot3_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dg + vlo, dd + vlo, dx + vlo, vn, dVecPart);
-        hipLaunchKernelGGL(vec_final_kernel, dim3(3), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 3, ctx->dScal + 1);
+        if (fxPending) {
+            double* const fxChunks = dRegPart + 2 * (size_t)nRegPart;
+            hipLaunchKernelGGL(vec_dot3_fx_kernel<T>, dim3(kVecBlocks + kSumStageBlocks), dim3(kVecThreads), 0, ctx->stream, dg + vlo, dd + vlo, dx + vlo, vn, dVecPart,
+                               dRegPart, nRegPart, fxChunks);
+            hipLaunchKernelGGL(vec_final_fx_kernel, dim3(3 + 1), dim3(1024), 0, ctx->stream, dVecPart, kVecBlocks, 3, ctx->dScal + 1,
+                               fxChunks, kSumStageBlocks, dFxPart, nFxPart, ctx->dScal);
+            fxPending = false;
+        } else {
+            hipLaunchKernelGGL(vec_dot3_kernel<T>, dim3(kVecBlocks), dim3(kVecThreads), 0, ctx->stream, dg + vlo, dd + vlo, dx + vlo, vn, dVecPart);
+            hipLaunchKernelGGL(vec_final_kernel, dim3(3), dim3(256), 0, ctx->stream, dVecPart, kVecBlocks, 3, ctx->dScal + 1);
+        }
         DCA_TRY(reduce_scalars(0, 4));     // fx (local data term) and the three partial dot products
         DCA_TRY(read_scalars(kSlotDginit + 1));
         *fx = ctx->hScal[0]; *gd = ctx->hScal[1]; *xx = ctx->hScal[2]; *gg = ctx->hScal[3];
@@ -2193,7 +2280,7 @@ struct PlmEngine : PlmEngineBase {
         o.max_iterations = max_iterations;
         o.verbose = verbose;
         auto t0 = std::chrono::steady_clock::now();
-        DCA_TRY(evaluate_async());
+        DCA_TRY(evaluate_async(true));
         v_neg(dd, dg);
         double fx, gd, xx, gg;
         DCA_TRY(eval_scalars(&fx, &gd, &xx, &gg));
@@ -2239,7 +2326,7 @@ struct PlmEngine : PlmEngineBase {
             v_step(dx, dxp, *stp, dd);
             DCA_ROUND_STAGE(32, dx, P);
             if ((*rc_hip = publish_x())) return 0;            // sharded vectors: every rank needs the x its evaluation reads
-            if ((*rc_hip = evaluate_async())) return 0;
+            if ((*rc_hip = evaluate_async(true))) return 0;
             double dg_;
             if ((*rc_hip = eval_scalars(f, &dg_, xx, gg))) return 0;
             if (!have_dginit) {
