@@ -439,13 +439,16 @@ SWEEP_SMALL = {"DCA_SWEEP_MIN": "256", "DCA_SWEEP_PANEL": "128"}
 
 @pytest.mark.parametrize("env", [{}, {"DCA_SWEEP_CAP": "8", "DCA_SWEEP_PRIO_CAP": "8"}, {"DCA_SWEEP_PER_CU": "1", "DCA_SWEEP_STAGES": "4"},
                                  {"DCA_SWEEP_PER_CU": "1", "DCA_SWEEP_STAGES": "3", "DCA_SWEEP_CAP": "16"}, {"DCA_SWEEP_PANEL": "256"},
-                                 {"DCA_SWEEP_MASK": "240"}, {"DCA_SWEEP": "0", "DCA_CHOLINV_BLOCKED_MIN": "5000"}])
+                                 {"DCA_SWEEP_MASK": "240"}, {"DCA_SWEEP": "0", "DCA_CHOLINV_BLOCKED_MIN": "5000"},
+                                 {"DCA_SWEEP_FACTOR_MAX_N": "0"}, {"DCA_SWEEP_FACTOR_MAX_N": "0", "DCA_SWEEP_COPY": "0"}, {"DCA_SWEEP_COPY": "1"},
+                                 {"DCA_SWEEP_RESERVE": "4", "DCA_SWEEP_RESERVE_MAX_N": "100000"}])
 def test_spd_inverse_block_sweep_at_small_sizes(env):
     """Round 6: the symmetric block sweep (cholinv_sweep) is what runs from n = 2560 on; forced here onto small matrices (panels of 128 /
     256 columns -- ragged last panel, last tile row of 64, a 64-column last panel --, tiny workgroup caps so that the tile
     hand-out wraps and steals across the XCD chunks, one workgroup per CU with three / four operand stages, CU-masked streams)
     and compared with LAPACK; an indefinite matrix must come back as DCA_ERR_NOT_SPD with the pivot of the Cholesky
-    factorisation.  The last parameter set is the three-phase form on the same matrices."""
+    factorisation.  {DCA_SWEEP: 0} is the three-phase form on the same matrices; the sets after it: the next pivot block through
+    P instead of from X (what n >= 4500 takes), with / without the copy kernel, and CUs reserved for the chain by the update kernel."""
     import subprocess
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
@@ -465,6 +468,29 @@ def test_spd_inverse_block_sweep_at_small_sizes(env):
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **dict(SWEEP_SMALL, **env)))
     assert p.returncode == 0, p.stderr[-2000:]
     assert float(p.stdout.strip().splitlines()[-1]) < 1e-11
+
+
+def test_fused_fx_sums_give_the_bits_of_the_separate_kernels():
+    """Round 6: on one GPU the optimiser sums fx inside the two launches of the line search's dot products (vec_dot3_fx_kernel,
+    vec_final_fx_kernel); DCA_PLM_FUSE_FX=0 keeps the four separate launches.  Same code over the same operands in the same order: x, fx
+    and the counters after 12 iterations are equal to the last bit, in float32 and in float64, for q = 5 and q = 21."""
+    import subprocess
+    code = (
+        "import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+        "from pydca_amd import _lib\n"
+        "for q, L, N, prec in ((5, 37, 900, _lib.DCA_F32), (21, 30, 700, _lib.DCA_F32), (5, 37, 900, _lib.DCA_F64), (21, 30, 700, _lib.DCA_F64)):\n"
+        "    rng = np.random.default_rng(q * 100 + L); X = rng.integers(0, q, size=(N, L), dtype=np.uint8)\n"
+        "    ctx = _lib.Context(0, prec); ctx.set_msa(X, q); ctx.compute_weights(0.8, prec); ctx.plm_configure(1.0, 10.0); ctx.plm_init_x()\n"
+        "    ctx.plm_lbfgs_begin(100); st = ctx.plm_lbfgs_iterate(12)\n"
+        "    x = ctx.plm_get_x(np.float64 if prec == _lib.DCA_F64 else np.float32)\n"
+        "    print(q, prec, st.iterations, st.evaluations, repr(st.fx), hashlib.sha256(x.tobytes()).hexdigest())\n"
+        "    ctx.close()\n" % ROOT)
+    outs = []
+    for fuse in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, DCA_PLM_FUSE_FX=fuse))
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(p.stdout.strip().splitlines()[-4:])
+    assert len(outs[0]) == 4 and outs[0] == outs[1], outs
 
 
 def test_scores_kernel(L_, oracle_mf):
