@@ -593,7 +593,8 @@ template <typename T, int Q, int JW, int WAVES_>
 __global__ __launch_bounds__(WAVES_ * 64)
 void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT2,
                         T* __restrict__ G, int N, int L, int Cs, int halo, int numChunks, int NT, int ctBase, int numPairs, int splitX,
-                        int numJG, int chunksPerSplit, size_t slabElems, int blockChunks)
+                        int numJG, int chunksPerSplit, size_t slabElems, int blockChunks,
+                        int firstBlocksX, int ctBase2, int numPairs2, int splitX2, int chunksPerSplit2)
 {
     constexpr int WAVES = WAVES_;                      // 16; 8 or 4 in the float64 mode on alignments with few column strips (configure)
     constexpr int JG = WAVES * JW;                     // sites (Q = 25: site pairs; L is then their number) per workgroup
@@ -610,7 +611,14 @@ void plm_scatter_kernel(const T* __restrict__ R, const uint16_t* __restrict__ XT
     // the same XCD (id % 8) so that their reads of the strip can meet in that XCD's L2.  The main launch has one pair
     // per strip and the splits in blockIdx.y; the launch for the strips left over after the full sets of eight
     // (launch_eval) carries a finer split in the pair index (splitX) so that it fills all XCDs for a fraction of a round.
-    const int id = blockIdx.x;
+    // A launch may carry a SECOND set of (strip, split) pairs behind the first firstBlocksX workgroups of every grid row -- the
+    // left-over strips with their finer split (round 6: as a launch of their own they ran AFTER the main one, which at config C
+    // leaves 32 CUs idle for its whole length: 269 + 48 us; merged they fill those CUs).  The second set has no blockIdx.y.
+    int id = blockIdx.x;
+    if (id >= firstBlocksX) {
+        if (blockIdx.y != 0) return;
+        id -= firstBlocksX; ctBase = ctBase2; numPairs = numPairs2; splitX = splitX2; chunksPerSplit = chunksPerSplit2; blockChunks = 0;
+    }
     const int xcd = id % kNumXcd, k = id / kNumXcd;
     const int pr = (k / numJG) * kNumXcd + xcd;
     const int jg = k % numJG;
@@ -1973,19 +1981,29 @@ struct PlmEngine : PlmEngineBase {
             const int scatThreads = scatWaves * 64;
             const int mainCT = numCT - scatRemCT;            // strips of the main launch (all of them without a left-over launch)
             const size_t lds = (size_t)2 * kNC * kRowBytes;
+            static const bool mergeRemEnv = !(getenv("DCA_SCATTER_MERGE") && atoi(getenv("DCA_SCATTER_MERGE")) == 0);
+            const bool mergeRem = mergeRemEnv && !(numCT < kNumXcd || scatPerBlock);
             auto launch = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ScopedKernelClock kc(ctx, "plm_scatter");
                 if (numCT < kNumXcd || scatPerBlock)        // E: 6 strips would leave two XCDs idle: deal the (strip, split) pairs to the XCDs instead
                     hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(numCT * scatSplit, kNumXcd) * numJG, 1), dim3(scatThreads), lds, st, dR, dXT2, dG,
-                                       N, gUnits, Cs, halo, numScatChunks, NT, 0, numCT * scatSplit, scatSplit, numJG, scatChunksPerSplit, (size_t)Grows * Cs, scatBlockChunks);
-                else
+                                       N, gUnits, Cs, halo, numScatChunks, NT, 0, numCT * scatSplit, scatSplit, numJG, scatChunksPerSplit, (size_t)Grows * Cs, scatBlockChunks, 0x7fffffff, 0, 0, 1, 0);
+                else if (scatRemCT && mergeRem) {
+                    // main strips and left-over strips in ONE launch (the left-over workgroups behind the main ones of every row)
+                    const int remPairs = scatRemCT * scatRemSplit;
+                    const int mainX = kNumXcd * ceil_div(mainCT, kNumXcd) * numJG, remX = kNumXcd * ceil_div(remPairs, kNumXcd) * numJG;
+                    hipLaunchKernelGGL(kern, dim3(mainX + remX, scatSplit), dim3(scatThreads), lds, st, dR, dXT2, dG,
+                                       N, gUnits, Cs, halo, numScatChunks, NT, 0, mainCT, 1, numJG, scatChunksPerSplit, (size_t)Grows * Cs, scatBlockChunks,
+                                       mainX, mainCT, remPairs, scatRemSplit, scatRemChunksPerSplit);
+                } else
                     hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(mainCT, kNumXcd) * numJG, scatSplit), dim3(scatThreads), lds, st, dR, dXT2, dG,
-                                       N, gUnits, Cs, halo, numScatChunks, NT, 0, mainCT, 1, numJG, scatChunksPerSplit, (size_t)Grows * Cs, scatBlockChunks);
+                                       N, gUnits, Cs, halo, numScatChunks, NT, 0, mainCT, 1, numJG, scatChunksPerSplit, (size_t)Grows * Cs, scatBlockChunks, 0x7fffffff, 0, 0, 1, 0);
                 if (scatRemCT) {
                     const int remPairs = scatRemCT * scatRemSplit;
-                    hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(remPairs, kNumXcd) * numJG, 1), dim3(scatThreads), lds, st, dR, dXT2, dG,
-                                       N, gUnits, Cs, halo, numScatChunks, NT, mainCT, remPairs, scatRemSplit, numJG, scatRemChunksPerSplit, (size_t)Grows * Cs, 0);
+                    if (!mergeRem)
+                        hipLaunchKernelGGL(kern, dim3(kNumXcd * ceil_div(remPairs, kNumXcd) * numJG, 1), dim3(scatThreads), lds, st, dR, dXT2, dG,
+                                           N, gUnits, Cs, halo, numScatChunks, NT, mainCT, remPairs, scatRemSplit, numJG, scatRemChunksPerSplit, (size_t)Grows * Cs, 0, 0x7fffffff, 0, 0, 1, 0);
                     const int col0 = mainCT * CW, ncols = Cs - col0;
                     hipLaunchKernelGGL(plm_sum_slabs_cols_kernel<T>, dim3((unsigned)(((size_t)Lq * ncols + 255) / 256)), dim3(256), 0, st, dG,
                                        (size_t)Grows * Cs, Cs, col0, ncols, Lq, scatRemSplit, scatSplit);

@@ -493,6 +493,30 @@ def test_fused_fx_sums_give_the_bits_of_the_separate_kernels():
     assert len(outs[0]) == 4 and outs[0] == outs[1], outs
 
 
+def test_left_over_strips_in_the_main_scatter_launch_give_the_same_bits():
+    """Round 6: the column strips left over after the full sets of eight ride behind the main strips' workgroups in ONE launch
+    (DCA_SCATTER_MERGE=0: a launch of their own, after the main one).  Every workgroup does what it did before: fx and the gradient are
+    equal to the last bit.  DCA_SCATTER_REM=1 forces the left-over launch wherever there are left-over strips (9 and 12 strips here)."""
+    import subprocess
+    code = (
+        "import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+        "from pydca_amd import _lib\n"
+        "for q, L, N in ((21, 50, 3000), (5, 300, 4000), (21, 200, 2500)):\n"
+        "    rng = np.random.default_rng(q * 100 + L); X = rng.integers(0, q, size=(N, L), dtype=np.uint8)\n"
+        "    ctx = _lib.Context(0, _lib.DCA_F32); ctx.set_msa(X, q); ctx.compute_weights(0.8, _lib.DCA_F32); ctx.plm_configure(1.0, 10.0); ctx.plm_init_x()\n"
+        "    ctx.plm_lbfgs_begin(100); st = ctx.plm_lbfgs_iterate(4)\n"
+        "    fx = ctx.plm_gradient(); g = ctx.plm_get_g()\n"
+        "    print(q, L, st.evaluations, repr(st.fx), repr(fx), hashlib.sha256(g.tobytes()).hexdigest())\n"
+        "    ctx.close()\n" % ROOT)
+    outs = []
+    for merge in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, DCA_SCATTER_MERGE=merge, DCA_SCATTER_REM="1"))
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(p.stdout.strip().splitlines()[-3:])
+    assert len(outs[0]) == 3 and outs[0] == outs[1], outs
+
+
 def test_scores_kernel(L_, oracle_mf):
     """FN / FN_APC kernel vs plmdca.py:437-524 restated in numpy (float64)."""
     rng = np.random.default_rng(3)
