@@ -359,6 +359,10 @@ int dca_spd_inverse(dca_ctx* ctx, const double* A, int n, double* Ainv_out);
  * for a kernel tag ("weights", "plm_logits", "plm_softmax", "plm_scatter", "plm_expand",
  * "plm_fold", "lbfgs_vec", "mf_counts", "mf_inverse", "scores"). */
 int dca_set_profiling(dca_ctx* ctx, int on);
+/* Only the stage of this name ("plm_scatter", "plm_logits", "mf_inverse", ...) is bracketed -- two event records per launch of it
+ * instead of two per stage (an event record costs the stream ~5 us: 14 per plmDCA iteration are 5 % of config C's step, 0.4 % of
+ * D's).  NULL or "" switches profiling off.  Measurement aid of bench.py's timed region; no reference counterpart. */
+int dca_set_profiling_only(dca_ctx* ctx, const char* stage);
 int dca_get_kernel_time(dca_ctx* ctx, const char* tag, double* ms_out, int* launches_out);
 int dca_reset_kernel_times(dca_ctx* ctx);
 

@@ -132,6 +132,7 @@ def lib():
         "dca_sw_align": (i, [C.c_char_p, i, C.c_char_p, i, vp, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p,
                              C.c_char_p, C.POINTER(i)]),
         "dca_set_profiling": (i, [vp, i]),
+        "dca_set_profiling_only": (i, [vp, C.c_char_p]),
         "dca_get_kernel_time": (i, [vp, C.c_char_p, C.POINTER(d), C.POINTER(i)]),
         "dca_reset_kernel_times": (i, [vp]),
         "plmdcaBackend": (C.c_void_p, [C.c_ushort, C.c_ushort, C.c_char_p, C.c_uint, C.c_float, C.c_float, C.c_float,
@@ -156,7 +157,7 @@ EXPORTS = ["dca_weights_work", "dca_compute_weights_sharded", "dca_weights_parti
            "dca_mf_di_scores", "dca_plm_pair_couplings", "dca_mf_fields", "dca_mf_pair_couplings",
            "dca_mf_single_site_freqs",
            "dca_mf_pair_site_freqs", "dca_mf_corr_mat", "dca_mf_couplings", "dca_mf_scores", "dca_mf_run",
-           "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_sw_scores", "dca_sw_align", "dca_scores_order", "dca_set_profiling", "dca_get_kernel_time",
+           "dca_mf_corr_from_freqs", "dca_spd_inverse", "dca_sw_scores", "dca_sw_align", "dca_scores_order", "dca_set_profiling", "dca_set_profiling_only", "dca_get_kernel_time",
            "dca_reset_kernel_times", "dca_plm_run", "plmdcaBackend", "freeFieldsAndCouplings"]
 
 
@@ -588,6 +589,10 @@ class Context:
     # ---- timing
     def set_profiling(self, on=True):
         check(self._l.dca_set_profiling(self._h, int(bool(on))))
+
+    def set_profiling_only(self, stage):
+        """Clock ONE stage only (None: profiling off): two event records per launch of it instead of two per stage."""
+        check(self._l.dca_set_profiling_only(self._h, stage.encode() if stage else None))
 
     def reset_kernel_times(self):
         check(self._l.dca_reset_kernel_times(self._h))

@@ -671,7 +671,14 @@ int dca_spd_inverse(dca_ctx* ctx, const double* A, int n, double* Ainv_out)
 }
 
 // ------------------------------------------------------------------ timing
-int dca_set_profiling(dca_ctx* ctx, int on) { if (!ctx) return DCA_ERR_ARG; ctx->profiling = on != 0; return DCA_OK; }
+int dca_set_profiling(dca_ctx* ctx, int on) { if (!ctx) return DCA_ERR_ARG; ctx->profiling = on != 0; ctx->profile_only.clear(); return DCA_OK; }
+int dca_set_profiling_only(dca_ctx* ctx, const char* stage)
+{
+    if (!ctx) return DCA_ERR_ARG;
+    ctx->profiling = stage && *stage;
+    ctx->profile_only = stage ? stage : "";
+    return DCA_OK;
+}
 int dca_reset_kernel_times(dca_ctx* ctx)
 {
     CHECK_CTX(ctx);

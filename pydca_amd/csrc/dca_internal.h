@@ -92,6 +92,7 @@ struct dca_ctx {
     size_t commStageBytes = 0;
 
     bool profiling = false;
+    std::string profile_only;      // non-empty: only the stage of this name is clocked (bench.py's timed region: the roofline kernel alone)
     std::map<std::string, KernelClock> clocks;
 };
 
@@ -102,6 +103,7 @@ struct ScopedKernelClock {
     hipEvent_t a = nullptr, b = nullptr;
     ScopedKernelClock(dca_ctx* c, const char* tag) : ctx(c) {
         if (!c->profiling) return;
+        if (!c->profile_only.empty() && c->profile_only != tag) return;
         kc = &c->clocks[tag];
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { kc = nullptr; return; }
         hipEventRecord(a, c->stream);
