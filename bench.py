@@ -680,8 +680,7 @@ def main():
                 # stage is plm_scatter_kernel (main strips and, when the strip count is not a multiple of 8, the left-over strips
                 # behind them in the same launch) + plm_sum_slabs_cols_kernel: a rocprofv3 kernel trace lists those separately
                 "stage_kernels": {"plm_logits": ["plm_logits_kernel"],
-                                  "plm_scatter": ["plm_scatter_kernel (main)", "plm_scatter_kernel (left-over strips)",
-                                                  "plm_sum_slabs_cols_kernel"]}[dom],
+                                  "plm_scatter": ["plm_scatter_kernel (main and left-over column strips in one launch)", "plm_sum_slabs_cols_kernel"]}[dom],
                 "gather_formulation": model["formulation"], "issued_adds_per_sequence_site_column": model[dom]["adds"],
                 "note": "gather kernel: bound on chip by the issue of the indexed packed adds (1 SALU + 1 VALU per 512-byte row piece), not by HBM; "
                         "peak = fp%d vector peak counted in adds" % (32 if args.precision == 32 else 64),
