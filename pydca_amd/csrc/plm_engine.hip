@@ -876,14 +876,58 @@ struct StripMap {
     const void* recv[kMaxStripRanks];
     int recvCs[kMaxStripRanks];
 };
+// g[h_i(a)] = 2 lambda_h h + sum_n R[n][(i,a)]; the column sum of R is the sum over b of
+// any site's rows of G (site 0 here).  (:463-471, :538-539, :573-578)
+// colSum (float64 mode): the column sums of R summed order-independently by plm_colsum_* below; else they are taken
+// from G as described above.
+template <typename T>
+__device__ __forceinline__ void fold_fields_body(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
+                                                 double* __restrict__ regPart, int Lq, int q, int Cs, T lambdaH, int addReg,
+                                                 size_t slabElems, int nsplit, const double* __restrict__ colSum, int blk)
+{
+    __shared__ double red[256];
+    const int c = blk * blockDim.x + threadIdx.x;
+    double reg = 0.0;
+    if (c < Lq) {
+        const T xv = x[c];
+        T gv = addReg ? (T)2 * lambdaH * xv : (T)0;
+        T s = 0;
+        if (colSum) s = (T)colSum[c];
+        else for (int b = 0; b < q; ++b) s += slab_sum(G, (size_t)b * Cs + c, slabElems, nsplit);
+        g[c] = gv + s;
+        if (addReg) reg = (double)lambdaH * (double)xv * (double)xv;
+    }
+    __shared__ double redLo[256];
+    red[threadIdx.x] = reg;
+    redLo[threadIdx.x] = 0.0;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) dd_add2(red[threadIdx.x], redLo[threadIdx.x], red[threadIdx.x + s], redLo[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { regPart[2 * (size_t)blk] = red[0]; regPart[2 * (size_t)blk + 1] = redLo[0]; }
+}
+template <typename T>
+__global__ void plm_fold_fields_kernel(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
+                                       double* __restrict__ regPart, int Lq, int q, int Cs, T lambdaH, int addReg,
+                                       size_t slabElems, int nsplit, const double* __restrict__ colSum)
+{
+    fold_fields_body<T>(x, G, g, regPart, Lq, q, Cs, lambdaH, addReg, slabElems, nsplit, colSum, (int)blockIdx.x);
+}
+// what the pair fold carries behind its own workgroups when the fields ride in its launch (one GPU: round 6)
+template <typename T> struct FoldFieldsArgs { const T* x; T* g; double* regPart; int Lq; T lambdaH; const double* colSum; int pairBlocks; };
 template <typename T>
 __global__ __launch_bounds__(64 * kFoldWaves)
 void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
                            const PairIJ* __restrict__ pairs, double* __restrict__ regPart,
                            int L, int q, int Cs, T lambdaJ, int addReg, size_t slabElems, int nsplit, int pairBegin, int pairEnd,
-                           const StripMap sm)
+                           const StripMap sm, const FoldFieldsArgs<T> ff)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dca_smem[];
+    if (ff.pairBlocks >= 0 && (int)blockIdx.x >= ff.pairBlocks) {      // the field fold's workgroups, behind the pairs'
+        fold_fields_body<T>(ff.x, G, ff.g, ff.regPart, ff.Lq, q, Cs, ff.lambdaH, addReg, slabElems, nsplit, ff.colSum, (int)blockIdx.x - ff.pairBlocks);
+        return;
+    }
     const int q2 = q * q;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     T* tile = reinterpret_cast<T*>(dca_smem) + (size_t)wave * ((q2 + 3) / 4 * 4);     // G[(j,b)][(i,a)] stored as tile[b*q+a]
@@ -923,38 +967,6 @@ void plm_fold_pairs_kernel(const T* __restrict__ x, const T* __restrict__ G, T* 
     }
     dd_wave_reduce(reg, regLo);                                               // fixed tree
     if (lane == 0) { regPart[2 * (size_t)p] = reg; regPart[2 * (size_t)p + 1] = regLo; }
-}
-
-// g[h_i(a)] = 2 lambda_h h + sum_n R[n][(i,a)]; the column sum of R is the sum over b of
-// any site's rows of G (site 0 here).  (:463-471, :538-539, :573-578)
-// colSum (float64 mode): the column sums of R summed order-independently by plm_colsum_* below; else they are taken
-// from G as described above.
-template <typename T>
-__global__ void plm_fold_fields_kernel(const T* __restrict__ x, const T* __restrict__ G, T* __restrict__ g,
-                                       double* __restrict__ regPart, int Lq, int q, int Cs, T lambdaH, int addReg,
-                                       size_t slabElems, int nsplit, const double* __restrict__ colSum)
-{
-    __shared__ double red[256];
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    double reg = 0.0;
-    if (c < Lq) {
-        const T xv = x[c];
-        T gv = addReg ? (T)2 * lambdaH * xv : (T)0;
-        T s = 0;
-        if (colSum) s = (T)colSum[c];
-        else for (int b = 0; b < q; ++b) s += slab_sum(G, (size_t)b * Cs + c, slabElems, nsplit);
-        g[c] = gv + s;
-        if (addReg) reg = (double)lambdaH * (double)xv * (double)xv;
-    }
-    __shared__ double redLo[256];
-    red[threadIdx.x] = reg;
-    redLo[threadIdx.x] = 0.0;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) dd_add2(red[threadIdx.x], redLo[threadIdx.x], red[threadIdx.x + s], redLo[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { regPart[2 * (size_t)blockIdx.x] = red[0]; regPart[2 * (size_t)blockIdx.x + 1] = redLo[0]; }
 }
 
 // ------------------------------------------------------------------ L-BFGS vector kernels
@@ -2063,6 +2075,12 @@ struct PlmEngine : PlmEngineBase {
                     hipLaunchKernelGGL(plm_colsum_parts_kernel<T>, dim3(ceil_div(LqLoc, 64), kColSumRowBlocks), dim3(256), 0, st, dR, N, Cs, LqLoc, dColPart);
                 hipLaunchKernelGGL(plm_colsum_final_kernel, dim3(ceil_div(LqLoc, 256)), dim3(256), 0, st, dColPart, kColSumRowBlocks, LqLoc, dColSum);
             }
+            // one GPU: the field fold's few workgroups ride behind the pair fold's in ONE launch (same threads, same sums; a launch
+            // boundary and a 5 - 11 us kernel less per evaluation); with strips the gradient-table rows travel in between
+            static const bool mergeFieldsEnv = !(getenv("DCA_FOLD_MERGE") && atoi(getenv("DCA_FOLD_MERGE")) == 0);
+            const int nOwnedPairs = pairEnd - pairBegin;
+            const bool mergeFields = mergeFieldsEnv && !strips && nOwnedPairs > 0;
+            if (!mergeFields)
             hipLaunchKernelGGL(plm_fold_fields_kernel<T>, dim3(ceil_div(LqLoc, 256)), dim3(256), 0, st, dx + (size_t)cS0 * q, dG, dg + (size_t)cS0 * q,
                                dRegPart + 2 * npairs, LqLoc, q, Cs, (T)lambda_h, add_reg, (size_t)Grows * Cs, foldSlabs, dColSum);
             StripMap sm;
@@ -2072,9 +2090,12 @@ struct PlmEngine : PlmEngineBase {
             if (strips && !stripEmulate) DCA_TRY(exchange_g());
             const size_t lds = (size_t)kFoldWaves * ((q * q + 3) / 4 * 4) * sizeof(T);
             const int nOwned = pairEnd - pairBegin;
-            if (nOwned > 0)
-                hipLaunchKernelGGL(plm_fold_pairs_kernel<T>, dim3((unsigned)ceil_div(nOwned, kFoldWaves)), dim3(64 * kFoldWaves), lds, st, dx, dG, dg, dPairs,
-                                   dRegPart, L, q, Cs, (T)lambda_J, add_reg, (size_t)Grows * Cs, foldSlabs, pairBegin, pairEnd, sm);
+            if (nOwned > 0) {
+                const int pairBlocks = ceil_div(nOwned, kFoldWaves);
+                FoldFieldsArgs<T> ff{dx + (size_t)cS0 * q, dg + (size_t)cS0 * q, dRegPart + 2 * npairs, LqLoc, (T)lambda_h, dColSum, mergeFields ? pairBlocks : -1};
+                hipLaunchKernelGGL(plm_fold_pairs_kernel<T>, dim3((unsigned)(pairBlocks + (mergeFields ? ceil_div(LqLoc, 256) : 0))), dim3(64 * kFoldWaves), lds, st, dx, dG, dg, dPairs,
+                                   dRegPart, L, q, Cs, (T)lambda_J, add_reg, (size_t)Grows * Cs, foldSlabs, pairBegin, pairEnd, sm, ff);
+            }
         }
         DCA_ROUND_STAGE(16, dg, P);
         // fx = regulariser + data term  -> ctx->dScal[0]

@@ -509,12 +509,13 @@ def test_left_over_strips_in_the_main_scatter_launch_give_the_same_bits():
         "    print(q, L, st.evaluations, repr(st.fx), repr(fx), hashlib.sha256(g.tobytes()).hexdigest())\n"
         "    ctx.close()\n" % ROOT)
     outs = []
-    for merge in ("1", "0"):
+    # the third run: the field fold as a launch of its own instead of behind the pair fold's workgroups (DCA_FOLD_MERGE=0)
+    for env in ({}, {"DCA_SCATTER_MERGE": "0"}, {"DCA_FOLD_MERGE": "0"}):
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, DCA_SCATTER_MERGE=merge, DCA_SCATTER_REM="1"))
+                           env=dict(os.environ, DCA_SCATTER_REM="1", **env))
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(p.stdout.strip().splitlines()[-3:])
-    assert len(outs[0]) == 3 and outs[0] == outs[1], outs
+    assert len(outs[0]) == 3 and outs[0] == outs[1] == outs[2], outs
 
 
 def test_scores_kernel(L_, oracle_mf):
